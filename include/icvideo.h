@@ -1,0 +1,113 @@
+/*
+ * icvideo.h — C ABI of libicvideo.so: hand-written HIP kernels (gfx950 / MI355X) for the
+ * buffer-conditioned Wan2.1 DiT denoising loop behind InfiniCube's
+ * `infinicube.videogen.WanVideoGenerator`.
+ *
+ * The reference has NO FFI for this path: its boundary is a Python class that forwards to the
+ * third-party `diffsynth` package [R infinicube/videogen/inference.py:25-26,216-226].  Each entry
+ * point below therefore cites the reference call site whose work it performs ("replaces") and
+ * the row of SURVEY.md §8(a-3) (K1..K13) that specifies its math.  The Python binding a
+ * maintainer adds is the ctypes stub in INTEGRATION.md (infinicube_amd/native.py is that stub).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / C++ types cross this boundary.
+ *   - Every tensor pointer is a BORROWED DEVICE pointer (HBM); the caller owns the memory.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it.
+ *   - Return 0 on success; non-zero = error, text via icv_last_error() (thread-local).
+ *   - bf16 = raw uint16 storage; "f32" = float.  Row-major everywhere; ld* are in ELEMENTS.
+ *   - head_dim is fixed at 128 (both Wan2.1 sizes).
+ */
+#ifndef ICVIDEO_H_
+#define ICVIDEO_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICV_ABI_VERSION 1
+
+/* ---- library / device ------------------------------------------------------------------ */
+int icv_abi_version(void);
+const char* icv_last_error(void);
+/* out[0]=multiprocessor (CU) count, out[1]=max LDS bytes per block, out[2]=gcn arch as int (950),
+ * out[3]=warp (wavefront) size.  Replaces nothing in the reference (device probing). */
+int icv_device_info(int device, int64_t out[4]);
+
+/* ---- GEMM with fused epilogues (K1, K2, K4, K7, K9, K10, K11 of SURVEY §8a-3) ------------
+ * C[M,N] = A[M,K] (bf16, lda) x W[N,K]^T (bf16, torch Linear layout, ldw)  (+ bias f32[N])
+ * Replaces the nn.Linear / Conv3d-as-GEMM calls inside diffsynth's WanModel reached from
+ * `self.pipe(...)` [R infinicube/videogen/inference.py:216-226].
+ * K must be a multiple of 64; N a multiple of 4; M arbitrary.
+ * Output column n lands in sub-buffer n / nsplit at column n % nsplit:
+ *   addr = out + (n / nsplit) * split_stride + m * ldo + (n % nsplit)   (nsplit = N: plain)
+ */
+enum {
+  ICV_EPI_BF16 = 0,       /* out bf16 = acc + bias                                        */
+  ICV_EPI_GELU_BF16 = 1,  /* out bf16 = gelu_tanh(acc + bias)                   (K10)     */
+  ICV_EPI_RESID_F32 = 2,  /* out f32  = resid[m,n] + gate[n] * (acc + bias)     (K7/K10)  */
+  ICV_EPI_F32 = 3         /* out f32  = acc + bias                              (K11)     */
+};
+int icv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                  int64_t M, int64_t N, int64_t K, int epilogue,
+                  void* out, int64_t ldo, int64_t nsplit, int64_t split_stride,
+                  const float* resid, int64_t ldr, const float* gate, void* stream);
+
+/* ---- small-M fp32 GEMV (K2: time embedding / time projection) ----------------------------
+ * out[m,n] = out_act( sum_k in_act(x[m,k]) * W[n,k] + bias[n] ),  x,out,bias f32; W bf16.
+ * act: 0 = identity, 1 = SiLU.  M <= 8.  K multiple of 8. */
+int icv_gemv_f32(const float* x, const void* W, const float* bias, float* out,
+                 int64_t M, int64_t N, int64_t K, int in_act, int out_act, void* stream);
+
+/* ---- K2 sinusoidal timestep embedding: out f32[dim] = cat[cos(t f_i), sin(t f_i)] -------- */
+int icv_sinusoidal_embedding(double timestep, int64_t dim, float* out, void* stream);
+
+/* ---- out[r, :] = a[r, :] + b[:]   (rows x n, f32): modulation + t_mod (Appendix A.4) ------ */
+int icv_bcast_add_f32(const float* a, const float* b, float* out, int64_t rows, int64_t n,
+                      void* stream);
+
+/* ---- K3 / K8: LayerNorm (fp32 stats) [+ affine] [+ adaLN modulate] -> bf16 ----------------
+ * out = (LN(x) * weight + bias) * (1 + scale) + shift ; any of weight/bias/scale/shift may be
+ * NULL.  x f32 [rows, d] (ldx), out bf16 [rows, d] (ldo).  d multiple of 256, d <= 8192. */
+int icv_ln_modulate(const float* x, int64_t ldx, const float* weight, const float* bias,
+                    const float* shift, const float* scale, void* out, int64_t ldo,
+                    int64_t rows, int64_t d, float eps, void* stream);
+
+/* ---- K5: RMSNorm over the full model dim (+ 3-D RoPE), in place on bf16 -------------------
+ * Up to two tensors per launch (q and k): x0/x1 bf16 [rows, d] (ld), w0/w1 f32 [d]; x1 may be
+ * NULL.  RoPE is applied when rope_tab != NULL: rope_tab = f32 (cos,sin) pairs laid out
+ * [T][22] ++ [Hp][21] ++ [Wp][21] (per-axis tables, angles computed in fp64 on the host),
+ * token index of local row r = tok0 + r, token -> (f, h, w) with w fastest. */
+int icv_rmsnorm_rope(void* x0, const float* w0, void* x1, const float* w1, int64_t ld,
+                     int64_t rows, int64_t d, float eps, const float* rope_tab,
+                     int64_t T, int64_t Hp, int64_t Wp, int64_t tok0, void* stream);
+
+/* ---- K6 / K9: flash attention forward, non-causal, head_dim 128, bf16 in/out --------------
+ * q [Sq, H*128] (ldq), k/v [Skv, H*128] (ldk/ldv), o [Sq, H*128] (ldo); fp32 softmax/accum.
+ * softmax(q k^T * scale) v per head.  Sq, Skv arbitrary (>0). */
+int icv_attention_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
+                      int64_t ldv, void* o, int64_t ldo, int64_t Sq, int64_t Skv, int64_t heads,
+                      float scale, void* stream);
+
+/* ---- K1: im2col for Conv3d(k = s = (1,2,2)) on a [C,T,H8,W8] f32 latent -------------------
+ * out bf16 [n_tok, C*4] (ldo), row = token tok0 + r (f, hp, wp; wp fastest),
+ * col = c*4 + y*2 + z  (== conv weight [d, C, 1, 2, 2] flattened). */
+int icv_patchify(const float* latent, int64_t C, int64_t T, int64_t H8, int64_t W8,
+                 void* out, int64_t ldo, int64_t tok0, int64_t n_tok, void* stream);
+
+/* ---- K11 tail + K12: unpatchify + CFG combine + Euler step, fused -------------------------
+ * For local tokens r in [0, n_tok): v = hu + cfg_scale * (hc - hu) (hu may be NULL -> v = hc);
+ * latent[c, f, 2hp+y, 2wp+z] += v[r, (y*2+z)*C + c] * dsigma.   hc/hu f32 [n_tok, 4*C] (ldh).
+ * If vel_out != NULL the combined velocity is also scattered there (same layout as latent). */
+int icv_unpatchify_cfg_euler(float* latent, float* vel_out, const float* hc, const float* hu,
+                             int64_t ldh, float cfg_scale, float dsigma, int64_t C, int64_t T,
+                             int64_t H8, int64_t W8, int64_t tok0, int64_t n_tok, void* stream);
+
+/* ---- dtype plumbing: f32 -> bf16 (round-to-nearest-even), n elements ---------------------- */
+int icv_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICVIDEO_H_ */

@@ -1,0 +1,42 @@
+// libicvideo: error reporting, version, device probing (plain C ABI, see include/icvideo.h).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "icv_common.h"
+
+static thread_local char g_err[512] = "";
+
+void icv_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int icv_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    icv_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return 2;
+  }
+  return 0;
+}
+
+extern "C" int icv_abi_version(void) { return ICV_ABI_VERSION; }
+extern "C" const char* icv_last_error(void) { return g_err; }
+
+extern "C" int icv_device_info(int device, int64_t out[4]) {
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) {
+    icv_set_error("icv_device_info: %s", hipGetErrorString(e));
+    return 2;
+  }
+  out[0] = prop.multiProcessorCount;
+  out[1] = (int64_t)prop.sharedMemPerBlock;
+  int arch = 0;
+  sscanf(prop.gcnArchName, "gfx%d", &arch);
+  out[2] = arch;
+  out[3] = prop.warpSize;
+  return 0;
+}

@@ -1,0 +1,23 @@
+#!/usr/bin/env bash
+# Build libicvideo.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+# Usage: infinicube_amd/csrc/build.sh [extra hipcc flags]
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+root="$(cd "$here/../.." && pwd)"
+out="$here/libicvideo.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$root/include" -I"$here" -Wno-unused-result)
+objs=()
+pids=()
+mkdir -p "$here/build"
+for src in api elementwise gemm attn; do
+  obj="$here/build/$src.o"
+  if [[ ! -f "$obj" || "$here/$src.hip" -nt "$obj" || "$here/icv_common.h" -nt "$obj" || "$root/include/icvideo.h" -nt "$obj" ]]; then
+    "$HIPCC" "${FLAGS[@]}" "$@" -c "$here/$src.hip" -o "$obj" &
+    pids+=($!)
+  fi
+  objs+=("$obj")
+done
+for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$out"
+echo "built $out"

@@ -1,0 +1,198 @@
+// bf16 MFMA GEMM with fused epilogues for the DiT projections.
+//   C[M,N] = A[M,K] x W[N,K]^T, both operands K-contiguous (torch Linear layout) -> both MFMA
+//   fragments are 16-byte K-slices, no transposes anywhere.
+//
+// v1 structure ("step-3" of the CDNA4 guide): 128x128x64 block tile, 4 waves (2x2), wave tile
+// 64x64 = 4x4 fragments of v_mfma_f32_16x16x32_bf16, fp32 accumulate.
+//   * HBM -> LDS by LDS-DMA (global_load_lds_dwordx4): no VGPR round trip.  The DMA destination
+//     is lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE address and
+//     mirrored on the ds_read_b128 side (same involution both sides).
+//   * LDS image per operand tile: [128 rows][8 chunks of 16 B]; physical chunk pc of row r holds
+//     logical chunk pc ^ ((r>>1)&7)  -> the 16 lanes of a ds_read_b128 service group hit 16
+//     distinct 16-B slots of the 256-B bank row (conflict-free).
+//   * Operands are swapped in the MFMA (W fragment as A-operand, A fragment as B-operand), so a
+//     lane ends up with 4 CONSECUTIVE n for one m: epilogue loads/stores are 8/16-byte vectors.
+//   * 1-D grid, XCD-aware remap (block b runs on XCD b%8 -> give each XCD a contiguous chunk of
+//     tiles) + grouped (8 m-tiles x all n-tiles) ordering so co-resident blocks share panels in L2.
+#include "icv_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+
+struct GemmParams {
+  const bf16_t* A; int64_t lda;
+  const bf16_t* W; int64_t ldw;
+  const float* bias;
+  int64_t M, N, K;
+  void* out; int64_t ldo; int64_t nsplit; int64_t split_stride;
+  const float* resid; int64_t ldr;
+  const float* gate;
+  int tiles_m, tiles_n;
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+// stage one 128x64 bf16 tile (rows row0.. of a [rows_total, ld] matrix, k-offset k0) into LDS
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ base, int64_t ld,
+                                           int64_t row0, int64_t rows_total, int64_t k0,
+                                           char* lds_tile, int tid) {
+  const int wave = tid >> 6;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int r = p * 32 + (tid >> 3);
+    const int pc = tid & 7;
+    const int c = pc ^ ((r >> 1) & 7);
+    int64_t gr = row0 + r;
+    gr = gr < rows_total ? gr : rows_total - 1;  // clamp: tail rows read valid memory, never stored
+    const bf16_t* src = base + gr * ld + k0 + c * 8;
+    char* dst = lds_tile + p * 4096 + wave * 1024;  // wave-uniform; HW adds lane*16
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- block -> tile: bijective XCD remap, then grouped ordering ----
+  const int nwg = p.tiles_m * p.tiles_n;
+  int wg;
+  {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  constexpr int GM = 8;
+  const int group_size = GM * p.tiles_n;
+  const int g = wg / group_size;
+  const int first_m = g * GM;
+  const int gm = min(p.tiles_m - first_m, GM);
+  const int tm = first_m + (wg % group_size) % gm;
+  const int tn = (wg % group_size) / gm;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nt = (int)(p.K / BK);
+  stage_tile(p.A, p.lda, m0, p.M, 0, smem, tid);
+  stage_tile(p.W, p.ldw, n0, p.N, 0, smem + TILE_BYTES, tid);
+  __syncthreads();
+
+  // per-lane fragment addressing (constant over the K loop)
+  const int fr = lane & 15;   // row within a 16-row fragment
+  const int kq = lane >> 4;   // which 8-wide k-chunk of a 32-wide k-step
+
+  for (int t = 0; t < nt; ++t) {
+    char* cur = smem + (t & 1) * STAGE_BYTES;
+    if (t + 1 < nt) {
+      char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
+      stage_tile(p.A, p.lda, m0, p.M, (int64_t)(t + 1) * BK, nxt, tid);
+      stage_tile(p.W, p.ldw, n0, p.N, (int64_t)(t + 1) * BK, nxt + TILE_BYTES, tid);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = wm * 64 + i * 16 + fr;
+        const int pc = (ks * 4 + kq) ^ ((r >> 1) & 7);
+        af[i] = *reinterpret_cast<const bf16x8*>(cur + r * 128 + pc * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = wn * 64 + j * 16 + fr;
+        const int pc = (ks * 4 + kq) ^ ((r >> 1) & 7);
+        wf[j] = *reinterpret_cast<const bf16x8*>(cur + TILE_BYTES + r * 128 + pc * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();  // next tile landed (vmcnt(0) inside) and everyone is done with `cur`
+  }
+
+  // ---- epilogue: lane owns m = fr, n = kq*4 + 0..3 of each 16x16 fragment ----
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + wm * 64 + i * 16 + fr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 16 + kq * 4;
+      if (n >= p.N) continue;
+      f32x4 v = acc[i][j];
+      if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      const int64_t sub = n / p.nsplit, col = n - sub * p.nsplit;
+      const int64_t off = sub * p.split_stride + m * p.ldo + col;
+      if (EPI == ICV_EPI_BF16 || EPI == ICV_EPI_GELU_BF16) {
+        if (EPI == ICV_EPI_GELU_BF16) {
+          v[0] = gelu_tanh(v[0]); v[1] = gelu_tanh(v[1]); v[2] = gelu_tanh(v[2]); v[3] = gelu_tanh(v[3]);
+        }
+        *reinterpret_cast<uint2*>((bf16_t*)p.out + off) =
+            make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      } else if (EPI == ICV_EPI_RESID_F32) {
+        const float4 r = *reinterpret_cast<const float4*>(p.resid + m * p.ldr + n);
+        float4 o;
+        if (p.gate) {
+          const float4 gt = *reinterpret_cast<const float4*>(p.gate + n);
+          o = make_float4(r.x + gt.x * v[0], r.y + gt.y * v[1], r.z + gt.z * v[2], r.w + gt.w * v[3]);
+        } else {
+          o = make_float4(r.x + v[0], r.y + v[1], r.z + v[2], r.w + v[3]);
+        }
+        *reinterpret_cast<float4*>((float*)p.out + off) = o;
+      } else {
+        *reinterpret_cast<float4*>((float*)p.out + off) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int icv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw,
+                             const float* bias, int64_t M, int64_t N, int64_t K, int epilogue,
+                             void* out, int64_t ldo, int64_t nsplit, int64_t split_stride,
+                             const float* resid, int64_t ldr, const float* gate, void* stream) {
+  ICV_REQUIRE(A && W && out, "icv_gemm_bf16: null pointer");
+  ICV_REQUIRE(M > 0 && N > 0 && K >= 64 && K % 64 == 0, "icv_gemm_bf16: K=%lld must be a positive multiple of 64", (long long)K);
+  ICV_REQUIRE(N % 4 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldo % 4 == 0, "icv_gemm_bf16: N%%4, lda%%8, ldw%%8, ldo%%4 alignment");
+  if (nsplit <= 0) nsplit = N;
+  ICV_REQUIRE(nsplit % 4 == 0 && N % nsplit == 0, "icv_gemm_bf16: nsplit must divide N and be a multiple of 4");
+  ICV_REQUIRE(epilogue != ICV_EPI_RESID_F32 || (resid && ldr % 4 == 0 && nsplit == N), "icv_gemm_bf16: RESID epilogue needs resid, ldr%%4==0, no split");
+  GemmParams p;
+  p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.bias = bias;
+  p.M = M; p.N = N; p.K = K; p.out = out; p.ldo = ldo; p.nsplit = nsplit; p.split_stride = split_stride;
+  p.resid = resid; p.ldr = ldr; p.gate = gate;
+  p.tiles_m = (int)((M + BM - 1) / BM);
+  p.tiles_n = (int)((N + BN - 1) / BN);
+  const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
+  ICV_REQUIRE(nwg < (1LL << 31), "icv_gemm_bf16: grid too large");
+  dim3 grid((unsigned)nwg), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  switch (epilogue) {
+    case ICV_EPI_BF16: hipLaunchKernelGGL(gemm_bf16_kernel<ICV_EPI_BF16>, grid, block, 0, st, p); break;
+    case ICV_EPI_GELU_BF16: hipLaunchKernelGGL(gemm_bf16_kernel<ICV_EPI_GELU_BF16>, grid, block, 0, st, p); break;
+    case ICV_EPI_RESID_F32: hipLaunchKernelGGL(gemm_bf16_kernel<ICV_EPI_RESID_F32>, grid, block, 0, st, p); break;
+    case ICV_EPI_F32: hipLaunchKernelGGL(gemm_bf16_kernel<ICV_EPI_F32>, grid, block, 0, st, p); break;
+    default: icv_set_error("icv_gemm_bf16: unknown epilogue %d", epilogue); return 1;
+  }
+  return icv_check_launch("icv_gemm_bf16");
+}

@@ -1,0 +1,83 @@
+"""ctypes binding of libicvideo.so (C ABI declared in include/icvideo.h).
+
+This is the stub a maintainer of the reference would add next to
+``infinicube/videogen/inference.py``.  There is NO fallback: if the shared
+library is missing or fails to load, importing ``lib()`` raises — the product path never routes
+through PyTorch eager or the oracle.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libicvideo.so")
+
+EPI_BF16, EPI_GELU_BF16, EPI_RESID_F32, EPI_F32 = 0, 1, 2, 3
+ACT_NONE, ACT_SILU = 0, 1
+
+# name -> (restype, argtypes); must list EVERY symbol include/icvideo.h declares
+# (tests/test_abi.py parses the header and checks this table and the .so against it).
+_P, _I, _F = c_void_p, c_int64, c_float
+SIGNATURES = {
+    "icv_abi_version": (c_int, []),
+    "icv_last_error": (c_char_p, []),
+    "icv_device_info": (c_int, [c_int, ctypes.POINTER(c_int64)]),
+    "icv_gemm_bf16": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, c_int, _P, _I, _I, _I, _P, _I, _P, _P]),
+    "icv_gemv_f32": (c_int, [_P, _P, _P, _P, _I, _I, _I, c_int, c_int, _P]),
+    "icv_sinusoidal_embedding": (c_int, [c_double, _I, _P, _P]),
+    "icv_bcast_add_f32": (c_int, [_P, _P, _P, _I, _I, _P]),
+    "icv_ln_modulate": (c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "icv_rmsnorm_rope": (c_int, [_P, _P, _P, _P, _I, _I, _I, _F, _P, _I, _I, _I, _I, _P]),
+    "icv_attention_fwd": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _F, _P]),
+    "icv_patchify": (c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
+    "icv_unpatchify_cfg_euler": (c_int, [_P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _I, _I, _P]),
+    "icv_cast_f32_to_bf16": (c_int, [_P, _P, _I, _P]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load libicvideo.so (once).  Raises NativeError loudly if it is absent or broken."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(
+            f"{LIB_PATH} not found: build it with infinicube_amd/csrc/build.sh "
+            "(or python -c 'import __graft_entry__ as g; g.build()').  There is no CPU/eager fallback.")
+    try:
+        l = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the box
+        raise NativeError(f"failed to load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(l, name)
+        except AttributeError as e:
+            raise NativeError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    got = l.icv_abi_version()
+    if got != 1:
+        raise NativeError(f"libicvideo ABI version {got}, binding expects 1")
+    _lib = l
+    return l
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().icv_last_error()
+        raise NativeError(f"{what or 'libicvideo'} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t) -> Optional[int]:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

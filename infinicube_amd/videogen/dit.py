@@ -1,0 +1,272 @@
+"""Host driver of the buffer-conditioned Wan2.1 DiT forward and denoising loop.
+
+This replaces what ``self.pipe(...)`` does inside its sampling loop
+[R infinicube/videogen/inference.py:216-226] — the diffsynth fork's ``WanModel.forward`` per step,
+twice (cond / uncond), plus CFG and the flow-match Euler update.
+All arithmetic runs in libicvideo HIP kernels through ``ops`` (ops.HipOps); this file owns the
+HBM layout, the step-invariant caches and the sequence-parallel schedule:
+
+  HBM layout (per rank, n = local tokens, d = model dim)
+    x        f32  [n, d]        residual stream (fp32: 288 GB of HBM3E makes this free, and it
+                                removes the bf16 round-off random walk over 3 adds x L layers x 100 forwards)
+    h        bf16 [n, d]        LN/modulate output -> GEMM A operand
+    qkv      bf16 [3, n, d]     q | k | v planes written by ONE fused QKV GEMM (split epilogue), so
+                                the K and V planes are contiguous all-gather send buffers
+    kv_full  bf16 [2, S, d]     gathered K, V (world > 1 only)
+    att      bf16 [n, d]        attention output -> O-projection A operand
+    ff       bf16 [n, ffn]      GELU(FFN1) output
+    weights  bf16 [N, K]        torch Linear layout == the K-contiguous B operand of the MFMA GEMM
+  Step-invariant caches: guidance-buffer tokens f32 [n, d] (once per generation; K1), text
+  embedding + per-layer cross-attention K/V bf16 [L, text_len, d] per CFG branch (K9), RoPE tables.
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+
+from .config import TokenGrid, WanDiTConfig
+from .ops import BF16, EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_F32, F32, RopeTable
+from .scheduler import FlowMatchScheduler
+from .seqpar import KVGather, ShardPlan
+
+ACT_SILU = 1
+
+
+@dataclass
+class ContextKV:
+    """Cross-attention keys/values of one prompt for all layers (step-invariant)."""
+    k: torch.Tensor  # bf16 [L, text_len, d]
+    v: torch.Tensor  # bf16 [L, text_len, d]
+
+
+class WanDiT:
+    def __init__(self, cfg: WanDiTConfig, state_dict: Dict[str, torch.Tensor], ops,
+                 buffer_embedder_sd: Optional[Dict[str, torch.Tensor]] = None):
+        self.cfg = cfg.validate()
+        self.ops = ops
+        d = cfg.dim
+        sd = state_dict
+        W = lambda name: ops.to_device(sd[name], BF16)   # noqa: E731  matrices: bf16 in HBM
+        V = lambda name: ops.to_device(sd[name], F32)    # noqa: E731  vectors: fp32
+
+        kp = cfg.in_dim * cfg.patch_elems
+        self.k_patch = ((kp + 63) // 64) * 64            # GEMM K granularity (i2v in_dim=36 -> 144 -> 192)
+        self.patch_w = self._pad_k(W("patch_embedding.weight").reshape(d, kp), self.k_patch)
+        self.patch_b = V("patch_embedding.bias")
+        self.text0_w, self.text0_b = W("text_embedding.0.weight"), V("text_embedding.0.bias")
+        self.text2_w, self.text2_b = W("text_embedding.2.weight"), V("text_embedding.2.bias")
+        self.time0_w, self.time0_b = W("time_embedding.0.weight"), V("time_embedding.0.bias")
+        self.time2_w, self.time2_b = W("time_embedding.2.weight"), V("time_embedding.2.bias")
+        self.tproj_w, self.tproj_b = W("time_projection.1.weight"), V("time_projection.1.bias")
+        self.head_w, self.head_b = W("head.head.weight"), V("head.head.bias")
+        self.head_mod = V("head.modulation").reshape(2, d).contiguous()
+        self.layers = []
+        mods = []
+        for i in range(cfg.num_layers):
+            p = f"blocks.{i}"
+            sa, ca = f"{p}.self_attn", f"{p}.cross_attn"
+            lw = dict(
+                wqkv=torch.cat([W(f"{sa}.q.weight"), W(f"{sa}.k.weight"), W(f"{sa}.v.weight")], 0).contiguous(),
+                bqkv=torch.cat([V(f"{sa}.q.bias"), V(f"{sa}.k.bias"), V(f"{sa}.v.bias")], 0).contiguous(),
+                nq=V(f"{sa}.norm_q.weight"), nk=V(f"{sa}.norm_k.weight"),
+                wo=W(f"{sa}.o.weight"), bo=V(f"{sa}.o.bias"),
+                n3w=V(f"{p}.norm3.weight"), n3b=V(f"{p}.norm3.bias"),
+                xq_w=W(f"{ca}.q.weight"), xq_b=V(f"{ca}.q.bias"),
+                xkv_w=torch.cat([W(f"{ca}.k.weight"), W(f"{ca}.v.weight")], 0).contiguous(),
+                xkv_b=torch.cat([V(f"{ca}.k.bias"), V(f"{ca}.v.bias")], 0).contiguous(),
+                xnq=V(f"{ca}.norm_q.weight"), xnk=V(f"{ca}.norm_k.weight"),
+                xo_w=W(f"{ca}.o.weight"), xo_b=V(f"{ca}.o.bias"),
+                f0_w=W(f"{p}.ffn.0.weight"), f0_b=V(f"{p}.ffn.0.bias"),
+                f2_w=W(f"{p}.ffn.2.weight"), f2_b=V(f"{p}.ffn.2.bias"),
+            )
+            self.layers.append(lw)
+            mods.append(V(f"{p}.modulation").reshape(6 * d))
+        self.modulation = torch.stack(mods, 0).contiguous()  # f32 [L, 6d]
+        self.buffer_embedder = None
+        if buffer_embedder_sd is not None:
+            self.load_buffer_embedder(buffer_embedder_sd)
+        self.plan: Optional[ShardPlan] = None
+
+    # ------------------------------------------------------------------------------------
+    @staticmethod
+    def _pad_k(w: torch.Tensor, k_to: int) -> torch.Tensor:
+        if w.shape[1] == k_to:
+            return w.contiguous()
+        out = torch.zeros((w.shape[0], k_to), dtype=w.dtype, device=w.device)
+        out[:, : w.shape[1]] = w
+        return out
+
+    def load_buffer_embedder(self, bsd: Dict[str, torch.Tensor]):
+        """Guidance-buffer embedder weights (strict).  Variant recovered from the key names:
+        'proj.*' = one conv over the channel-concatenated buffers (H1), '{semantic,coordinate}_proj.*'
+        = one conv per buffer (H2).  SURVEY.md §8a K1 — the fork's real layout is unknown ([EXT])."""
+        d, ops = self.cfg.dim, self.ops
+        keys = set(bsd.keys())
+        if keys == {"proj.weight", "proj.bias"}:
+            names = ["proj"]
+        elif keys == {"semantic_proj.weight", "semantic_proj.bias", "coordinate_proj.weight", "coordinate_proj.bias"}:
+            names = ["semantic_proj", "coordinate_proj"]
+        else:
+            raise KeyError(f"buffer embedder: unexpected keys {sorted(keys)} (strict load)")
+        convs = []
+        for nm in names:
+            w = ops.to_device(bsd[f"{nm}.weight"], BF16)
+            cin = w.shape[1]
+            k = cin * self.cfg.patch_elems
+            kpad = ((k + 63) // 64) * 64
+            convs.append(dict(w=self._pad_k(w.reshape(d, k), kpad), b=ops.to_device(bsd[f"{nm}.bias"], F32),
+                              cin=cin, k=kpad))
+        self.buffer_embedder = convs
+
+    # ------------------------------------------------------------------------------------
+    def prepare(self, grid: TokenGrid, plan: Optional[ShardPlan] = None, kv_gather=None):
+        """Allocate the per-generation workspace for this token grid / shard."""
+        cfg, ops = self.cfg, self.ops
+        self.grid = grid
+        self.plan = plan or ShardPlan.make(grid.S)
+        if self.plan.S != grid.S:
+            raise ValueError("shard plan does not match the token grid")
+        n, d, S = self.plan.n_tok, cfg.dim, grid.S
+        self.rope = RopeTable.build(grid.T, grid.Hp, grid.Wp, ops.device, cfg.head_dim)
+        a = ops.alloc
+        self.x = a((n, d), F32)
+        self.h = a((n, d), BF16)
+        self.qkv = a((3, n, d), BF16)
+        self.att = a((n, d), BF16)
+        self.ff = a((n, cfg.ffn_dim), BF16)
+        self.patches = torch.zeros((n, self.k_patch), dtype=BF16, device=ops.device)
+        self.head_out = a((2, n, cfg.out_dim * cfg.patch_elems), F32)
+        self.mod = a((cfg.num_layers, 6 * d), F32)
+        self.hmod = a((2, d), F32)
+        self.t_sin = a((1, cfg.freq_dim), F32)
+        self.t_a = a((1, d), F32)
+        self.t_e = a((1, d), F32)
+        self.t_mod = a((1, 6 * d), F32)
+        self._t_cached = None
+        if self.plan.world > 1:
+            self.kv_full = a((2, S, d), BF16)
+            self.kv_gather = kv_gather or KVGather(self.plan)
+        else:
+            self.kv_full, self.kv_gather = None, None
+        return self
+
+    # ------------------------------------------------------------------------------------
+    def encode_context(self, context: torch.Tensor) -> ContextKV:
+        """text_embedding MLP + every layer's cross-attention K (RMS-normed) and V; once per prompt."""
+        cfg, ops = self.cfg, self.ops
+        d, L = cfg.dim, cfg.num_layers
+        ctx = ops.to_device(context, BF16)
+        n = ctx.shape[0]
+        t1 = ops.alloc((n, d), BF16)
+        emb = ops.alloc((n, d), BF16)
+        ops.gemm(ctx, self.text0_w, self.text0_b, t1, EPI_GELU_BF16)
+        ops.gemm(t1, self.text2_w, self.text2_b, emb, EPI_BF16)
+        kv = ops.alloc((L, 2, n, d), BF16)
+        for i, lw in enumerate(self.layers):
+            ops.gemm(emb, lw["xkv_w"], lw["xkv_b"], kv[i], EPI_BF16, nsplit=d)
+            ops.rmsnorm_rope(kv[i, 0], lw["xnk"], eps=cfg.eps)
+        return ContextKV(kv[:, 0], kv[:, 1])
+
+    def embed_buffers(self, buffer_latents: torch.Tensor) -> torch.Tensor:
+        """Guidance-buffer tokens f32 [n, d] for this shard (step-invariant)."""
+        if self.buffer_embedder is None:
+            raise RuntimeError("buffer embedder not initialised")
+        ops, plan = self.ops, self.plan
+        bl = ops.to_device(buffer_latents, F32)
+        out = ops.alloc((plan.n_tok, self.cfg.dim), F32)
+        c0 = 0
+        for j, cv in enumerate(self.buffer_embedder):
+            part = bl[c0: c0 + cv["cin"]].contiguous()
+            c0 += cv["cin"]
+            pt = torch.zeros((plan.n_tok, cv["k"]), dtype=BF16, device=ops.device)
+            ops.patchify(part, pt, plan.tok0, plan.n_tok)
+            if j == 0:
+                ops.gemm(pt, cv["w"], cv["b"], out, EPI_F32)
+            else:
+                ops.gemm(pt, cv["w"], cv["b"], out, EPI_RESID_F32, resid=out)
+        if c0 != bl.shape[0]:
+            raise ValueError(f"buffer latents have {bl.shape[0]} channels, embedder consumes {c0}")
+        return out
+
+    # ------------------------------------------------------------------------------------
+    def _time_state(self, timestep: float):
+        """t = MLP(sinus(timestep)); t_mod = Linear(SiLU(t)); per-layer modulation tables (fp32)."""
+        if self._t_cached == timestep:
+            return
+        ops = self.ops
+        ops.sinusoidal(timestep, self.t_sin)
+        ops.gemv(self.t_sin, self.time0_w, self.time0_b, self.t_a, 0, ACT_SILU)
+        ops.gemv(self.t_a, self.time2_w, self.time2_b, self.t_e, 0, 0)
+        ops.gemv(self.t_e, self.tproj_w, self.tproj_b, self.t_mod, ACT_SILU, 0)
+        ops.bcast_add(self.modulation, self.t_mod, self.mod)      # [L,6d] + [6d]
+        ops.bcast_add(self.head_mod, self.t_e, self.hmod)         # [2,d] + [d]  (note: t, not t_mod)
+        self._t_cached = timestep
+
+    def forward_tokens(self, latent: torch.Tensor, ctx: ContextKV, timestep: float,
+                       buf_tokens: Optional[torch.Tensor], head_out: torch.Tensor,
+                       num_layers: Optional[int] = None):
+        """One DiT forward on this rank's token shard: latent f32 [C,T,H8,W8] (full, replicated) ->
+        head_out f32 [n, out_dim*4] (velocity in token space)."""
+        cfg, ops, plan = self.cfg, self.ops, self.plan
+        d, H, n, eps = cfg.dim, cfg.num_heads, plan.n_tok, cfg.eps
+        scale = 1.0 / math.sqrt(cfg.head_dim)
+        self._time_state(timestep)
+        # K1: patch embed (+ cached guidance-buffer tokens fused into the GEMM epilogue)
+        ops.patchify(latent, self.patches, plan.tok0, n)
+        if buf_tokens is not None:
+            ops.gemm(self.patches, self.patch_w, self.patch_b, self.x, EPI_RESID_F32, resid=buf_tokens)
+        else:
+            ops.gemm(self.patches, self.patch_w, self.patch_b, self.x, EPI_F32)
+        q, k, v = self.qkv[0], self.qkv[1], self.qkv[2]
+        L = cfg.num_layers if num_layers is None else num_layers
+        for i in range(L):
+            lw = self.layers[i]
+            m = self.mod[i]
+            sh1, sc1, g1 = m[0:d], m[d:2 * d], m[2 * d:3 * d]
+            sh2, sc2, g2 = m[3 * d:4 * d], m[4 * d:5 * d], m[5 * d:6 * d]
+            # --- self-attention ---
+            ops.ln_modulate(self.x, self.h, shift=sh1, scale=sc1, eps=eps)                  # K3
+            ops.gemm(self.h, lw["wqkv"], lw["bqkv"], self.qkv, EPI_BF16, nsplit=d)          # K4
+            ops.rmsnorm_rope(q, lw["nq"], k, lw["nk"], eps=eps, rope=self.rope, tok0=plan.tok0)  # K5
+            if plan.world > 1:
+                self.kv_gather(k, v, self.kv_full[0], self.kv_full[1])                      # K13
+                ops.attention(q, self.kv_full[0], self.kv_full[1], self.att, H, scale)      # K6
+            else:
+                ops.attention(q, k, v, self.att, H, scale)                                  # K6
+            ops.gemm(self.att, lw["wo"], lw["bo"], self.x, EPI_RESID_F32, resid=self.x, gate=g1)  # K7
+            # --- cross-attention to text (no gate) ---
+            ops.ln_modulate(self.x, self.h, weight=lw["n3w"], bias=lw["n3b"], eps=eps)      # K8
+            ops.gemm(self.h, lw["xq_w"], lw["xq_b"], q, EPI_BF16)                           # K9
+            ops.rmsnorm_rope(q, lw["xnq"], eps=eps)
+            ops.attention(q, ctx.k[i], ctx.v[i], self.att, H, scale)
+            ops.gemm(self.att, lw["xo_w"], lw["xo_b"], self.x, EPI_RESID_F32, resid=self.x)
+            # --- FFN ---
+            ops.ln_modulate(self.x, self.h, shift=sh2, scale=sc2, eps=eps)                  # K3
+            ops.gemm(self.h, lw["f0_w"], lw["f0_b"], self.ff, EPI_GELU_BF16)                # K10
+            ops.gemm(self.ff, lw["f2_w"], lw["f2_b"], self.x, EPI_RESID_F32, resid=self.x, gate=g2)
+        # K11: head
+        ops.ln_modulate(self.x, self.h, shift=self.hmod[0], scale=self.hmod[1], eps=eps)
+        ops.gemm(self.h, self.head_w, self.head_b, head_out, EPI_F32)
+
+    # ------------------------------------------------------------------------------------
+    def denoise(self, latent: torch.Tensor, ctx_cond: ContextKV, ctx_uncond: Optional[ContextKV],
+                buf_tokens: Optional[torch.Tensor], scheduler: FlowMatchScheduler,
+                cfg_scale: float = 5.0, steps: Optional[range] = None, on_step=None) -> torch.Tensor:
+        """The hot loop: per step 2 DiT forwards (cond, uncond) + fused unpatchify/CFG/Euler.
+        ``latent`` f32 [C,T,H8,W8] is updated IN PLACE for this rank's tokens."""
+        ops, plan = self.ops, self.plan
+        use_cfg = ctx_uncond is not None and cfg_scale != 1.0
+        for i in (steps if steps is not None else range(len(scheduler.sigmas))):
+            ts = scheduler.timesteps[i]
+            self.forward_tokens(latent, ctx_cond, ts, buf_tokens, self.head_out[0])
+            if use_cfg:
+                self.forward_tokens(latent, ctx_uncond, ts, buf_tokens, self.head_out[1])
+            ops.unpatchify_cfg_euler(latent, self.head_out[0], self.head_out[1] if use_cfg else None,
+                                     cfg_scale, scheduler.dsigma(i), plan.tok0, plan.n_tok)
+            if on_step is not None:
+                on_step(i, latent)
+        return latent

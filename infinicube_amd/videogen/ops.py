@@ -1,0 +1,175 @@
+"""Operator layer of the DiT host code: thin, checked wrappers that hand torch tensors' device
+pointers to the C ABI (include/icvideo.h).  PyTorch is plumbing here (HBM allocation, streams);
+every arithmetic op of the denoising loop runs in libicvideo's HIP kernels.
+
+The host driver (dit.py) is written against this small interface so that its sharding / caching
+logic can be exercised on CPU by the tests, which inject their own checker implementation
+(tests/oracle_ops.py).  The product never does that: ``HipOps`` is the only implementation in this
+package and it raises if the native library or a GPU is missing.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from .. import native
+from ..native import EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_F32  # noqa: F401 (re-export)
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@dataclass
+class RopeTable:
+    """Per-axis (cos, sin) f32 tables, concatenated [T][22] ++ [Hp][21] ++ [Wp][21] pairs
+    (SURVEY.md Appendix A.3); angles are computed in fp64 on the host."""
+    table: torch.Tensor  # f32 [(T*22 + Hp*21 + Wp*21), 2]
+    T: int
+    Hp: int
+    Wp: int
+
+    @staticmethod
+    def build(T: int, Hp: int, Wp: int, device, head_dim: int = 128, theta: float = 10000.0) -> "RopeTable":
+        hw = head_dim // 3
+        dims = (head_dim - 2 * hw, hw, hw)
+        parts = []
+        for axis_dim, n in zip(dims, (T, Hp, Wp)):
+            inv = 1.0 / (theta ** (torch.arange(0, axis_dim, 2, dtype=torch.float64)[: axis_dim // 2] / axis_dim))
+            ang = torch.outer(torch.arange(n, dtype=torch.float64), inv)
+            parts.append(torch.stack([torch.cos(ang), torch.sin(ang)], dim=-1).reshape(-1, 2))
+        tab = torch.cat(parts, dim=0).to(torch.float32).contiguous().to(device)
+        return RopeTable(tab, T, Hp, Wp)
+
+
+def _chk(t: torch.Tensor, dtype, name: str, last_contig: bool = True):
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if last_contig and t.dim() >= 1 and t.stride(-1) != 1:
+        raise ValueError(f"{name}: innermost dimension must be contiguous")
+
+
+class HipOps:
+    """The product operator set: every method enqueues one libicvideo kernel on the current
+    HIP stream of ``device``."""
+
+    name = "hip"
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise native.NativeError(
+                f"HipOps needs a ROCm GPU device ('cuda:N'), got {device!r}; there is no CPU fallback")
+        if not torch.cuda.is_available():
+            raise native.NativeError("HipOps: no GPU visible to PyTorch-ROCm; there is no CPU fallback")
+        self.lib = native.lib()
+
+    # -- helpers ---------------------------------------------------------------------------
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def alloc(self, shape, dtype) -> torch.Tensor:
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def to_device(self, t: torch.Tensor, dtype) -> torch.Tensor:
+        return t.detach().to(device=self.device, dtype=dtype).contiguous()
+
+    # -- kernels ---------------------------------------------------------------------------
+    def gemm(self, a, w, bias, out, epilogue, resid=None, gate=None, nsplit=None):
+        """out = epilogue(a @ w.T + bias).  a [M,K] bf16, w [N,K] bf16, bias f32[N] | None.
+        ``out`` is [M,N] (bf16 or f32 by epilogue), or [N/nsplit, M, nsplit] when nsplit is set."""
+        _chk(a, BF16, "gemm.a"); _chk(w, BF16, "gemm.w")
+        M, K = a.shape
+        N = w.shape[0]
+        if w.shape[1] != K:
+            raise ValueError(f"gemm: K mismatch {a.shape} x {w.shape}")
+        want = BF16 if epilogue in (EPI_BF16, EPI_GELU_BF16) else F32
+        _chk(out, want, "gemm.out")
+        if nsplit is None:
+            if tuple(out.shape) != (M, N):
+                raise ValueError(f"gemm: out shape {tuple(out.shape)} != {(M, N)}")
+            ldo, ns, sstride = out.stride(0), N, 0
+        else:
+            if tuple(out.shape) != (N // nsplit, M, nsplit):
+                raise ValueError(f"gemm: split out shape {tuple(out.shape)} != {(N // nsplit, M, nsplit)}")
+            ldo, ns, sstride = out.stride(1), nsplit, out.stride(0)
+        if bias is not None:
+            _chk(bias, F32, "gemm.bias")
+        if resid is not None:
+            _chk(resid, F32, "gemm.resid")
+        if gate is not None:
+            _chk(gate, F32, "gemm.gate")
+        native.check(self.lib.icv_gemm_bf16(
+            a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), native.ptr(bias), M, N, K, epilogue,
+            out.data_ptr(), ldo, ns, sstride, native.ptr(resid),
+            resid.stride(0) if resid is not None else 0, native.ptr(gate), self._stream()), "icv_gemm_bf16")
+
+    def gemv(self, x, w, bias, out, in_act=0, out_act=0):
+        _chk(x, F32, "gemv.x"); _chk(w, BF16, "gemv.w"); _chk(out, F32, "gemv.out")
+        M, K = x.shape
+        N = w.shape[0]
+        assert x.is_contiguous() and w.is_contiguous() and out.is_contiguous() and tuple(out.shape) == (M, N)
+        native.check(self.lib.icv_gemv_f32(x.data_ptr(), w.data_ptr(), native.ptr(bias), out.data_ptr(),
+                                           M, N, K, in_act, out_act, self._stream()), "icv_gemv_f32")
+
+    def sinusoidal(self, timestep: float, out):
+        _chk(out, F32, "sinusoidal.out")
+        native.check(self.lib.icv_sinusoidal_embedding(float(timestep), out.numel(), out.data_ptr(),
+                                                       self._stream()), "icv_sinusoidal_embedding")
+
+    def bcast_add(self, a, b, out):
+        _chk(a, F32, "bcast_add.a"); _chk(b, F32, "bcast_add.b"); _chk(out, F32, "bcast_add.out")
+        assert a.is_contiguous() and b.is_contiguous() and out.is_contiguous()
+        rows, n = a.numel() // b.numel(), b.numel()
+        native.check(self.lib.icv_bcast_add_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), rows, n,
+                                                self._stream()), "icv_bcast_add_f32")
+
+    def ln_modulate(self, x, out, weight=None, bias=None, shift=None, scale=None, eps=1e-6):
+        _chk(x, F32, "ln.x"); _chk(out, BF16, "ln.out")
+        rows, d = x.shape
+        native.check(self.lib.icv_ln_modulate(
+            x.data_ptr(), x.stride(0), native.ptr(weight), native.ptr(bias), native.ptr(shift),
+            native.ptr(scale), out.data_ptr(), out.stride(0), rows, d, eps, self._stream()), "icv_ln_modulate")
+
+    def rmsnorm_rope(self, x0, w0, x1=None, w1=None, eps=1e-6, rope: Optional[RopeTable] = None, tok0=0):
+        _chk(x0, BF16, "rms.x0"); _chk(w0, F32, "rms.w0")
+        rows, d = x0.shape
+        ld = x0.stride(0)
+        if x1 is not None:
+            _chk(x1, BF16, "rms.x1"); _chk(w1, F32, "rms.w1")
+            assert x1.shape == x0.shape and x1.stride(0) == ld
+        native.check(self.lib.icv_rmsnorm_rope(
+            x0.data_ptr(), w0.data_ptr(), native.ptr(x1), native.ptr(w1), ld, rows, d, eps,
+            rope.table.data_ptr() if rope is not None else None,
+            rope.T if rope else 0, rope.Hp if rope else 0, rope.Wp if rope else 0, tok0,
+            self._stream()), "icv_rmsnorm_rope")
+
+    def attention(self, q, k, v, o, heads: int, scale: float):
+        for t, nm in ((q, "q"), (k, "k"), (v, "v"), (o, "o")):
+            _chk(t, BF16, f"attention.{nm}")
+        native.check(self.lib.icv_attention_fwd(
+            q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
+            o.data_ptr(), o.stride(0), q.shape[0], k.shape[0], heads, scale, self._stream()),
+            "icv_attention_fwd")
+
+    def patchify(self, latent, out, tok0: int, n_tok: int):
+        _chk(latent, F32, "patchify.latent"); _chk(out, BF16, "patchify.out")
+        assert latent.is_contiguous()
+        C, T, H8, W8 = latent.shape
+        native.check(self.lib.icv_patchify(latent.data_ptr(), C, T, H8, W8, out.data_ptr(),
+                                           out.stride(0), tok0, n_tok, self._stream()), "icv_patchify")
+
+    def unpatchify_cfg_euler(self, latent, hc, hu, cfg_scale, dsigma, tok0, n_tok, vel_out=None):
+        _chk(latent, F32, "euler.latent"); _chk(hc, F32, "euler.hc")
+        assert latent.is_contiguous()
+        C, T, H8, W8 = latent.shape
+        native.check(self.lib.icv_unpatchify_cfg_euler(
+            latent.data_ptr(), native.ptr(vel_out), hc.data_ptr(), native.ptr(hu), hc.stride(0),
+            cfg_scale, dsigma, C, T, H8, W8, tok0, n_tok, self._stream()), "icv_unpatchify_cfg_euler")
+
+    def cast_bf16(self, src, out):
+        _chk(src, F32, "cast.src"); _chk(out, BF16, "cast.out")
+        assert src.is_contiguous() and out.is_contiguous() and src.numel() == out.numel()
+        native.check(self.lib.icv_cast_f32_to_bf16(src.data_ptr(), out.data_ptr(), src.numel(),
+                                                   self._stream()), "icv_cast_f32_to_bf16")

@@ -1,0 +1,123 @@
+"""Seeded synthetic weights / inputs of the Wan2.1 DiT shape (no checkpoints exist offline).
+
+Recipe from SURVEY.md §8d: Linear weights N(0, 0.02), biases N(0, 0.01),
+``modulation ~ N(0,1)/sqrt(d)``, norm affine weights 1 + N(0, 0.02), and a NON-ZERO buffer
+embedder (the reference zero-inits it [R infinicube/videogen/inference.py:86-88], which would
+make every conditioning test vacuous).  State-dict names follow the DiffSynth layout listed in
+SURVEY.md Appendix A.1 so real checkpoints load through the same code path.
+"""
+
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from .config import TokenGrid, WanDiTConfig
+
+
+def _randn(shape, std, seed, device, dtype):
+    if torch.device(device).type == "cpu":
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        return (torch.randn(shape, generator=g, dtype=torch.float32) * std).to(dtype)
+    g = torch.Generator(device=device).manual_seed(seed)
+    return (torch.randn(shape, generator=g, dtype=torch.float32, device=device) * std).to(dtype)
+
+
+def make_dit_state_dict(cfg: WanDiTConfig, seed: int = 0, device="cpu",
+                        dtype=torch.float32, weight_std: float = 0.02) -> Dict[str, torch.Tensor]:
+    """Random DiT weights.  ``device='cpu'`` is bit-reproducible everywhere (parity tests);
+    ``device='cuda'`` generates the 14B tensors directly in HBM (bench)."""
+    d, f = cfg.dim, cfg.ffn_dim
+    sd: Dict[str, torch.Tensor] = {}
+    counter = [seed * 100003]
+
+    def lin(name, n_out, n_in, std=weight_std):
+        counter[0] += 1
+        sd[f"{name}.weight"] = _randn((n_out, n_in), std, counter[0], device, dtype)
+        counter[0] += 1
+        sd[f"{name}.bias"] = _randn((n_out,), 0.01, counter[0], device, dtype)
+
+    def affine(name, n, with_bias=False):
+        counter[0] += 1
+        sd[f"{name}.weight"] = (1.0 + _randn((n,), 0.02, counter[0], device, torch.float32)).to(dtype)
+        if with_bias:
+            counter[0] += 1
+            sd[f"{name}.bias"] = _randn((n,), 0.01, counter[0], device, dtype)
+
+    counter[0] += 1
+    sd["patch_embedding.weight"] = _randn((d, cfg.in_dim) + tuple(cfg.patch), 0.02, counter[0], device, dtype)
+    counter[0] += 1
+    sd["patch_embedding.bias"] = _randn((d,), 0.01, counter[0], device, dtype)
+    lin("text_embedding.0", d, cfg.text_dim)
+    lin("text_embedding.2", d, d)
+    lin("time_embedding.0", d, cfg.freq_dim)
+    lin("time_embedding.2", d, d)
+    lin("time_projection.1", 6 * d, d)
+    for i in range(cfg.num_layers):
+        p = f"blocks.{i}"
+        for attn in ("self_attn", "cross_attn"):
+            for proj in ("q", "k", "v", "o"):
+                lin(f"{p}.{attn}.{proj}", d, d)
+            affine(f"{p}.{attn}.norm_q", d)
+            affine(f"{p}.{attn}.norm_k", d)
+        affine(f"{p}.norm3", d, with_bias=True)
+        lin(f"{p}.ffn.0", f, d)
+        lin(f"{p}.ffn.2", d, f)
+        counter[0] += 1
+        sd[f"{p}.modulation"] = _randn((1, 6, d), d ** -0.5, counter[0], device, dtype)
+    lin("head.head", cfg.out_dim * cfg.patch_elems, d)
+    counter[0] += 1
+    sd["head.modulation"] = _randn((1, 2, d), d ** -0.5, counter[0], device, dtype)
+    return sd
+
+
+def make_buffer_embedder_state_dict(cfg: WanDiTConfig, seed: int = 7, device="cpu",
+                                    dtype=torch.float32, variant: str = "concat",
+                                    zero_init: bool = False) -> Dict[str, torch.Tensor]:
+    """Buffer-embedder weights.  ``variant='concat'`` = hypothesis H1 of SURVEY.md §8a K1 (one
+    Conv3d over the two VAE-encoded buffers concatenated on channels); ``'dual'`` = H2 (one
+    Conv3d per buffer, summed)."""
+    d, c = cfg.dim, cfg.buffer_channels
+    std = 0.0 if zero_init else 0.02
+    sd: Dict[str, torch.Tensor] = {}
+    if variant == "concat":
+        sd["proj.weight"] = _randn((d, 2 * c) + tuple(cfg.patch), std, seed, device, dtype)
+        sd["proj.bias"] = _randn((d,), 0.0 if zero_init else 0.01, seed + 1, device, dtype)
+    elif variant == "dual":
+        for j, nm in enumerate(("semantic_proj", "coordinate_proj")):
+            sd[f"{nm}.weight"] = _randn((d, c) + tuple(cfg.patch), std, seed + 2 * j, device, dtype)
+            sd[f"{nm}.bias"] = _randn((d,), 0.0 if zero_init else 0.01, seed + 2 * j + 1, device, dtype)
+    else:
+        raise ValueError(f"unknown buffer embedder variant {variant!r}")
+    return sd
+
+
+def make_latent_noise(grid: TokenGrid, seed: int = 0, channels: int = 16) -> torch.Tensor:
+    """``randn((C,T,H/8,W/8), generator=cpu.manual_seed(seed), fp32)`` — the upstream noise recipe
+    (rand_device='cpu')."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randn((1,) + grid.latent_shape(channels), generator=g, dtype=torch.float32)[0]
+
+
+def make_text_context(cfg: WanDiTConfig, seed: int) -> torch.Tensor:
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randn((cfg.text_len, cfg.text_dim), generator=g, dtype=torch.float32) * 0.1
+
+
+def make_buffer_latents(cfg: WanDiTConfig, grid: TokenGrid, seed: int = 3) -> torch.Tensor:
+    """Stand-in for the two VAE-encoded guidance buffers: (2*buffer_channels, T, H/8, W/8)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randn(grid.latent_shape(2 * cfg.buffer_channels), generator=g, dtype=torch.float32)
+
+
+def make_dummy_buffers(grid: TokenGrid):
+    """cfg #1 'dummy guidance buffers' (SURVEY.md §8d): constant semantic, per-channel ramps."""
+    import numpy as np
+    n, h, w = grid.num_frames, grid.height, grid.width
+    sem = np.full((n, h, w, 3), 128, dtype=np.uint8)
+    co = np.empty((n, h, w, 3), dtype=np.uint8)
+    co[..., 0] = np.linspace(0, 255, w, dtype=np.float32).astype(np.uint8)[None, None, :]
+    co[..., 1] = np.linspace(0, 255, h, dtype=np.float32).astype(np.uint8)[None, :, None]
+    co[..., 2] = np.linspace(0, 255, n, dtype=np.float32).astype(np.uint8)[:, None, None]
+    return sem, co

@@ -1,0 +1,243 @@
+"""ORACLE — CPU restatement of the buffer-conditioned Wan2.1 DiT denoising loop.
+
+THIS IS TEST INFRASTRUCTURE.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import it.  Nothing under ``infinicube_amd/`` imports it, and the product
+path has no CPU fallback.
+
+** PARITY UNPINNED ** — the reference's arithmetic for this path lives in the third-party package
+``diffsynth @ git+https://github.com/yifanlu0227/DiffSynth-Studio-InfiniCube`` (no tag, no commit)
+[R pyproject.toml:71], which is absent from /root/reference and from this container, and the
+reference's only harness asserts nothing numeric [R infinicube/videogen/test_api.py:88-90].  What
+is restated here is the *published* Wan2.1 / DiffSynth ``wan_video_dit`` algorithm
+(every line tagged [EXT] there), anchored on the reference's own call sites:
+
+  * the nine kwargs of ``pipe(...)``                 [R infinicube/videogen/inference.py:216-226]
+  * ``initialize_buffer_embedder(16, zero_init)``    [R infinicube/videogen/inference.py:86-88]
+  * "embeds guidance buffers to tokens and adds to noisy tokens"  [R README.md:65]
+  * model list (DiT / UMT5 / Wan-VAE)                [R infinicube/videogen/inference.py:67-79]
+  * 480p = 480x832, 93-frame cap                     [R infinicube/inference/guidance_buffer_generation.py:79-82,744-745]
+
+Everything is plain PyTorch on CPU in ``dtype`` (fp32 by default, fp64 on request); RoPE angles
+and the sinusoidal embedding are computed in fp64 as upstream does.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------------------------
+# A.2 embeddings
+# --------------------------------------------------------------------------------------------
+def sinusoidal_embedding_1d(dim: int, position: Tensor) -> Tensor:
+    """cat[cos(t f_i), sin(t f_i)], f_i = 10000^(-i/(dim/2)), fp64 (Appendix A.2)."""
+    half = dim // 2
+    freqs = torch.pow(10000.0, -torch.arange(half, dtype=torch.float64) / half)
+    ang = torch.outer(position.to(torch.float64).reshape(-1), freqs)
+    return torch.cat([torch.cos(ang), torch.sin(ang)], dim=1)
+
+
+def time_embed(sd: Dict[str, Tensor], cfg, timestep: float, dtype=torch.float32) -> Tuple[Tensor, Tensor]:
+    """returns (t [d], t_mod [6, d])."""
+    emb = sinusoidal_embedding_1d(cfg.freq_dim, torch.tensor([timestep], dtype=torch.float64)).to(dtype)
+    t = F.linear(F.silu(F.linear(emb, sd["time_embedding.0.weight"].to(dtype), sd["time_embedding.0.bias"].to(dtype))),
+                 sd["time_embedding.2.weight"].to(dtype), sd["time_embedding.2.bias"].to(dtype))
+    t_mod = F.linear(F.silu(t), sd["time_projection.1.weight"].to(dtype), sd["time_projection.1.bias"].to(dtype))
+    return t[0], t_mod[0].reshape(6, cfg.dim)
+
+
+def text_embed(sd: Dict[str, Tensor], context: Tensor, dtype=torch.float32) -> Tensor:
+    h = F.linear(context.to(dtype), sd["text_embedding.0.weight"].to(dtype), sd["text_embedding.0.bias"].to(dtype))
+    h = F.gelu(h, approximate="tanh")
+    return F.linear(h, sd["text_embedding.2.weight"].to(dtype), sd["text_embedding.2.bias"].to(dtype))
+
+
+# --------------------------------------------------------------------------------------------
+# A.3 RoPE-3D
+# --------------------------------------------------------------------------------------------
+def rope_axis_dims(head_dim: int) -> Tuple[int, int, int]:
+    """(44, 42, 42) real dims for head_dim 128: f gets the remainder."""
+    hw = head_dim // 3
+    return head_dim - 2 * hw, hw, hw
+
+
+def rope_axis_angles(axis_dim: int, n_pos: int, theta: float = 10000.0) -> Tensor:
+    """[n_pos, axis_dim/2] fp64 angles pos * theta^(-2j/axis_dim)."""
+    inv = 1.0 / (theta ** (torch.arange(0, axis_dim, 2, dtype=torch.float64)[: axis_dim // 2] / axis_dim))
+    return torch.outer(torch.arange(n_pos, dtype=torch.float64), inv)
+
+
+def rope_freqs_3d(head_dim: int, T: int, Hp: int, Wp: int) -> Tensor:
+    """complex128 [T*Hp*Wp, head_dim/2]: first 22 pairs <- frame, next 21 <- row, last 21 <- col."""
+    df, dh, dw = rope_axis_dims(head_dim)
+    af, ah, aw = rope_axis_angles(df, T), rope_axis_angles(dh, Hp), rope_axis_angles(dw, Wp)
+    ang = torch.cat([
+        af[:, None, None, :].expand(T, Hp, Wp, -1),
+        ah[None, :, None, :].expand(T, Hp, Wp, -1),
+        aw[None, None, :, :].expand(T, Hp, Wp, -1)], dim=-1).reshape(T * Hp * Wp, -1)
+    return torch.polar(torch.ones_like(ang), ang)
+
+
+def rope_apply(x: Tensor, freqs: Tensor, num_heads: int) -> Tensor:
+    """x [S, heads*hd]; rotate adjacent pairs (2i, 2i+1) in complex128, cast back."""
+    S = x.shape[0]
+    xc = torch.view_as_complex(x.to(torch.float64).reshape(S, num_heads, -1, 2))
+    out = torch.view_as_real(xc * freqs[:, None, :]).reshape(S, -1)
+    return out.to(x.dtype)
+
+
+# --------------------------------------------------------------------------------------------
+# A.4 block
+# --------------------------------------------------------------------------------------------
+def rms_norm(x: Tensor, w: Tensor, eps: float) -> Tensor:
+    return x * torch.rsqrt(x.pow(2).mean(dim=-1, keepdim=True) + eps) * w
+
+
+def layer_norm(x: Tensor, w: Optional[Tensor], b: Optional[Tensor], eps: float) -> Tensor:
+    return F.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+def modulate(x: Tensor, shift: Tensor, scale: Tensor) -> Tensor:
+    return x * (1.0 + scale) + shift
+
+
+def attention(q: Tensor, k: Tensor, v: Tensor, num_heads: int) -> Tensor:
+    """q [Sq, H*hd], k/v [Sk, H*hd] -> [Sq, H*hd]; non-causal softmax(q k^T / sqrt(hd)) v."""
+    Sq, Sk = q.shape[0], k.shape[0]
+    qh = q.reshape(Sq, num_heads, -1).transpose(0, 1)
+    kh = k.reshape(Sk, num_heads, -1).transpose(0, 1)
+    vh = v.reshape(Sk, num_heads, -1).transpose(0, 1)
+    o = F.scaled_dot_product_attention(qh[None], kh[None], vh[None])[0]
+    return o.transpose(0, 1).reshape(Sq, -1)
+
+
+def _lin(sd, name, x, dtype):
+    return F.linear(x, sd[f"{name}.weight"].to(dtype), sd[f"{name}.bias"].to(dtype))
+
+
+def dit_block(sd: Dict[str, Tensor], cfg, i: int, x: Tensor, ctx: Tensor, t_mod: Tensor,
+              freqs: Tensor, dtype=torch.float32, kv_override=None) -> Tensor:
+    p = f"blocks.{i}"
+    mod = sd[f"{p}.modulation"].to(dtype).reshape(6, cfg.dim) + t_mod
+    sh1, sc1, g1, sh2, sc2, g2 = mod.unbind(0)
+    H, eps = cfg.num_heads, cfg.eps
+    # self-attention
+    h = modulate(layer_norm(x, None, None, eps), sh1, sc1)
+    q = rope_apply(rms_norm(_lin(sd, f"{p}.self_attn.q", h, dtype), sd[f"{p}.self_attn.norm_q.weight"].to(dtype), eps), freqs, H)
+    k = rope_apply(rms_norm(_lin(sd, f"{p}.self_attn.k", h, dtype), sd[f"{p}.self_attn.norm_k.weight"].to(dtype), eps), freqs, H)
+    v = _lin(sd, f"{p}.self_attn.v", h, dtype)
+    if kv_override is not None:  # sequence-parallel tests: attend over gathered K/V
+        k, v = kv_override(k, v)
+    x = x + g1 * _lin(sd, f"{p}.self_attn.o", attention(q, k, v, H), dtype)
+    # cross-attention to text (no gate)
+    h = layer_norm(x, sd[f"{p}.norm3.weight"].to(dtype), sd[f"{p}.norm3.bias"].to(dtype), eps)
+    q = rms_norm(_lin(sd, f"{p}.cross_attn.q", h, dtype), sd[f"{p}.cross_attn.norm_q.weight"].to(dtype), eps)
+    k = rms_norm(_lin(sd, f"{p}.cross_attn.k", ctx, dtype), sd[f"{p}.cross_attn.norm_k.weight"].to(dtype), eps)
+    v = _lin(sd, f"{p}.cross_attn.v", ctx, dtype)
+    x = x + _lin(sd, f"{p}.cross_attn.o", attention(q, k, v, H), dtype)
+    # FFN
+    h = modulate(layer_norm(x, None, None, eps), sh2, sc2)
+    h = F.gelu(_lin(sd, f"{p}.ffn.0", h, dtype), approximate="tanh")
+    return x + g2 * _lin(sd, f"{p}.ffn.2", h, dtype)
+
+
+# --------------------------------------------------------------------------------------------
+# patchify / unpatchify / buffer embedder / head
+# --------------------------------------------------------------------------------------------
+def patchify_tokens(latent: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    """Conv3d(C->d, k=s=(1,2,2)) then 'c f h w -> (f h w) c'."""
+    y = F.conv3d(latent[None], w, b, stride=tuple(w.shape[2:]))[0]
+    return y.reshape(y.shape[0], -1).transpose(0, 1).contiguous()
+
+
+def buffer_embed(bsd: Dict[str, Tensor], buffer_latents: Tensor, dtype=torch.float32) -> Tensor:
+    """Guidance-buffer tokens [S, d] (step-invariant).  H1 'concat' or H2 'dual' (SURVEY §8a K1)."""
+    bl = buffer_latents.to(dtype)
+    if "proj.weight" in bsd:
+        return patchify_tokens(bl, bsd["proj.weight"].to(dtype), bsd["proj.bias"].to(dtype))
+    c = bl.shape[0] // 2
+    return (patchify_tokens(bl[:c], bsd["semantic_proj.weight"].to(dtype), bsd["semantic_proj.bias"].to(dtype))
+            + patchify_tokens(bl[c:], bsd["coordinate_proj.weight"].to(dtype), bsd["coordinate_proj.bias"].to(dtype)))
+
+
+def unpatchify(x: Tensor, grid: Tuple[int, int, int], out_dim: int, patch=(1, 2, 2)) -> Tensor:
+    """'(f h w) (x y z c) -> c (f x) (h y) (w z)'."""
+    f, h, w = grid
+    px, py, pz = patch
+    y = x.reshape(f, h, w, px, py, pz, out_dim).permute(6, 0, 3, 1, 4, 2, 5)
+    return y.reshape(out_dim, f * px, h * py, w * pz)
+
+
+def head(sd: Dict[str, Tensor], cfg, x: Tensor, t: Tensor, dtype=torch.float32) -> Tensor:
+    mod = sd["head.modulation"].to(dtype).reshape(2, cfg.dim) + t[None, :]
+    shift, scale = mod.unbind(0)
+    return _lin(sd, "head.head", modulate(layer_norm(x, None, None, cfg.eps), shift, scale), dtype)
+
+
+def dit_forward(sd: Dict[str, Tensor], cfg, latent: Tensor, context: Tensor, timestep: float,
+                buf_tokens: Optional[Tensor] = None, dtype=torch.float32,
+                num_layers: Optional[int] = None, return_tokens: bool = False) -> Tensor:
+    """One DiT forward: latent [C,T,H8,W8], raw text context [text_len, text_dim] -> velocity
+    [out_dim, T, H8, W8]."""
+    C, T, H8, W8 = latent.shape
+    grid = (T // cfg.patch[0], H8 // cfg.patch[1], W8 // cfg.patch[2])
+    t, t_mod = time_embed(sd, cfg, timestep, dtype)
+    ctx = text_embed(sd, context, dtype)
+    x = patchify_tokens(latent.to(dtype), sd["patch_embedding.weight"].to(dtype), sd["patch_embedding.bias"].to(dtype))
+    if buf_tokens is not None:
+        x = x + buf_tokens.to(dtype)
+    freqs = rope_freqs_3d(cfg.head_dim, *grid)
+    for i in range(cfg.num_layers if num_layers is None else num_layers):
+        x = dit_block(sd, cfg, i, x, ctx, t_mod, freqs, dtype)
+    if return_tokens:
+        return x
+    return unpatchify(head(sd, cfg, x, t, dtype), grid, cfg.out_dim, cfg.patch)
+
+
+# --------------------------------------------------------------------------------------------
+# A.5 / A.6 sampler + CFG loop
+# --------------------------------------------------------------------------------------------
+def flow_match_sigmas(num_steps: int, shift: float = 5.0) -> Tensor:
+    s = torch.linspace(1.0, 0.0, num_steps + 1, dtype=torch.float64)[:-1]
+    return shift * s / (1.0 + (shift - 1.0) * s)
+
+
+def denoise_loop(sd, bsd, cfg, noise: Tensor, ctx_cond: Tensor, ctx_uncond: Tensor,
+                 buffer_latents: Optional[Tensor], num_steps: int = 50, cfg_scale: float = 5.0,
+                 shift: float = 5.0, dtype=torch.float32, trace: Optional[list] = None) -> Tensor:
+    """for sigma in sigmas: v = v_u + s (v_c - v_u); x += v (sigma_next - sigma)."""
+    sig = flow_match_sigmas(num_steps, shift)
+    buf = buffer_embed(bsd, buffer_latents, dtype) if buffer_latents is not None else None
+    x = noise.to(dtype).clone()
+    for i in range(num_steps):
+        ts = float(sig[i]) * 1000.0
+        v_c = dit_forward(sd, cfg, x, ctx_cond, ts, buf, dtype)
+        if cfg_scale != 1.0:
+            v_u = dit_forward(sd, cfg, x, ctx_uncond, ts, buf, dtype)
+            v = v_u + cfg_scale * (v_c - v_u)
+        else:
+            v = v_c
+        nxt = float(sig[i + 1]) if i + 1 < num_steps else 0.0
+        x = x + v * (nxt - float(sig[i]))
+        if trace is not None:
+            trace.append(x.clone())
+    return x
+
+
+def round_state_dict_to_bf16(sd: Dict[str, Tensor]) -> Dict[str, Tensor]:
+    """Matrices are stored in bf16 by the product; give the oracle the same rounded values so a
+    parity gap measures kernel arithmetic, not weight quantisation (SURVEY.md §8d tolerance)."""
+    return {k: v.to(torch.bfloat16).to(torch.float32) for k, v in sd.items()}
+
+
+def psnr(a: Tensor, b: Tensor) -> float:
+    a, b = a.double(), b.double()
+    mse = float(((a - b) ** 2).mean())
+    peak = float(b.abs().max())
+    return float("inf") if mse == 0 else 10.0 * math.log10(peak * peak / mse)

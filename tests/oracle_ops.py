@@ -1,0 +1,109 @@
+"""TEST-ONLY operator set: the ops.HipOps interface implemented with the CPU oracle's arithmetic.
+
+Lets the `-m "not gpu"` tests drive the product's host logic (infinicube_amd/videogen/dit.py:
+weight packing, caches, split-QKV layout, sequence-parallel sharding, the fused unpatchify/CFG/
+Euler indexing) on CPU, and gives the GPU tests a rounding-point-exact emulation of the HIP
+pipeline (fp32 math, bf16 storage where the C ABI stores bf16).  The product never imports this.
+"""
+
+from __future__ import annotations
+
+import math
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import wan_ref as R  # noqa: E402
+
+BF16, F32 = torch.bfloat16, torch.float32
+EPI_BF16, EPI_GELU_BF16, EPI_RESID_F32, EPI_F32 = 0, 1, 2, 3
+
+
+class OracleOps:
+    name = "oracle-cpu"
+
+    def __init__(self, device="cpu"):
+        self.device = torch.device(device)
+
+    def alloc(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def to_device(self, t, dtype):
+        return t.detach().to(device=self.device, dtype=dtype).contiguous()
+
+    def gemm(self, a, w, bias, out, epilogue, resid=None, gate=None, nsplit=None):
+        assert a.dtype == BF16 and w.dtype == BF16
+        acc = a.float() @ w.float().t()
+        if bias is not None:
+            acc = acc + bias
+        if epilogue == EPI_GELU_BF16:
+            acc = F.gelu(acc, approximate="tanh")
+        if epilogue == EPI_RESID_F32:
+            acc = resid + (gate * acc if gate is not None else acc)
+        if nsplit is None:
+            out.copy_(acc.to(out.dtype))
+        else:
+            M, N = acc.shape
+            out.copy_(acc.reshape(M, N // nsplit, nsplit).permute(1, 0, 2).to(out.dtype))
+
+    def gemv(self, x, w, bias, out, in_act=0, out_act=0):
+        xi = F.silu(x) if in_act == 1 else x
+        y = xi @ w.float().t()
+        if bias is not None:
+            y = y + bias
+        out.copy_(F.silu(y) if out_act == 1 else y)
+
+    def sinusoidal(self, timestep, out):
+        out.copy_(R.sinusoidal_embedding_1d(out.numel(), torch.tensor([timestep], dtype=torch.float64))
+                  .to(F32).reshape(out.shape))
+
+    def bcast_add(self, a, b, out):
+        out.copy_((a.reshape(-1, b.numel()) + b.reshape(1, -1)).reshape(out.shape))
+
+    def ln_modulate(self, x, out, weight=None, bias=None, shift=None, scale=None, eps=1e-6):
+        y = R.layer_norm(x, weight, bias, eps)
+        if scale is not None:
+            y = y * (1.0 + scale)
+        if shift is not None:
+            y = y + shift
+        out.copy_(y.to(BF16))
+
+    def rmsnorm_rope(self, x0, w0, x1=None, w1=None, eps=1e-6, rope=None, tok0=0):
+        for x, w in ((x0, w0), (x1, w1)):
+            if x is None:
+                continue
+            y = R.rms_norm(x.float(), w, eps)
+            if rope is not None:
+                freqs = R.rope_freqs_3d(128, rope.T, rope.Hp, rope.Wp)[tok0: tok0 + x.shape[0]]
+                y = R.rope_apply(y, freqs, x.shape[1] // 128)
+            x.copy_(y.to(BF16))
+
+    def attention(self, q, k, v, o, heads, scale):
+        assert abs(scale - 1.0 / math.sqrt(q.shape[1] // heads)) < 1e-9
+        o.copy_(R.attention(q.float(), k.float(), v.float(), heads).to(BF16))
+
+    def patchify(self, latent, out, tok0, n_tok):
+        C, T, H8, W8 = latent.shape
+        Hp, Wp = H8 // 2, W8 // 2
+        tok = latent.reshape(C, T, Hp, 2, Wp, 2).permute(1, 2, 4, 0, 3, 5).reshape(T * Hp * Wp, C * 4)
+        out[:, : C * 4].copy_(tok[tok0: tok0 + n_tok].to(BF16))
+
+    def unpatchify_cfg_euler(self, latent, hc, hu, cfg_scale, dsigma, tok0, n_tok, vel_out=None):
+        C, T, H8, W8 = latent.shape
+        Hp, Wp = H8 // 2, W8 // 2
+        v = hc if hu is None else hu + cfg_scale * (hc - hu)
+        full = torch.zeros((T * Hp * Wp, 4 * C), dtype=F32)
+        full[tok0: tok0 + n_tok] = v
+        vel = R.unpatchify(full, (T, Hp, Wp), C)
+        mask = torch.zeros((T * Hp * Wp, 4 * C), dtype=F32)
+        mask[tok0: tok0 + n_tok] = 1.0
+        m = R.unpatchify(mask, (T, Hp, Wp), C)
+        latent.add_(vel * m * dsigma)
+        if vel_out is not None:
+            vel_out.copy_(torch.where(m > 0, vel, vel_out))
+
+    def cast_bf16(self, src, out):
+        out.copy_(src.to(BF16))
