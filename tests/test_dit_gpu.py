@@ -1,0 +1,74 @@
+"""End-to-end parity of the HIP DiT path (host driver + C ABI kernels) against the CPU oracle.
+
+Bars: one forward cosine >= 0.999 and rel-L2 <= 2e-2; denoise loop final-latent
+PSNR >= 40 dB vs the fp32 oracle fed the same bf16-rounded weights.
+"""
+import pytest
+import torch
+
+from oracle import wan_ref as R
+from oracle_ops import OracleOps
+from infinicube_amd.videogen import synthetic as syn
+from infinicube_amd.videogen.config import TokenGrid, preset
+from infinicube_amd.videogen.dit import WanDiT
+from infinicube_amd.videogen.scheduler import FlowMatchScheduler
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(name, grid, variant="concat"):
+    cfg = preset(name)
+    sd = syn.make_dit_state_dict(cfg)
+    bsd = syn.make_buffer_embedder_state_dict(cfg, variant=variant)
+    return cfg, sd, bsd, R.round_state_dict_to_bf16(sd), R.round_state_dict_to_bf16(bsd)
+
+
+@pytest.mark.parametrize("name,grid,variant", [
+    ("tiny", TokenGrid(5, 64, 96), "concat"),
+    ("tiny", TokenGrid(9, 80, 112), "dual"),
+    ("small", TokenGrid(17, 128, 160), "concat"),
+])
+def test_forward_parity(hip_ops, name, grid, variant):
+    cfg, sd, bsd, sdr, bsdr = _setup(name, grid, variant)
+    noise, ctx = syn.make_latent_noise(grid), syn.make_text_context(cfg, 1)
+    bl = syn.make_buffer_latents(cfg, grid)
+    m = WanDiT(cfg, sd, hip_ops, bsd).prepare(grid)
+    ck = m.encode_context(ctx)
+    bt = m.embed_buffers(bl)
+    lat = noise.to("cuda:0")
+    m.forward_tokens(lat, ck, 731.0, bt, m.head_out[0])
+    torch.cuda.synchronize()
+    v = R.unpatchify(m.head_out[0].cpu(), (grid.T, grid.Hp, grid.Wp), cfg.out_dim)
+    vref = R.dit_forward(sdr, cfg, noise, ctx, 731.0, R.buffer_embed(bsdr, bl))
+    rel = float((v - vref).norm() / vref.norm())
+    cos = float(torch.nn.functional.cosine_similarity(v.flatten(), vref.flatten(), dim=0))
+    assert cos >= 0.999 and rel <= 2e-2, f"forward parity: cos={cos} rel-L2={rel}"
+    # the buffer conditioning must actually matter (non-zero embedder) and be applied
+    m.forward_tokens(lat, ck, 731.0, None, m.head_out[1])
+    torch.cuda.synchronize()
+    assert float((m.head_out[0] - m.head_out[1]).abs().max()) > 1e-3
+    # rounding-point-exact CPU emulation of the same pipeline agrees much tighter
+    e = WanDiT(cfg, sd, OracleOps(), bsd).prepare(grid)
+    e.forward_tokens(noise.clone(), e.encode_context(ctx), 731.0, e.embed_buffers(bl), e.head_out[0])
+    rel_e = float((m.head_out[0].cpu() - e.head_out[0]).norm() / e.head_out[0].norm())
+    assert rel_e <= 1e-2, f"HIP vs bf16-emulated host pipeline rel-L2={rel_e}"
+
+
+def test_denoise_loop_psnr(hip_ops):
+    grid = TokenGrid(9, 64, 96)
+    cfg, sd, bsd, sdr, bsdr = _setup("tiny", grid)
+    noise = syn.make_latent_noise(grid)
+    c1, c2 = syn.make_text_context(cfg, 1), syn.make_text_context(cfg, 2)
+    bl = syn.make_buffer_latents(cfg, grid)
+    steps = 10
+    m = WanDiT(cfg, sd, hip_ops, bsd).prepare(grid)
+    lat = noise.clone().to("cuda:0")
+    m.denoise(lat, m.encode_context(c1), m.encode_context(c2), m.embed_buffers(bl), FlowMatchScheduler(steps), 5.0)
+    torch.cuda.synchronize()
+    ref = R.denoise_loop(sdr, bsdr, cfg, noise, c1, c2, bl, num_steps=steps)
+    p = R.psnr(lat.cpu(), ref)
+    assert p >= 40.0, f"final-latent PSNR {p:.1f} dB < 40 dB"
+    # determinism: same seed/buffers/prompt => bit-identical latents
+    lat2 = noise.clone().to("cuda:0")
+    m.denoise(lat2, m.encode_context(c1), m.encode_context(c2), m.embed_buffers(bl), FlowMatchScheduler(steps), 5.0)
+    assert torch.equal(lat, lat2)

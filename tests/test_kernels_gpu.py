@@ -1,0 +1,240 @@
+"""Per-kernel parity: libicvideo HIP kernels (through the C ABI) vs the CPU oracle.
+
+Tolerance (SURVEY.md §8d, bf16 outputs vs fp32 oracle on identical bf16-rounded inputs):
+    |delta| <= 2^-7 * |ref| + 2^-8 * rms(ref)      (attention: 2^-7 * |ref| + 2^-7 * rms(ref))
+fp32 outputs use rtol 1e-4 of rms unless noted.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import wan_ref as R
+from infinicube_amd.videogen.ops import RopeTable, EPI_BF16, EPI_GELU_BF16, EPI_RESID_F32, EPI_F32
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rnd(shape, seed, std=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * std).to(dtype)
+
+
+def assert_bf16_close(got, ref, what="", abs_floor=2.0 ** -8):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    rms = ref.pow(2).mean().sqrt()
+    tol = (2.0 ** -7) * ref.abs() + abs_floor * rms
+    bad = (got - ref).abs() > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} outside tol; max err {(got - ref).abs().max():.4g}, rms {rms:.4g}"
+
+
+def assert_f32_close(got, ref, rtol=1e-4, what=""):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    rms = ref.pow(2).mean().sqrt()
+    err = (got - ref).abs().max()
+    assert err <= rtol * max(float(rms), 1e-12) * 10 + rtol * float(ref.abs().max()), f"{what}: max err {err:.4g} rms {rms:.4g}"
+
+
+@pytest.mark.parametrize("d", [256, 1536, 5120])
+@pytest.mark.parametrize("mode", ["plain", "modulate", "affine", "all"])
+def test_ln_modulate(hip_ops, d, mode):
+    rows = 37
+    x = rnd((rows, d), 1, 2.0) + 0.5
+    w = 1 + rnd((d,), 2, 0.1) if mode in ("affine", "all") else None
+    b = rnd((d,), 3, 0.1) if mode in ("affine", "all") else None
+    sh = rnd((d,), 4, 0.3) if mode in ("modulate", "all") else None
+    sc = rnd((d,), 5, 0.3) if mode in ("modulate", "all") else None
+    ref = R.layer_norm(x, w, b, 1e-6)
+    if sc is not None:
+        ref = R.modulate(ref, sh, sc)
+    dv = lambda t: None if t is None else t.to(DEV)
+    out = torch.empty((rows, d), dtype=torch.bfloat16, device=DEV)
+    hip_ops.ln_modulate(x.to(DEV), out, dv(w), dv(b), dv(sh), dv(sc), 1e-6)
+    assert_bf16_close(out, ref, f"ln d={d} {mode}")
+
+
+@pytest.mark.parametrize("d", [256, 512, 1536, 5120])
+def test_rmsnorm_rope(hip_ops, d):
+    T, Hp, Wp = 3, 4, 5
+    S = T * Hp * Wp
+    tok0, n = 7, 41   # a shard in the middle of the grid
+    heads = d // 128
+    planes = rnd((3, n, d), 11).to(torch.bfloat16)
+    w0, w1 = 1 + rnd((d,), 12, 0.1), 1 + rnd((d,), 13, 0.1)
+    freqs = R.rope_freqs_3d(128, T, Hp, Wp)[tok0: tok0 + n]
+    ref0 = R.rope_apply(R.rms_norm(planes[0].float(), w0, 1e-6), freqs, heads)
+    ref1 = R.rope_apply(R.rms_norm(planes[1].float(), w1, 1e-6), freqs, heads)
+    g = planes.to(DEV)
+    rope = RopeTable.build(T, Hp, Wp, DEV)
+    hip_ops.rmsnorm_rope(g[0], w0.to(DEV), g[1], w1.to(DEV), 1e-6, rope, tok0)
+    assert_bf16_close(g[0], ref0, "rms+rope q")
+    assert_bf16_close(g[1], ref1, "rms+rope k")
+    assert torch.equal(g[2].cpu(), planes[2]), "v plane must be untouched"
+    # no-rope, single tensor (cross-attention q / k)
+    g2 = planes[2].clone().to(DEV)
+    hip_ops.rmsnorm_rope(g2, w0.to(DEV), eps=1e-6)
+    assert_bf16_close(g2, R.rms_norm(planes[2].float(), w0, 1e-6), "rms only")
+
+
+GEMM_SHAPES = [(200, 256, 128), (1, 256, 64), (129, 64, 256), (1000, 1536, 1536), (777, 512, 8960), (300, 4608, 1536)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("epi", [EPI_BF16, EPI_GELU_BF16, EPI_RESID_F32, EPI_F32])
+def test_gemm(hip_ops, M, N, K, epi):
+    a = rnd((M, K), 21).to(torch.bfloat16)
+    w = rnd((N, K), 22, 1.0 / math.sqrt(K)).to(torch.bfloat16)
+    bias = rnd((N,), 23, 0.1)
+    acc = a.float() @ w.float().t() + bias
+    if epi in (EPI_BF16, EPI_GELU_BF16):
+        ref = F.gelu(acc, approximate="tanh") if epi == EPI_GELU_BF16 else acc
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+        hip_ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out, epi)
+        assert_bf16_close(out, ref, f"gemm {M}x{N}x{K} epi{epi}")
+    elif epi == EPI_RESID_F32:
+        resid, gate = rnd((M, N), 24), rnd((N,), 25)
+        x = resid.clone().to(DEV)
+        hip_ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), x, epi, resid=x, gate=gate.to(DEV))
+        assert_f32_close(x, resid + gate * acc, what="gemm resid gate (in place)")
+        x2 = torch.empty((M, N), device=DEV)
+        hip_ops.gemm(a.to(DEV), w.to(DEV), None, x2, epi, resid=resid.to(DEV))
+        assert_f32_close(x2, resid + (acc - bias), what="gemm resid nogate nobias")
+    else:
+        out = torch.empty((M, N), device=DEV)
+        hip_ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out, epi)
+        assert_f32_close(out, acc, what="gemm f32")
+
+
+def test_gemm_split_and_strided(hip_ops):
+    M, d, K = 333, 256, 512
+    a_full = rnd((M, K + 64), 31).to(torch.bfloat16)
+    a = a_full[:, :K]            # strided A (lda = K + 64)
+    w = rnd((3 * d, K), 32, 0.05).to(torch.bfloat16)
+    bias = rnd((3 * d,), 33, 0.1)
+    ref = (a.float() @ w.float().t() + bias).reshape(M, 3, d).permute(1, 0, 2)
+    out = torch.full((3, M, d), 7.0, dtype=torch.bfloat16, device=DEV)
+    hip_ops.gemm(a_full.to(DEV)[:, :K], w.to(DEV), bias.to(DEV), out, EPI_BF16, nsplit=d)
+    assert_bf16_close(out, ref, "split qkv gemm")
+
+
+def test_gemm_transposed_identity(hip_ops):
+    """A = I with an ASYMMETRIC W catches any row/col swap of the MFMA C layout."""
+    n = 128
+    a = torch.eye(n).to(torch.bfloat16)
+    w = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251 - 125).to(torch.bfloat16)
+    out = torch.empty((n, n), device=DEV)
+    hip_ops.gemm(a.to(DEV), w.to(DEV), None, out, EPI_F32)
+    assert torch.equal(out.cpu(), w.float().t())
+
+
+@pytest.mark.parametrize("M", [1, 3])
+def test_gemv_and_time_path(hip_ops, M):
+    K, N = 256, 1536
+    x, w, b = rnd((M, K), 41), rnd((N, K), 42, 0.05).to(torch.bfloat16), rnd((N,), 43, 0.1)
+    out = torch.empty((M, N), device=DEV)
+    hip_ops.gemv(x.to(DEV), w.to(DEV), b.to(DEV), out, 1, 1)
+    assert_f32_close(out, F.silu(F.silu(x) @ w.float().t() + b), rtol=2e-5, what="gemv silu/silu")
+    hip_ops.gemv(x.to(DEV), w.to(DEV), None, out, 0, 0)
+    assert_f32_close(out, x @ w.float().t(), rtol=2e-5, what="gemv plain")
+
+
+def test_sinusoidal_bcast_cast(hip_ops):
+    out = torch.empty((1, 256), device=DEV)
+    hip_ops.sinusoidal(937.5, out)
+    ref = R.sinusoidal_embedding_1d(256, torch.tensor([937.5], dtype=torch.float64)).float()
+    assert (out.cpu() - ref).abs().max() < 2e-6
+    a, b = rnd((5, 96), 51), rnd((96,), 52)
+    o = torch.empty((5, 96), device=DEV)
+    hip_ops.bcast_add(a.to(DEV), b.to(DEV), o)
+    assert torch.equal(o.cpu(), a + b)
+    src = rnd((1027,), 53)
+    dst = torch.empty((1027,), dtype=torch.bfloat16, device=DEV)
+    hip_ops.cast_bf16(src.to(DEV), dst)
+    assert torch.equal(dst.cpu(), src.to(torch.bfloat16))
+
+
+ATTN_CASES = [
+    (256, 64, 1), (300, 300, 2), (256, 512, 2), (100, 32, 2), (33, 1, 1), (513, 1000, 3), (2240, 2240, 12),
+]
+
+
+@pytest.mark.parametrize("Sq,Skv,H", ATTN_CASES)
+def test_attention(hip_ops, Sq, Skv, H):
+    d = H * 128
+    q, k, v = (rnd((Sq, d), 61).to(torch.bfloat16), rnd((Skv, d), 62).to(torch.bfloat16),
+               rnd((Skv, d), 63).to(torch.bfloat16))
+    ref = R.attention(q.float(), k.float(), v.float(), H)
+    o = torch.zeros((Sq, d), dtype=torch.bfloat16, device=DEV)
+    hip_ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), o, H, 1.0 / math.sqrt(128))
+    # attention has TWO bf16 rounding points (P before the PV MFMA, then the output), so its
+    # absolute floor is 2^-7 * rms instead of 2^-8 * rms
+    assert_bf16_close(o, ref, f"attention Sq={Sq} Skv={Skv} H={H}", abs_floor=2.0 ** -7)
+
+
+def test_attention_strided_planes_and_spike(hip_ops):
+    """q/k/v as planes of one [3, n, d] buffer (the fused-QKV layout) and a key that forces the
+    online-softmax rescale late in the sequence (running max jumps at the last tile)."""
+    n, H = 700, 2
+    d = H * 128
+    planes = rnd((3, n, d), 71).to(torch.bfloat16)
+    planes[1, 650] = planes[0, 5] * 6.0   # key 650 ~ 6x query 5: a huge score in the last tile
+    planes[1, 3] = planes[0, 400] * 4.0   # and an early spike for another query
+    ref = R.attention(planes[0].float(), planes[1].float(), planes[2].float(), H)
+    g = planes.to(DEV)
+    o = torch.zeros((n, d), dtype=torch.bfloat16, device=DEV)
+    hip_ops.attention(g[0], g[1], g[2], o, H, 1.0 / math.sqrt(128))
+    assert_bf16_close(o, ref, "attention planes+spike", abs_floor=2.0 ** -7)
+
+
+def test_attention_permutation_invariance(hip_ops):
+    """Size-independent property at a larger size: permuting the keys/values together must not
+    change the output beyond rounding (checks tail masking + tile order independence)."""
+    Sq, Skv, H = 1024, 4000, 4
+    d = H * 128
+    q, k, v = (rnd((Sq, d), 81).to(torch.bfloat16).to(DEV), rnd((Skv, d), 82).to(torch.bfloat16).to(DEV),
+               rnd((Skv, d), 83).to(torch.bfloat16).to(DEV))
+    perm = torch.randperm(Skv, generator=torch.Generator().manual_seed(5)).to(DEV)
+    o1 = torch.empty((Sq, d), dtype=torch.bfloat16, device=DEV)
+    o2 = torch.empty_like(o1)
+    hip_ops.attention(q, k, v, o1, H, 1.0 / math.sqrt(128))
+    hip_ops.attention(q, k[perm].contiguous(), v[perm].contiguous(), o2, H, 1.0 / math.sqrt(128))
+    assert (o1.float() - o2.float()).abs().max() < 2e-2 * o1.float().abs().max()
+
+
+def test_patchify_and_unpatchify_euler(hip_ops):
+    C, T, H8, W8 = 16, 3, 8, 12
+    Hp, Wp = H8 // 2, W8 // 2
+    S = T * Hp * Wp
+    lat = rnd((C, T, H8, W8), 91)
+    tok0, n = 5, 40
+    out = torch.zeros((n, 64), dtype=torch.bfloat16, device=DEV)
+    hip_ops.patchify(lat.to(DEV), out, tok0, n)
+    ref = lat.reshape(C, T, Hp, 2, Wp, 2).permute(1, 2, 4, 0, 3, 5).reshape(S, C * 4)[tok0: tok0 + n]
+    assert torch.equal(out.cpu(), ref.to(torch.bfloat16))
+    # conv-as-GEMM equivalence against F.conv3d
+    w = rnd((32, C, 1, 2, 2), 92, 0.1)
+    conv = R.patchify_tokens(lat.to(torch.bfloat16).float(), w.to(torch.bfloat16).float(), None)[tok0: tok0 + n]
+    assert torch.allclose(out.cpu().float() @ w.to(torch.bfloat16).float().reshape(32, -1).t(), conv, atol=1e-4)
+    # fused unpatchify + CFG + Euler on a shard
+    hc, hu = rnd((n, 64), 93), rnd((n, 64), 94)
+    full_c, full_u = torch.zeros((S, 64)), torch.zeros((S, 64))
+    full_c[tok0: tok0 + n], full_u[tok0: tok0 + n] = hc, hu
+    vel = R.unpatchify(full_u + 5.0 * (full_c - full_u), (T, Hp, Wp), C)
+    lat_g = lat.clone().to(DEV)
+    vel_g = torch.zeros_like(lat_g)
+    hip_ops.unpatchify_cfg_euler(lat_g, hc.to(DEV), hu.to(DEV), 5.0, -0.125, tok0, n, vel_out=vel_g)
+    assert torch.allclose(vel_g.cpu(), vel, atol=1e-5)
+    assert torch.allclose(lat_g.cpu(), lat + vel * (-0.125), atol=1e-5)
+    lat_g2 = lat.clone().to(DEV)
+    hip_ops.unpatchify_cfg_euler(lat_g2, hc.to(DEV), None, 1.0, 0.5, tok0, n)
+    assert torch.allclose(lat_g2.cpu(), lat + R.unpatchify(full_c, (T, Hp, Wp), C) * 0.5, atol=1e-5)
+
+
+def test_error_reporting(hip_ops):
+    from infinicube_amd import native
+    a = torch.zeros((8, 100), dtype=torch.bfloat16, device=DEV)   # K = 100 not a multiple of 64
+    w = torch.zeros((8, 100), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(native.NativeError, match="multiple of 64"):
+        hip_ops.gemm(a, w, None, torch.empty((8, 8), dtype=torch.bfloat16, device=DEV), EPI_BF16)

@@ -16,12 +16,13 @@ __global__ void probe(unsigned short* out_tr, float* out_c) {
   // every lane supplies its own contiguous 8 bytes: element index lane*4
   s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + lane * 4));
   for (int j = 0; j < 4; ++j) out_tr[lane * 4 + j] = (unsigned short)r[j];
-  // MFMA layout: A[i][k] = i (row id), B[k][j] = (k==0) -> C[i][j] = i * 1 (for k = 0 only)
+  // MFMA 32x32x16 C/D layout check with an asymmetric product
   bf16x8 a, b;
   for (int e = 0; e < 8; ++e) {
     const int k = (lane >> 5) * 8 + e;
-    a[e] = (__bf16)(float)((lane & 31) + 1);   // A[i][k] = i+1 for all k
-    b[e] = (__bf16)((k == 0) ? (float)(100 * ((lane & 31) + 1)) : 0.f);  // B[0][j] = 100*(j+1)
+    // C[i][j] = A[i][0]*B[0][j] + A[i][1]*B[1][j] = i + 64*j  (asymmetric, exact in bf16)
+    a[e] = (__bf16)((k == 0) ? (float)(lane & 31) : (k == 1 ? 64.f : 0.f));
+    b[e] = (__bf16)((k == 0) ? 1.f : (k == 1 ? (float)(lane & 31) : 0.f));
   }
   f32x16 c = {0};
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -49,13 +50,13 @@ int main() {
     printf("\n");
   }
   printf("TR_ASSUMPTION %s (lane t elem j <- lane 4j + t/4, elem t%%4 within each 16-lane group)\n", ok_tr ? "HOLDS" : "FAILS");
-  // C[i][j] = (i+1) * 100 * (j+1): decode (row i, col j) per lane/reg
+  // C[i][j] = i + 64*j
   int ok_c = 1;
   for (int l = 0; l < 64; ++l)
     for (int e = 0; e < 16; ++e) {
       const float v = h_c[l * 16 + e];
       const int j = l & 31, i = (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
-      if (v != (float)((i + 1) * 100 * (j + 1))) ok_c = 0;
+      if (v != (float)(i + 64 * j)) ok_c = 0;
     }
   printf("MFMA32_CD_ASSUMPTION %s (col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))\n", ok_c ? "HOLDS" : "FAILS");
   return 0;
