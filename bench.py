@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py — denoise-steps/s of the buffer-conditioned Wan2.1 DiT loop on MI355X.
+
+Metric (BASELINE.json): "denoise steps/sec ... for 93-frame 480p Wan2.1, 1/2/4/8 GPU".
+One STEP = one scheduler step = 2 DiT forwards (cond + uncond, cfg 5) + fused unpatchify/CFG/Euler
+over synthetic 93x480x832 latents (16x24x60x104, S = 37,440 tokens), random-init weights of the
+named architecture, non-zero guidance-buffer tokens, inputs resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model 1.3b|14b]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1 = token-sequence parallelism (strong scaling: the same 37,440-token video is split over the
+ranks; per-layer RCCL all-gather of K/V).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from infinicube_amd.videogen import synthetic as syn  # noqa: E402
+from infinicube_amd.videogen.config import GRID_480P, TokenGrid, dit_forward_flops, preset  # noqa: E402
+from infinicube_amd.videogen.dit import WanDiT  # noqa: E402
+from infinicube_amd.videogen.ops import HipOps  # noqa: E402
+from infinicube_amd.videogen.scheduler import FlowMatchScheduler  # noqa: E402
+from infinicube_amd.videogen.seqpar import ShardPlan  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+CFG_SCALE = 5.0
+
+
+def cpu_baseline(cfg, grid, threads):
+    """The CPU oracle (oracle/wan_ref.py, kind='port': the reference has no separate CPU DiT and its
+    diffsynth dependency cannot travel) timed on this box's host cores on a BOUNDED sample of the
+    same workload: ONE of the L layers; its token-local ops (LN/modulate, projections, RMSNorm+RoPE,
+    cross-attention, FFN) on a 4096-token slice, its self-attention on a 512-query slice against all
+    S keys; both scaled to S tokens, then x L layers x 2 forwards."""
+    import dataclasses
+    import torch.nn.functional as F
+    from oracle import wan_ref as R
+    torch.set_num_threads(threads)
+    S, d, H = grid.S, cfg.dim, cfg.num_heads
+    ts, qs = min(4096, S), min(512, S)
+    one = dataclasses.replace(cfg, num_layers=1)
+    sd = syn.make_dit_state_dict(one, seed=0)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((ts, d), generator=g)
+    ctx = torch.randn((cfg.text_len, d), generator=g)
+    t_mod = torch.randn((6, d), generator=g) * 0.1
+    kf, vf = torch.randn((S, d), generator=g), torch.randn((S, d), generator=g)
+    freqs = R.rope_freqs_3d(cfg.head_dim, grid.T, grid.Hp, grid.Wp)[:ts]
+    p = "blocks.0"
+    f32 = torch.float32
+    t0 = time.perf_counter()
+    mod = sd[f"{p}.modulation"].reshape(6, d) + t_mod
+    h = R.modulate(R.layer_norm(x, None, None, cfg.eps), mod[0], mod[1])
+    q = R.rope_apply(R.rms_norm(R._lin(sd, f"{p}.self_attn.q", h, f32), sd[f"{p}.self_attn.norm_q.weight"], cfg.eps), freqs, H)
+    k = R.rope_apply(R.rms_norm(R._lin(sd, f"{p}.self_attn.k", h, f32), sd[f"{p}.self_attn.norm_k.weight"], cfg.eps), freqs, H)
+    v = R._lin(sd, f"{p}.self_attn.v", h, f32)
+    x = x + mod[2] * R._lin(sd, f"{p}.self_attn.o", v + k, f32)   # attention output stand-in (timed below)
+    hh = R.layer_norm(x, sd[f"{p}.norm3.weight"], sd[f"{p}.norm3.bias"], cfg.eps)
+    q2 = R.rms_norm(R._lin(sd, f"{p}.cross_attn.q", hh, f32), sd[f"{p}.cross_attn.norm_q.weight"], cfg.eps)
+    k2 = R.rms_norm(R._lin(sd, f"{p}.cross_attn.k", ctx, f32), sd[f"{p}.cross_attn.norm_k.weight"], cfg.eps)
+    v2 = R._lin(sd, f"{p}.cross_attn.v", ctx, f32)
+    x = x + R._lin(sd, f"{p}.cross_attn.o", R.attention(q2, k2, v2, H), f32)
+    h = R.modulate(R.layer_norm(x, None, None, cfg.eps), mod[3], mod[4])
+    x = x + mod[5] * R._lin(sd, f"{p}.ffn.2", F.gelu(R._lin(sd, f"{p}.ffn.0", h, f32), approximate="tanh"), f32)
+    t1 = time.perf_counter()
+    a = R.attention(q[:qs], kf, vf, H)
+    t2 = time.perf_counter()
+    assert torch.isfinite(x).all() and torch.isfinite(a).all()
+    t_local, t_attn = (t1 - t0) * (S / ts), (t2 - t1) * (S / qs)
+    t_step = 2.0 * cfg.num_layers * (t_local + t_attn)
+    return {
+        "value": 1.0 / t_step, "unit": "denoise steps/s", "cores": threads, "kind": "port",
+        "sample": (f"oracle/wan_ref.py fp32, 1 of {cfg.num_layers} layers: token-local ops on {ts} tokens "
+                   f"({t1 - t0:.1f}s) and self-attention of {qs} queries x {S} keys ({t2 - t1:.1f}s), each scaled to "
+                   f"S={S}, x{cfg.num_layers} layers x2 forwards = {t_step:.0f} s/step; host cpu_count={os.cpu_count()}"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default=os.environ.get("ICV_BENCH_MODEL", "1.3b"), choices=["1.3b", "14b", "small", "tiny"])
+    ap.add_argument("--frames", type=int, default=GRID_480P.num_frames)
+    ap.add_argument("--height", type=int, default=GRID_480P.height)
+    ap.add_argument("--width", type=int, default=GRID_480P.width)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    cfg = preset(args.model)
+    grid = TokenGrid(args.frames, args.height, args.width)
+    plan = ShardPlan.make(grid.S, world, rank)
+    ops = HipOps(device)
+
+    # ---- synthetic weights / inputs, resident in HBM before timing (SURVEY.md §8d recipe) ----
+    sd = syn.make_dit_state_dict(cfg, seed=0, device=device, dtype=torch.bfloat16)
+    bsd = syn.make_buffer_embedder_state_dict(cfg, device=device, dtype=torch.bfloat16)
+    model = WanDiT(cfg, sd, ops, bsd)
+    del sd, bsd
+    model.prepare(grid, plan)
+    ctx_c = model.encode_context(syn.make_text_context(cfg, 1))
+    ctx_u = model.encode_context(syn.make_text_context(cfg, 2))
+    buf = model.embed_buffers(syn.make_buffer_latents(cfg, grid))
+    latent = syn.make_latent_noise(grid, seed=0).to(device)
+    total_steps = 50
+    sched = FlowMatchScheduler(total_steps)
+
+    # ---- per-launch timing of the dominant kernel (self-attention) with events on the launch stream
+    attn_events = []
+    record = {"on": False}
+    raw_attention = ops.attention
+
+    def timed_attention(q, k, v, o, heads, scale):
+        if record["on"] and k.shape[0] == grid.S:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            raw_attention(q, k, v, o, heads, scale)
+            e1.record()
+            attn_events.append((e0, e1))
+        else:
+            raw_attention(q, k, v, o, heads, scale)
+
+    ops.attention = timed_attention
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    def run_steps(first, count):
+        model.denoise(latent, ctx_c, ctx_u, buf, sched, CFG_SCALE,
+                      steps=[(first + i) % total_steps for i in range(count)])
+
+    run_steps(0, args.warmup)
+    sync()
+    record["on"] = True
+    t0 = time.perf_counter()
+    run_steps(args.warmup, args.steps)
+    sync()
+    elapsed = time.perf_counter() - t0
+    record["on"] = False
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(latent).all(), "latent went non-finite"
+
+    attn_ms = sum(a.elapsed_time(b) for a, b in attn_events) / max(len(attn_events), 1)
+    attn_flops = 4.0 * plan.n_tok * grid.S * cfg.dim            # per launch on this rank (4 S^2 d)
+    attn_tflops = attn_flops / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
+    f_step = 2.0 * dit_forward_flops(cfg, grid.S)
+
+    if rank == 0:
+        out = {
+            "metric": "denoise steps/sec, 93-frame 480p Wan2.1 buffer-conditioned DiT loop",
+            "value": args.steps / elapsed,
+            "unit": "denoise steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic (seeded latents/text context/guidance-buffer latents, random-init weights of the named architecture)",
+            "config": {
+                "workload": f"Wan2.1-{args.model.upper()} t2v DiT, {args.frames} frames {args.height}x{args.width}, "
+                            f"S={grid.S} tokens, 1 step = 2 DiT forwards (cond+uncond, cfg {CFG_SCALE}) + Euler; "
+                            f"50-step flow-match schedule (shift 5)",
+                "model": f"wan2.1-t2v-{args.model}", "tokens": grid.S, "layers": cfg.num_layers, "dim": cfg.dim,
+                "parallelism": f"sp{world}" if world > 1 else "single-gpu",
+                "wallclock_50_steps_s": 50.0 * elapsed / args.steps,
+                "algorithmic_pflop_per_step": f_step / 1e15,
+                "model_tflops_all_gpus": f_step * args.steps / elapsed / 1e12,
+                "frac_of_bf16_mfma_peak": f_step * args.steps / elapsed / 1e12 / (PEAK_BF16_TFLOPS * world),
+            },
+            "roofline": {
+                "kernel": "attn_fwd_kernel (self-attention, K6)",
+                "bound": "mfma", "achieved": attn_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": attn_tflops / PEAK_BF16_TFLOPS, "traffic": None,
+                "avg_launch_ms": attn_ms, "launches_timed": len(attn_events),
+                "algorithmic_flop_per_launch": attn_flops,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = args.cpu_threads or min(os.cpu_count() or 1, 32)  # >32 threads oversubscribes these GEMM sizes
+            out["cpu_baseline"] = cpu_baseline(cfg, grid, threads)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
