@@ -1,0 +1,71 @@
+"""Checkpoint / video I/O at the boundary.
+
+``load_state_dict(path) -> Dict[str, Tensor]`` and ``save_video(frames, path, fps=, quality=)`` are
+the two free functions the reference imports from diffsynth
+[R infinicube/videogen/inference.py:25] and calls at [R infinicube/videogen/inference.py:103,231].
+"""
+
+from __future__ import annotations
+
+import glob
+import json
+import os
+import struct
+from typing import Dict, List
+
+import torch
+
+
+def load_state_dict(path: str, device: str = "cpu") -> Dict[str, torch.Tensor]:
+    """Flat ``{name: tensor}``; safetensors by extension, torch pickle otherwise."""
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        return load_file(path, device=device)
+    sd = torch.load(path, map_location=device, weights_only=True)
+    if isinstance(sd, dict) and "state_dict" in sd and isinstance(sd["state_dict"], dict):
+        sd = sd["state_dict"]
+    return sd
+
+
+def load_sharded_state_dict(pattern: str, device: str = "cpu") -> Dict[str, torch.Tensor]:
+    files = sorted(glob.glob(pattern))
+    if not files:
+        raise FileNotFoundError(f"no checkpoint file matches {pattern!r} (skip_download=True: nothing is fetched)")
+    out: Dict[str, torch.Tensor] = {}
+    for f in files:
+        out.update(load_state_dict(f, device))
+    return out
+
+
+def describe_checkpoint(path: str) -> Dict[str, Dict[str, tuple]]:
+    """Read ONLY the safetensors header and report ``buffer_embedder.*`` / ``dit.*`` names+shapes:
+    selects the embedder variant and the model size without touching tensor data."""
+    with open(path, "rb") as f:
+        (n,) = struct.unpack("<Q", f.read(8))
+        header = json.loads(f.read(n))
+    out = {"buffer_embedder": {}, "dit": {}, "other": {}}
+    for k, meta in header.items():
+        if k == "__metadata__":
+            continue
+        grp = "buffer_embedder" if k.startswith("buffer_embedder.") else "dit" if k.startswith("dit.") else "other"
+        out[grp][k] = tuple(meta["shape"])
+    return out
+
+
+def save_video(frames: List, save_path: str, fps: int = 10, quality: int = 8) -> None:
+    """mp4 (libx264 through imageio-ffmpeg, like diffsynth's save_video).  imageio is part of the
+    reference's environment; if it is absent here this raises instead of silently writing nothing,
+    because stage 3 reads the file [R infinicube/inference/scene_gaussian_generation.py:290-293]."""
+    try:
+        import imageio
+    except ImportError as e:
+        raise RuntimeError(
+            f"save_video({save_path!r}): the 'imageio' (+ imageio-ffmpeg) package is required to write mp4") from e
+    import numpy as np
+    os.makedirs(os.path.dirname(os.path.abspath(save_path)), exist_ok=True)
+    writer = imageio.get_writer(save_path, fps=fps, quality=quality)
+    try:
+        for fr in frames:
+            writer.append_data(np.asarray(fr))
+    finally:
+        writer.close()

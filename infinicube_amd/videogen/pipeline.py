@@ -1,0 +1,276 @@
+"""``WanVideoPipeline`` / ``ModelConfig`` — the surface the reference reaches into diffsynth for
+(SURVEY.md §8a-2 rows D1-D5), re-implemented MI355X-native.
+
+Pinned by the reference's call sites:
+  * ``ModelConfig(model_id=, origin_file_pattern=, skip_download=True)``        [R infinicube/videogen/inference.py:67-69,77-79]
+  * ``WanVideoPipeline.from_pretrained(torch_dtype=, device=, model_configs=)`` [R infinicube/videogen/inference.py:63,73]
+  * ``pipe.dit`` / ``pipe.buffer_embedder`` with ``load_state_dict``            [R infinicube/videogen/inference.py:106-127]
+  * ``pipe.initialize_buffer_embedder(buffer_channels=16, zero_init=True)``     [R infinicube/videogen/inference.py:86-88]
+  * ``pipe.enable_vram_management()``                                           [R infinicube/videogen/inference.py:97]
+  * ``pipe(prompt=, negative_prompt=, semantic_buffer_video=, coordinate_buffer_video=, height=,
+    width=, num_frames=, seed=, tiled=) -> List[PIL.Image]``                    [R infinicube/videogen/inference.py:216-226]
+Everything the fork does *inside* those calls is [EXT]: 50 flow-match steps,
+shift 5, cfg 5, CPU-generator noise, VAE-encode the two buffer videos, embed, add to the tokens.
+
+The denoising loop runs in libicvideo's HIP kernels (dit.WanDiT + ops.HipOps).  The text encoder
+and the VAE are outside the hot loop and stay on stock PyTorch-ROCm modules behind two tiny
+interfaces (``encode(prompt) -> [text_len, text_dim]``; ``encode/decode`` video<->latent).
+"""
+
+from __future__ import annotations
+
+import os
+from collections import namedtuple
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+from PIL import Image
+
+from .config import TokenGrid, WanDiTConfig, infer_config_from_state_dict
+from .io import load_sharded_state_dict
+from .scheduler import FlowMatchScheduler
+from .seqpar import ShardPlan, gather_latent
+
+_IncompatibleKeys = namedtuple("_IncompatibleKeys", ["missing_keys", "unexpected_keys"])
+
+
+class ModelConfig:
+    """Where a model file lives: ``models/<model_id>/<origin_file_pattern>`` (diffsynth's layout,
+    [R README.md:33]) or an explicit ``path``.  ``skip_download`` is accepted and always honoured:
+    this implementation never downloads."""
+
+    def __init__(self, path=None, model_id: Optional[str] = None, origin_file_pattern: Optional[str] = None,
+                 skip_download: bool = False, offload_device=None, offload_dtype=None, local_model_path: Optional[str] = None,
+                 **unused):
+        self.path = path
+        self.model_id = model_id
+        self.origin_file_pattern = origin_file_pattern
+        self.skip_download = skip_download
+        self.offload_device = offload_device
+        self.offload_dtype = offload_dtype
+        self.local_model_path = local_model_path
+
+    def resolve(self) -> str:
+        if self.path is not None:
+            return self.path if isinstance(self.path, str) else self.path[0]
+        root = self.local_model_path or os.environ.get("ICV_MODEL_ROOT", "models")
+        return os.path.join(root, self.model_id or "", self.origin_file_pattern or "")
+
+    def __repr__(self):
+        return f"ModelConfig(model_id={self.model_id!r}, origin_file_pattern={self.origin_file_pattern!r})"
+
+
+class DiTHolder:
+    """``pipe.dit``: owns the DiT state dict until the first generation packs it into HBM
+    (``dit.WanDiT``); supports the reference's partial fine-tune overlay
+    ``dit.load_state_dict(state, strict=False)`` [R infinicube/videogen/inference.py:127]."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: Optional[WanDiTConfig] = None):
+        self._sd = dict(state_dict)
+        self.cfg = cfg or infer_config_from_state_dict(self._sd)
+        self.version = 0
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return self._sd
+
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
+        missing = [k for k in self._sd if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in self._sd]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for WanModel: missing {missing[:5]}..., unexpected {unexpected[:5]}...")
+        for k, v in state_dict.items():
+            if k in self._sd:
+                if tuple(v.shape) != tuple(self._sd[k].shape):
+                    raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(v.shape)} vs model {tuple(self._sd[k].shape)}")
+                self._sd[k] = v
+        self.version += 1
+        return _IncompatibleKeys(missing, unexpected)
+
+
+class BufferEmbedder:
+    """``pipe.buffer_embedder``: guidance buffers -> tokens added to the noisy tokens [R README.md:65].
+    Default layout = hypothesis H1 of SURVEY.md §8a K1: the two VAE-encoded buffers concatenated on
+    channels (2 x buffer_channels) -> ``Conv3d(2C -> dim, kernel = stride = (1,2,2))``, zero-initialised.
+    ``load_state_dict`` is STRICT, as the reference's call is [R infinicube/videogen/inference.py:113]."""
+
+    def __init__(self, dim: int, buffer_channels: int = 16, zero_init: bool = True, patch=(1, 2, 2), variant: str = "concat"):
+        self.dim, self.buffer_channels, self.patch, self.variant = dim, buffer_channels, tuple(patch), variant
+        shapes = self._shapes()
+        g = torch.Generator().manual_seed(1234)
+        self._sd = {k: (torch.zeros(s) if (zero_init or k.endswith("bias")) else torch.randn(s, generator=g) * 0.02)
+                    for k, s in shapes.items()}
+        self.version = 0
+
+    def _shapes(self):
+        d, c, p = self.dim, self.buffer_channels, self.patch
+        if self.variant == "concat":
+            return {"proj.weight": (d, 2 * c) + p, "proj.bias": (d,)}
+        return {"semantic_proj.weight": (d, c) + p, "semantic_proj.bias": (d,),
+                "coordinate_proj.weight": (d, c) + p, "coordinate_proj.bias": (d,)}
+
+    def state_dict(self):
+        return self._sd
+
+    def parameters(self):
+        return list(self._sd.values())
+
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
+        keys = set(state_dict)
+        if keys != set(self._sd):
+            # the fork's real layout is unknown ([EXT]); accept the other known variant if it fits exactly
+            other = BufferEmbedder(self.dim, self.buffer_channels, True, self.patch,
+                                   "dual" if self.variant == "concat" else "concat")
+            if keys == set(other._sd):
+                self.variant, self._sd = other.variant, other._sd
+            elif strict:
+                raise RuntimeError(
+                    f"Error(s) in loading state_dict for BufferEmbedder: expected keys {sorted(self._sd)} "
+                    f"(or {sorted(other._sd)}), got {sorted(keys)}")
+        for k, v in state_dict.items():
+            if k in self._sd:
+                if tuple(v.shape) != tuple(self._sd[k].shape):
+                    raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(v.shape)} vs model {tuple(self._sd[k].shape)}")
+                self._sd[k] = v
+        self.version += 1
+        return _IncompatibleKeys([], [])
+
+
+def _video_to_tensor(frames: Sequence[Image.Image], height: int, width: int) -> torch.Tensor:
+    """List[PIL RGB] -> f32 [3, F, H, W] in [-1, 1] (diffsynth preprocess_video)."""
+    arrs = []
+    for im in frames:
+        if im.size != (width, height):
+            im = im.resize((width, height), Image.BILINEAR)
+        arrs.append(np.asarray(im.convert("RGB"), dtype=np.uint8))
+    v = torch.from_numpy(np.stack(arrs, 0)).to(torch.float32)
+    return (v * (2.0 / 255.0) - 1.0).permute(3, 0, 1, 2).contiguous()
+
+
+def _tensor_to_video(video: torch.Tensor) -> List[Image.Image]:
+    """f32 [3, F, H, W] in [-1, 1] -> List[PIL RGB] (diffsynth vae_output_to_video)."""
+    v = ((video.float().clamp(-1, 1) + 1.0) * 127.5).round().to(torch.uint8).permute(1, 2, 3, 0).cpu().numpy()
+    return [Image.fromarray(f, mode="RGB") for f in v]
+
+
+class WanVideoPipeline:
+    def __init__(self, device="cuda:0", torch_dtype=torch.bfloat16, dit: Optional[DiTHolder] = None,
+                 text_encoder=None, vae=None, ops=None):
+        self.device = device
+        self.torch_dtype = torch_dtype
+        self.dit = dit
+        self.text_encoder = text_encoder
+        self.vae = vae
+        self.buffer_embedder: Optional[BufferEmbedder] = None
+        self.scheduler = FlowMatchScheduler(50, 5.0)
+        self._ops = ops
+        self._engine = None
+        self._engine_key = None
+        self.vram_management_enabled = False
+
+    # ---- D2 --------------------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, torch_dtype=torch.bfloat16, device="cuda", model_configs: Sequence[ModelConfig] = (),
+                        tokenizer_config: Optional[ModelConfig] = None, **unused) -> "WanVideoPipeline":
+        """Load DiT / UMT5 / Wan-VAE from local files (never downloads).  Files are recognised by
+        name, like the reference's three patterns [R infinicube/videogen/inference.py:67-69]."""
+        pipe = cls(device=device, torch_dtype=torch_dtype)
+        for mc in model_configs:
+            pattern = mc.resolve()
+            base = os.path.basename(pattern)
+            if "t5" in base.lower():
+                from .text_encoder import load_umt5_encoder
+                pipe.text_encoder = load_umt5_encoder(pattern, device, torch_dtype, tokenizer_config)
+            elif "vae" in base.lower():
+                from .vae import load_wan_vae
+                pipe.vae = load_wan_vae(pattern, device)
+            else:
+                pipe.dit = DiTHolder(load_sharded_state_dict(pattern))
+        if pipe.dit is None:
+            raise FileNotFoundError("from_pretrained: no DiT checkpoint among model_configs")
+        return pipe
+
+    # ---- D3 / D4 -----------------------------------------------------------------------------
+    def initialize_buffer_embedder(self, buffer_channels: int = 16, zero_init: bool = True):
+        self.buffer_embedder = BufferEmbedder(self.dit.cfg.dim, buffer_channels, zero_init, self.dit.cfg.patch)
+        return self.buffer_embedder
+
+    def enable_vram_management(self, **unused):
+        """diffsynth offloads layers to host RAM to fit an 80 GB A100 [R infinicube/videogen/inference.py:95-97].
+        With 288 GB of HBM3E the whole 14B DiT (28 GB bf16) + UMT5 + VAE stay resident: a no-op
+        with no numeric effect."""
+        self.vram_management_enabled = True
+
+    # ---- engine ------------------------------------------------------------------------------
+    def _get_ops(self):
+        if self._ops is None:
+            from .ops import HipOps
+            dev = "cuda:0" if str(self.device) == "cuda" else self.device
+            self._ops = HipOps(dev)   # raises loudly without GPU / native library: no fallback
+        return self._ops
+
+    def _get_engine(self):
+        from .dit import WanDiT
+        key = (self.dit.version, self.buffer_embedder.version if self.buffer_embedder else -1)
+        if self._engine is None or self._engine_key != key:
+            cfg = self.dit.cfg
+            if self.buffer_embedder is not None and cfg.buffer_channels != self.buffer_embedder.buffer_channels:
+                import dataclasses
+                cfg = dataclasses.replace(cfg, buffer_channels=self.buffer_embedder.buffer_channels)
+            self._engine = WanDiT(cfg, self.dit.state_dict(), self._get_ops(),
+                                  self.buffer_embedder.state_dict() if self.buffer_embedder else None)
+            self._engine_key = key
+        return self._engine
+
+    # ---- D5: the generation call -----------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, prompt: str, negative_prompt: str = "", semantic_buffer_video=None,
+                 coordinate_buffer_video=None, height: int = 480, width: int = 832, num_frames: int = 81,
+                 seed: Optional[int] = None, tiled: bool = True, num_inference_steps: int = 50,
+                 cfg_scale: float = 5.0, sigma_shift: float = 5.0, rand_device: str = "cpu",
+                 tile_size=(30, 52), tile_stride=(15, 26), progress_bar_cmd=None, return_latents: bool = False,
+                 **unused):
+        if self.text_encoder is None or self.vae is None:
+            raise RuntimeError("WanVideoPipeline: text encoder / VAE not loaded")
+        grid = TokenGrid(num_frames, height, width)
+        engine = self._get_engine()
+        ops = engine.ops
+        world, rank = 1, 0
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                world, rank = dist.get_world_size(), dist.get_rank()
+        except Exception:  # pragma: no cover
+            pass
+        plan = ShardPlan.make(grid.S, world, rank)
+        engine.prepare(grid, plan)
+        self.scheduler = FlowMatchScheduler(num_inference_steps, sigma_shift)
+        # text (cond / uncond), once per prompt
+        ctx_c = engine.encode_context(self.text_encoder.encode(prompt))
+        ctx_u = engine.encode_context(self.text_encoder.encode(negative_prompt)) if cfg_scale != 1.0 else None
+        # noise: CPU generator, fp32 (rand_device='cpu' upstream) -> identical across devices/ranks
+        g = torch.Generator(device="cpu")
+        if seed is not None:
+            g.manual_seed(int(seed))
+        latent = torch.randn((1, 16) + grid.latent_shape()[1:], generator=g, dtype=torch.float32)[0]
+        latent = ops.to_device(latent, torch.float32)
+        # guidance buffers -> VAE latents -> tokens (step-invariant)
+        buf_tokens = None
+        if self.buffer_embedder is not None and semantic_buffer_video is not None and coordinate_buffer_video is not None:
+            lats = []
+            for vid in (semantic_buffer_video, coordinate_buffer_video):
+                if len(vid) != num_frames:
+                    raise ValueError(f"buffer video has {len(vid)} frames, num_frames={num_frames}")
+                lats.append(self.vae.encode(_video_to_tensor(vid, height, width), tiled=tiled,
+                                            tile_size=tile_size, tile_stride=tile_stride).to(torch.float32))
+            buf_tokens = engine.embed_buffers(torch.cat(lats, dim=0))
+        # the hot loop (HIP)
+        it = range(num_inference_steps)
+        if progress_bar_cmd is not None:
+            it = progress_bar_cmd(it)
+        engine.denoise(latent, ctx_c, ctx_u, buf_tokens, self.scheduler, cfg_scale, steps=it)
+        latent = gather_latent(latent, plan, grid)
+        if return_latents:
+            return latent
+        video = self.vae.decode(latent, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride)
+        return _tensor_to_video(video)

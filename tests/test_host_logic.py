@@ -1,0 +1,140 @@
+"""Host-side logic of the product (dit.WanDiT, seqpar) on CPU with the TEST-ONLY oracle operator set:
+weight packing, fused split-QKV layout, caches, token-shard arithmetic, the per-layer K/V all-gather
+(world_size 2 over gloo, two real processes) and the end-of-loop latent exchange."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from infinicube_amd.videogen import synthetic as syn
+from infinicube_amd.videogen.config import TokenGrid, preset
+from infinicube_amd.videogen.dit import WanDiT
+from infinicube_amd.videogen.scheduler import FlowMatchScheduler
+from infinicube_amd.videogen.seqpar import KVGather, ShardPlan, gather_latent
+from oracle import wan_ref as R
+from oracle_ops import OracleOps
+
+CFG, GRID = preset("tiny"), TokenGrid(9, 64, 96)     # T=3, Hp=4, Wp=6 -> S=72
+
+
+def _inputs():
+    sd, bsd = syn.make_dit_state_dict(CFG), syn.make_buffer_embedder_state_dict(CFG)
+    return (sd, bsd, syn.make_latent_noise(GRID), syn.make_text_context(CFG, 1), syn.make_text_context(CFG, 2),
+            syn.make_buffer_latents(CFG, GRID))
+
+
+def test_shard_plan():
+    p = ShardPlan.make(37440, 8, 3)
+    assert (p.tok0, p.n_tok) == (3 * 4680, 4680)
+    assert sum(ShardPlan.make(37440, 8, r).n_tok for r in range(8)) == 37440
+    with pytest.raises(ValueError, match="not divisible"):
+        ShardPlan.make(37440, 7, 0)
+    with pytest.raises(ValueError):
+        ShardPlan.make(64, 2, 2)
+
+
+@pytest.mark.parametrize("variant", ["concat", "dual"])
+def test_forward_matches_oracle(variant):
+    sd, _, noise, c1, _, bl = _inputs()
+    bsd = syn.make_buffer_embedder_state_dict(CFG, variant=variant)
+    m = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID)
+    m.forward_tokens(noise.clone(), m.encode_context(c1), 500.0, m.embed_buffers(bl), m.head_out[0])
+    v = R.unpatchify(m.head_out[0], (GRID.T, GRID.Hp, GRID.Wp), CFG.out_dim)
+    sdr, bsdr = R.round_state_dict_to_bf16(sd), R.round_state_dict_to_bf16(bsd)
+    ref = R.dit_forward(sdr, CFG, noise, c1, 500.0, R.buffer_embed(bsdr, bl))
+    assert float((v - ref).norm() / ref.norm()) < 1e-2      # only bf16 storage rounding separates them
+
+
+def test_loop_matches_oracle_and_time_cache():
+    sd, bsd, noise, c1, c2, bl = _inputs()
+    m = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID)
+    lat = noise.clone()
+    m.denoise(lat, m.encode_context(c1), m.encode_context(c2), m.embed_buffers(bl), FlowMatchScheduler(4), 5.0)
+    ref = R.denoise_loop(R.round_state_dict_to_bf16(sd), R.round_state_dict_to_bf16(bsd), CFG, noise, c1, c2, bl, num_steps=4)
+    assert R.psnr(lat, ref) > 50.0
+    # cfg_scale == 1 -> single forward per step, no uncond branch needed
+    lat1 = noise.clone()
+    m.denoise(lat1, m.encode_context(c1), None, m.embed_buffers(bl), FlowMatchScheduler(2), 1.0)
+    ref1 = R.denoise_loop(R.round_state_dict_to_bf16(sd), R.round_state_dict_to_bf16(bsd), CFG, noise, c1, c2, bl, num_steps=2, cfg_scale=1.0)
+    assert R.psnr(lat1, ref1) > 50.0
+
+
+def test_inprocess_two_shards_equal_unsharded():
+    """Simulate world=2 in one process: run both shards with a gather that concatenates their K/V."""
+    sd, bsd, noise, c1, _, bl = _inputs()
+    full = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID)
+    full.forward_tokens(noise.clone(), full.encode_context(c1), 300.0, full.embed_buffers(bl), full.head_out[0])
+    # lock-step emulation: layer-by-layer is awkward, so exploit determinism — shard r's K/V for layer i
+    # equal rows [tok0, tok0+n) of the unsharded K/V; capture them from the full run via a recording ops.
+    rec = {}
+
+    class RecOps(OracleOps):
+        def attention(self, q, k, v, o, heads, scale):
+            if k.shape[0] == GRID.S:
+                rec.setdefault("kv", []).append((k.clone(), v.clone()))
+            super().attention(q, k, v, o, heads, scale)
+
+    f2 = WanDiT(CFG, sd, RecOps(), bsd).prepare(GRID)
+    f2.forward_tokens(noise.clone(), f2.encode_context(c1), 300.0, f2.embed_buffers(bl), f2.head_out[0])
+    outs = []
+    for r in range(2):
+        plan = ShardPlan.make(GRID.S, 2, r)
+        layer = {"i": 0}
+
+        def fake_gather(k_loc, v_loc, k_full, v_full, plan=plan, layer=layer):
+            kf, vf = rec["kv"][layer["i"]]
+            # this rank's own rows must equal what it computed locally (RoPE offsets, shard indexing)
+            assert torch.equal(kf[plan.tok0: plan.tok0 + plan.n_tok], k_loc)
+            assert torch.equal(vf[plan.tok0: plan.tok0 + plan.n_tok], v_loc)
+            k_full.copy_(kf); v_full.copy_(vf)
+            layer["i"] += 1
+
+        m = WanDiT(CFG, sd, OracleOps(), bsd)
+        # world>1 without torch.distributed: inject the gather
+        m.prepare(GRID, plan, kv_gather=fake_gather)
+        m.forward_tokens(noise.clone(), m.encode_context(c1), 300.0, m.embed_buffers(bl), m.head_out[0])
+        outs.append(m.head_out[0].clone())
+    assert torch.equal(torch.cat(outs, 0), full.head_out[0])
+
+
+def _sp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        sd, bsd, noise, c1, c2, bl = _inputs()
+        plan = ShardPlan.make(GRID.S, world, rank)
+        m = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID, plan)
+        assert isinstance(m.kv_gather, KVGather)
+        lat = noise.clone()
+        m.denoise(lat, m.encode_context(c1), m.encode_context(c2), m.embed_buffers(bl), FlowMatchScheduler(3), 5.0)
+        lat = gather_latent(lat, plan, GRID)
+        q.put((rank, lat))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_sequence_parallel_equals_single():
+    sd, bsd, noise, c1, c2, bl = _inputs()
+    single = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID)
+    ref = noise.clone()
+    single.denoise(ref, single.encode_context(c1), single.encode_context(c2), single.embed_buffers(bl), FlowMatchScheduler(3), 5.0)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_sp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # every rank ends with the FULL latent, identical to the single-process run (same math per token)
+    assert torch.equal(got[0], got[1])
+    # vs the single-process run: same math per token, but CPU GEMM blocking differs with the row count,
+    # and a 1e-7 difference can flip a bf16 storage rounding -> compare to rounding, not bitwise
+    assert float((got[0] - ref).norm() / ref.norm()) < 2e-3 and R.psnr(got[0], ref) > 55.0
