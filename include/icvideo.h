@@ -35,6 +35,9 @@ const char* icv_last_error(void);
  * out[3]=warp (wavefront) size.  Replaces nothing in the reference (device probing). */
 int icv_device_info(int device, int64_t out[4]);
 
+/* Kernel-variant switch for A/B measurement ("gemm256" = 0/1, ...); defaults = shipped config. */
+int icv_set_option(const char* name, int value);
+
 /* ---- GEMM with fused epilogues (K1, K2, K4, K7, K9, K10, K11 of SURVEY §8a-3) ------------
  * C[M,N] = A[M,K] (bf16, lda) x W[N,K]^T (bf16, torch Linear layout, ldw)  (+ bias f32[N])
  * Replaces the nn.Linear / Conv3d-as-GEMM calls inside diffsynth's WanModel reached from

@@ -22,6 +22,27 @@ int icv_check_launch(const char* what) {
   return 0;
 }
 
+// ---- runtime options (A/B switches for kernel variants; defaults are the shipped configuration) ----
+#include <map>
+#include <mutex>
+#include <string>
+static std::map<std::string, int> g_opts;
+static std::mutex g_opts_mu;
+int icv_get_option_int(const char* name, int dflt) {
+  std::lock_guard<std::mutex> lk(g_opts_mu);
+  auto it = g_opts.find(name);
+  return it == g_opts.end() ? dflt : it->second;
+}
+extern "C" int icv_set_option(const char* name, int value) {
+  if (!name) {
+    icv_set_error("icv_set_option: null name");
+    return 1;
+  }
+  std::lock_guard<std::mutex> lk(g_opts_mu);
+  g_opts[name] = value;
+  return 0;
+}
+
 extern "C" int icv_abi_version(void) { return ICV_ABI_VERSION; }
 extern "C" const char* icv_last_error(void) { return g_err; }
 

@@ -167,6 +167,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 
 }  // namespace
 
+int icv_gemm256_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                         int64_t M, int64_t N, int64_t K, int epilogue, void* out, int64_t ldo,
+                         int64_t nsplit, int64_t split_stride, const float* resid, int64_t ldr,
+                         const float* gate, hipStream_t st);
+int icv_get_option_int(const char* name, int dflt);
+
 extern "C" int icv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw,
                              const float* bias, int64_t M, int64_t N, int64_t K, int epilogue,
                              void* out, int64_t ldo, int64_t nsplit, int64_t split_stride,
@@ -177,6 +183,10 @@ extern "C" int icv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t 
   if (nsplit <= 0) nsplit = N;
   ICV_REQUIRE(nsplit % 4 == 0 && N % nsplit == 0, "icv_gemm_bf16: nsplit must divide N and be a multiple of 4");
   ICV_REQUIRE(epilogue != ICV_EPI_RESID_F32 || (resid && ldr % 4 == 0 && nsplit == N), "icv_gemm_bf16: RESID epilogue needs resid, ldr%%4==0, no split");
+  // large problems: 256x256 tile, 8 waves, 4-phase staggered schedule (gemm256.hip)
+  if (N % 256 == 0 && M >= 256 && icv_get_option_int("gemm256", 1))
+    return icv_gemm256_dispatch(A, lda, W, ldw, bias, M, N, K, epilogue, out, ldo, nsplit, split_stride,
+                                resid, ldr, gate, (hipStream_t)stream);
   GemmParams p;
   p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.bias = bias;
   p.M = M; p.N = N; p.K = K; p.out = out; p.ldo = ldo; p.nsplit = nsplit; p.split_stride = split_stride;

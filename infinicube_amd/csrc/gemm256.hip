@@ -1,0 +1,285 @@
+// 256x256x64 bf16 MFMA GEMM, 8 waves, 4 phases per K-tile, LDS-DMA with counted vmcnt, two wave
+// groups staggered by one barrier (one group issues MFMAs while the other reads LDS / issues DMA).
+// Same math/epilogues as gemm.hip; used when N % 256 == 0 and the problem is large.
+//
+// Geometry: block tile 256(M) x 256(N) x 64(K); waves = 2 (wr) x 4 (wc); wave tile 128 x 64 =
+// a-halves {a0,a1} (64 rows each) x b-halves {b0,b1} (32 cols each); v_mfma_f32_16x16x32_bf16,
+// operands swapped (W fragment = A operand) so a lane owns 4 consecutive n (vector epilogue).
+// LDS: 2 stages x 4 units x 16 KiB = 128 KiB.  A "unit" is what ONE phase needs from ALL waves:
+//   A0 = rows {wr*128 + [0,64)},  A1 = rows {wr*128 + 64 + [0,64)},
+//   B0 = cols {wc*64 + [0,32)},   B1 = cols {wc*64 + 32 + [0,32)}      (128 rows x 128 B each)
+// unit image: [128 rows][8 chunks of 16 B], physical chunk = logical ^ ((row>>1)&7) applied on the
+// DMA *source* address and mirrored on ds_read_b128 (conflict-free, see gemm.hip).
+//
+// Per K-tile t (stage s = t&1), every phase = L-segment ; barrier ; 16 MFMA ; barrier :
+//   ph1: read a0,b0 | DMA B1(t+1)->s^1 | vmcnt(8) |  a0 x b0
+//   ph2: read b1    | DMA A1(t+1)->s^1 | vmcnt(8) |  a0 x b1
+//   ph3: read a1    | DMA A0(t+2)->s   |          |  a1 x b1
+//   ph4: --         | DMA B0(t+2)->s   | vmcnt(8) |  a1 x b0   (b0 kept in VGPRs)
+// Invariants (wave group 1 runs one barrier behind group 0):
+//   RAW: a unit is read one phase AFTER the phase whose vmcnt retired it (every wave's share has
+//        landed and a barrier separates the wait from the read).  vmcnt(8) = 4 younger units in flight.
+//   WAR: a slot is re-staged >= 2 phases after its last ds_read (A0: read ph1, DMA ph3).
+//   Tail tiles re-load the last tile (clamped k) so the counted waits stay uniform.
+#include "icv_common.h"
+
+namespace g256 {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int UNIT_BYTES = 128 * 128;         // 16 KiB
+constexpr int STAGE_BYTES = 4 * UNIT_BYTES;   // A0 A1 B0 B1
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;    // 128 KiB
+constexpr int U_A0 = 0, U_A1 = 1, U_B0 = 2, U_B1 = 3;
+
+struct Params {
+  const bf16_t* A; int64_t lda;
+  const bf16_t* W; int64_t ldw;
+  const float* bias;
+  int64_t M, N, K;
+  void* out; int64_t ldo; int64_t nsplit; int64_t split_stride;
+  const float* resid; int64_t ldr;
+  const float* gate;
+  int tiles_m, tiles_n;
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+#define G256_BARRIER()                      \
+  do {                                      \
+    asm volatile("" ::: "memory");          \
+    __builtin_amdgcn_s_barrier();           \
+    asm volatile("" ::: "memory");          \
+  } while (0)
+#define G256_VMCNT8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+
+__device__ __forceinline__ void dma_unit(const char* __restrict__ base, const unsigned (&off)[2],
+                                         int64_t kbyte, char* lds_unit, int wave) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const char* src = base + (int64_t)off[q] + kbyte;
+    char* dst = lds_unit + q * 8192 + wave * 1024;  // wave-uniform; HW adds lane*16
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  // ---- block -> tile (bijective XCD remap + grouped order) ----
+  const int nwg = p.tiles_m * p.tiles_n;
+  int wg;
+  {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  constexpr int GM = 4;
+  const int group_size = GM * p.tiles_n;
+  const int g = wg / group_size;
+  const int first_m = g * GM;
+  const int gm = min(p.tiles_m - first_m, GM);
+  const int tm = first_m + (wg % group_size) % gm;
+  const int tn = (wg % group_size) / gm;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+  // ---- per-thread DMA source offsets (bytes from A / W base, k = 0), 2 passes per unit ----
+  unsigned offA[2][2], offB[2][2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int u = q * 64 + (tid >> 3);            // unit row 0..127
+    const int pc = tid & 7;
+    const int c = pc ^ ((u >> 1) & 7);            // logical 16-B chunk held by physical chunk pc
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int64_t ra = m0 + (u >> 6) * 128 + h * 64 + (u & 63);
+      ra = ra < p.M ? ra : p.M - 1;
+      offA[h][q] = (unsigned)((ra * p.lda + c * 8) * 2);
+      int64_t rb = n0 + (u >> 5) * 64 + h * 32 + (u & 31);
+      rb = rb < p.N ? rb : p.N - 1;
+      offB[h][q] = (unsigned)((rb * p.ldw + c * 8) * 2);
+    }
+  }
+  const char* Ab = reinterpret_cast<const char*>(p.A);
+  const char* Wb = reinterpret_cast<const char*>(p.W);
+  const int nt = (int)(p.K / BK);
+  auto kbyte = [&](int t) -> int64_t { return (int64_t)(t < nt ? t : nt - 1) * (BK * 2); };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- fragment read addressing: lane (fr = row in 16-row frag, kq = 8-wide k chunk) ----
+  const int fr = lane & 15, kq = lane >> 4;
+  // a-frag i (0..3) of a-half: unit row = wr*64 + i*16 + fr ; b-frag j (0..1): unit row = wc*32 + j*16 + fr
+  int a_off[2], b_off[2];  // byte offset within a unit for ks = 0,1 minus the i/j row term
+  const int ar = wr * 64 + fr, br = wc * 32 + fr;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    // (row + 16*i) keeps ((row>>1)&7) ^ pattern: (16*i)>>1 = 8*i does not touch bits 0..2 -> same swizzle
+    a_off[ks] = ar * 128 + (((ks * 4 + kq) ^ ((ar >> 1) & 7)) << 4);
+    b_off[ks] = br * 128 + (((ks * 4 + kq) ^ ((br >> 1) & 7)) << 4);
+  }
+
+  // ---- prologue: tile 0 complete + A0,B0 of tile 1 ----
+  dma_unit(Ab, offA[0], kbyte(0), smem + U_A0 * UNIT_BYTES, wave);
+  dma_unit(Wb, offB[0], kbyte(0), smem + U_B0 * UNIT_BYTES, wave);
+  dma_unit(Wb, offB[1], kbyte(0), smem + U_B1 * UNIT_BYTES, wave);
+  dma_unit(Ab, offA[1], kbyte(0), smem + U_A1 * UNIT_BYTES, wave);
+  dma_unit(Ab, offA[0], kbyte(1), smem + STAGE_BYTES + U_A0 * UNIT_BYTES, wave);
+  dma_unit(Wb, offB[0], kbyte(1), smem + STAGE_BYTES + U_B0 * UNIT_BYTES, wave);
+  G256_VMCNT8();     // A0(0), B0(0) landed (4 younger units in flight)
+  G256_BARRIER();
+  if (wr == 1) G256_BARRIER();  // stagger: group 1 runs one barrier behind group 0
+
+  bf16x8 af[4][2], b0f[2][2], b1f[2][2];
+
+#define G256_MFMA(AH, BF, BH)                                                                   \
+  {                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    __builtin_amdgcn_s_setprio(1);                                                              \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                            \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                               \
+      acc[(AH) * 4 + i][(BH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                \
+          BF[j][ks], af[i][ks], acc[(AH) * 4 + i][(BH) * 2 + j], 0, 0, 0);                      \
+    __builtin_amdgcn_s_setprio(0);                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+  }
+
+  for (int t = 0; t < nt; ++t) {
+    char* cur = smem + (t & 1) * STAGE_BYTES;
+    char* oth = smem + ((t + 1) & 1) * STAGE_BYTES;
+    // ---------------- phase 1: a0 x b0 ----------------
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        b0f[j][ks] = *reinterpret_cast<const bf16x8*>(cur + U_B0 * UNIT_BYTES + b_off[ks] + j * 2048);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        af[i][ks] = *reinterpret_cast<const bf16x8*>(cur + U_A0 * UNIT_BYTES + a_off[ks] + i * 2048);
+    }
+    dma_unit(Wb, offB[1], kbyte(t + 1), oth + U_B1 * UNIT_BYTES, wave);
+    G256_VMCNT8();
+    G256_BARRIER();
+    G256_MFMA(0, b0f, 0);
+    G256_BARRIER();
+    // ---------------- phase 2: a0 x b1 ----------------
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        b1f[j][ks] = *reinterpret_cast<const bf16x8*>(cur + U_B1 * UNIT_BYTES + b_off[ks] + j * 2048);
+    dma_unit(Ab, offA[1], kbyte(t + 1), oth + U_A1 * UNIT_BYTES, wave);
+    G256_VMCNT8();
+    G256_BARRIER();
+    G256_MFMA(0, b1f, 1);
+    G256_BARRIER();
+    // ---------------- phase 3: a1 x b1 ----------------
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        af[i][ks] = *reinterpret_cast<const bf16x8*>(cur + U_A1 * UNIT_BYTES + a_off[ks] + i * 2048);
+    dma_unit(Ab, offA[0], kbyte(t + 2), cur + U_A0 * UNIT_BYTES, wave);
+    G256_BARRIER();
+    G256_MFMA(1, b1f, 1);
+    G256_BARRIER();
+    // ---------------- phase 4: a1 x b0 ----------------
+    dma_unit(Wb, offB[0], kbyte(t + 2), cur + U_B0 * UNIT_BYTES, wave);
+    G256_VMCNT8();
+    G256_BARRIER();
+    G256_MFMA(1, b0f, 0);
+    G256_BARRIER();
+  }
+#undef G256_MFMA
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain tail DMA before the LDS is released
+  if (wr == 0) G256_BARRIER();                       // re-balance the stagger
+
+  // ---- epilogue: lane owns m = fr, n = kq*4 + 0..3 of each 16x16 fragment ----
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int64_t m = m0 + wr * 128 + (i >> 2) * 64 + (i & 3) * 16 + fr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + wc * 64 + (j >> 1) * 32 + (j & 1) * 16 + kq * 4;
+      if (n >= p.N) continue;
+      f32x4 v = acc[i][j];
+      if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      const int64_t sub = n / p.nsplit, col = n - sub * p.nsplit;
+      const int64_t off = sub * p.split_stride + m * p.ldo + col;
+      if (EPI == ICV_EPI_BF16 || EPI == ICV_EPI_GELU_BF16) {
+        if (EPI == ICV_EPI_GELU_BF16) {
+          v[0] = gelu_tanh(v[0]); v[1] = gelu_tanh(v[1]); v[2] = gelu_tanh(v[2]); v[3] = gelu_tanh(v[3]);
+        }
+        *reinterpret_cast<uint2*>((bf16_t*)p.out + off) =
+            make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      } else if (EPI == ICV_EPI_RESID_F32) {
+        const float4 r = *reinterpret_cast<const float4*>(p.resid + m * p.ldr + n);
+        float4 o;
+        if (p.gate) {
+          const float4 gt = *reinterpret_cast<const float4*>(p.gate + n);
+          o = make_float4(r.x + gt.x * v[0], r.y + gt.y * v[1], r.z + gt.z * v[2], r.w + gt.w * v[3]);
+        } else {
+          o = make_float4(r.x + v[0], r.y + v[1], r.z + v[2], r.w + v[3]);
+        }
+        *reinterpret_cast<float4*>((float*)p.out + off) = o;
+      } else {
+        *reinterpret_cast<float4*>((float*)p.out + off) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+template <int EPI>
+int launch(const Params& p, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) {
+      icv_set_error("gemm256: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return 2;
+    }
+    attr_set = true;
+  }
+  const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
+  hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p);
+  return icv_check_launch("icv_gemm_bf16(256)");
+}
+
+}  // namespace g256
+
+// Called by icv_gemm_bf16 (gemm.hip) when the shape qualifies.
+int icv_gemm256_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                         int64_t M, int64_t N, int64_t K, int epilogue, void* out, int64_t ldo,
+                         int64_t nsplit, int64_t split_stride, const float* resid, int64_t ldr,
+                         const float* gate, hipStream_t st) {
+  g256::Params p;
+  p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.bias = bias;
+  p.M = M; p.N = N; p.K = K; p.out = out; p.ldo = ldo; p.nsplit = nsplit; p.split_stride = split_stride;
+  p.resid = resid; p.ldr = ldr; p.gate = gate;
+  p.tiles_m = (int)((M + g256::BM - 1) / g256::BM);
+  p.tiles_n = (int)((N + g256::BN - 1) / g256::BN);
+  switch (epilogue) {
+    case ICV_EPI_BF16: return g256::launch<ICV_EPI_BF16>(p, st);
+    case ICV_EPI_GELU_BF16: return g256::launch<ICV_EPI_GELU_BF16>(p, st);
+    case ICV_EPI_RESID_F32: return g256::launch<ICV_EPI_RESID_F32>(p, st);
+    case ICV_EPI_F32: return g256::launch<ICV_EPI_F32>(p, st);
+  }
+  icv_set_error("icv_gemm_bf16: unknown epilogue %d", epilogue);
+  return 1;
+}

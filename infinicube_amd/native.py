@@ -26,6 +26,7 @@ SIGNATURES = {
     "icv_abi_version": (c_int, []),
     "icv_last_error": (c_char_p, []),
     "icv_device_info": (c_int, [c_int, ctypes.POINTER(c_int64)]),
+    "icv_set_option": (c_int, [c_char_p, c_int]),
     "icv_gemm_bf16": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, c_int, _P, _I, _I, _I, _P, _I, _P, _P]),
     "icv_gemv_f32": (c_int, [_P, _P, _P, _P, _I, _I, _I, c_int, c_int, _P]),
     "icv_sinusoidal_embedding": (c_int, [c_double, _I, _P, _P]),

@@ -78,7 +78,8 @@ def test_rmsnorm_rope(hip_ops, d):
     assert_bf16_close(g2, R.rms_norm(planes[2].float(), w0, 1e-6), "rms only")
 
 
-GEMM_SHAPES = [(200, 256, 128), (1, 256, 64), (129, 64, 256), (1000, 1536, 1536), (777, 512, 8960), (300, 4608, 1536)]
+GEMM_SHAPES = [(200, 256, 128), (1, 256, 64), (129, 64, 256), (1000, 1536, 1536), (777, 512, 8960), (300, 4608, 1536),
+               (256, 256, 64), (2000, 768, 192), (513, 1280, 1024)]
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
@@ -105,6 +106,30 @@ def test_gemm(hip_ops, M, N, K, epi):
         out = torch.empty((M, N), device=DEV)
         hip_ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out, epi)
         assert_f32_close(out, acc, what="gemm f32")
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_gemm_variants_agree_and_race_screen(hip_ops, variant):
+    """128-tile kernel vs 256-tile 4-phase kernel on the same problem (compare both to the oracle),
+    repeated to screen the counted-vmcnt schedule for races: every repeat must be bit-identical."""
+    M, N, K = 1500, 1024, 2048
+    a = rnd((M, K), 121).to(torch.bfloat16).to(DEV)
+    w = rnd((N, K), 122, 1.0 / math.sqrt(K)).to(torch.bfloat16).to(DEV)
+    bias = rnd((N,), 123, 0.1).to(DEV)
+    ref = a.float().cpu() @ w.float().cpu().t() + bias.cpu()
+    hip_ops.lib.icv_set_option(b"gemm256", variant)
+    try:
+        outs = []
+        for _ in range(6):
+            out = torch.empty((M, N), device=DEV)
+            hip_ops.gemm(a, w, bias, out, EPI_F32)
+            outs.append(out)
+        torch.cuda.synchronize()
+    finally:
+        hip_ops.lib.icv_set_option(b"gemm256", 1)
+    assert_f32_close(outs[0], ref, what=f"gemm variant {variant}")
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0]), "non-deterministic GEMM result (race in the pipelined schedule?)"
 
 
 def test_gemm_split_and_strided(hip_ops):
