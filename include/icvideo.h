@@ -93,6 +93,16 @@ int icv_attention_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, co
                       int64_t ldv, void* o, int64_t ldo, int64_t Sq, int64_t Skv, int64_t heads,
                       float scale, void* stream);
 
+/* ---- K6 split along the KEY axis (K13 overlap): attention over one chunk of keys with a carried
+ * online-softmax state, so the sequence-parallel path can consume K/V chunks as the RCCL all-gather
+ * delivers them.  State = acc f32 [Sq, H*128] (ldacc; un-normalised O) + ml f32 [Sq, H, 2] (running
+ * max, row sum).  first != 0: start from the empty state (acc/ml not read).  last != 0: normalise and
+ * write o (bf16); otherwise write the state back.  Key order across chunks is irrelevant. */
+int icv_attention_fwd_chunk(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
+                            int64_t ldv, void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml,
+                            int64_t Sq, int64_t Skv, int64_t heads, float scale, int first, int last,
+                            void* stream);
+
 /* ---- K1: im2col for Conv3d(k = s = (1,2,2)) on a [C,T,H8,W8] f32 latent -------------------
  * out bf16 [n_tok, C*4] (ldo), row = token tok0 + r (f, hp, wp; wp fastest),
  * col = c*4 + y*2 + z  (== conv weight [d, C, 1, 2, 2] flattened). */

@@ -10,7 +10,7 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$root/include" -I"$here" -W
 objs=()
 pids=()
 mkdir -p "$here/build"
-for src in api elementwise gemm gemm256 attn; do
+for src in api elementwise gemm gemm256 attn attn2; do
   obj="$here/build/$src.o"
   if [[ ! -f "$obj" || "$here/$src.hip" -nt "$obj" || "$here/icv_common.h" -nt "$obj" || "$root/include/icvideo.h" -nt "$obj" ]]; then
     "$HIPCC" "${FLAGS[@]}" "$@" -c "$here/$src.hip" -o "$obj" &
@@ -20,4 +20,5 @@ for src in api elementwise gemm gemm256 attn; do
 done
 for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$out"
+python3 -c "import ctypes,sys; ctypes.CDLL(sys.argv[1])" "$out"   # unresolved symbols fail here, not on the GPU box
 echo "built $out"

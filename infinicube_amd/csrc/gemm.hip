@@ -171,7 +171,6 @@ int icv_gemm256_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw,
                          int64_t M, int64_t N, int64_t K, int epilogue, void* out, int64_t ldo,
                          int64_t nsplit, int64_t split_stride, const float* resid, int64_t ldr,
                          const float* gate, hipStream_t st);
-int icv_get_option_int(const char* name, int dflt);
 
 extern "C" int icv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw,
                              const float* bias, int64_t M, int64_t N, int64_t K, int epilogue,

@@ -18,6 +18,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 void icv_set_error(const char* fmt, ...);
 int icv_check_launch(const char* what);
+int icv_get_option_int(const char* name, int dflt);  // runtime A/B switches (icv_set_option)
 
 #define ICV_REQUIRE(cond, ...)            \
   do {                                    \

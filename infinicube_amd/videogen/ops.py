@@ -153,6 +153,22 @@ class HipOps:
             o.data_ptr(), o.stride(0), q.shape[0], k.shape[0], heads, scale, self._stream()),
             "icv_attention_fwd")
 
+    def attention_chunk(self, q, k, v, o, acc, ml, heads: int, scale: float, first: bool, last: bool):
+        """Attention over one chunk of keys with carried softmax state (acc f32 [Sq, H*128], ml f32
+        [Sq, H, 2]); ``first`` starts from the empty state, ``last`` normalises into ``o``."""
+        for t, nm in ((q, "q"), (k, "k"), (v, "v")):
+            _chk(t, BF16, f"attention_chunk.{nm}")
+        if o is not None:
+            _chk(o, BF16, "attention_chunk.o")
+        if acc is not None:
+            _chk(acc, F32, "attention_chunk.acc"); _chk(ml, F32, "attention_chunk.ml")
+            assert ml.is_contiguous() and tuple(ml.shape) == (q.shape[0], heads, 2)
+        native.check(self.lib.icv_attention_fwd_chunk(
+            q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
+            native.ptr(o), o.stride(0) if o is not None else 0, native.ptr(acc),
+            acc.stride(0) if acc is not None else 0, native.ptr(ml), q.shape[0], k.shape[0], heads, scale,
+            int(first), int(last), self._stream()), "icv_attention_fwd_chunk")
+
     def patchify(self, latent, out, tok0: int, n_tok: int):
         _chk(latent, F32, "patchify.latent"); _chk(out, BF16, "patchify.out")
         assert latent.is_contiguous()

@@ -1,0 +1,55 @@
+"""Micro-benchmark of icv_attention_fwd on the DiT shapes (run on the GPU box)."""
+import sys, os, math
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from infinicube_amd.videogen.ops import HipOps
+
+ops = HipOps("cuda:0")
+cases = [("1.3b self", 37440, 37440, 12), ("14b self", 37440, 37440, 40), ("sp8 14b", 4680, 37440, 40), ("14b cross", 37440, 512, 40)]
+if len(sys.argv) > 1:
+    cases = [c for c in cases if c[0].startswith(sys.argv[1])]
+n = int(os.environ.get("ATTN_ITERS", "3"))
+if os.environ.get("ATTN_ACC"):
+    # accuracy of the kernel vs fp64 attention on a moderately long sequence, per defer-max threshold
+    torch.manual_seed(0)
+    Sq, Skv, H = 1024, 4096, 2
+    q = torch.randn((Sq, H * 128), device="cuda").to(torch.bfloat16)
+    k = torch.randn((Skv, H * 128), device="cuda").to(torch.bfloat16)
+    v = torch.randn((Skv, H * 128), device="cuda").to(torch.bfloat16)
+    qh, kh, vh = (t.double().reshape(-1, H, 128).transpose(0, 1) for t in (q, k, v))
+    ref = (torch.softmax(qh @ kh.transpose(1, 2) / math.sqrt(128), -1) @ vh).transpose(0, 1).reshape(Sq, -1)
+    for thr in (0, 2, 4, 8):
+        ops.lib.icv_set_option(b"attn_defer_max_log2", thr)
+        o = torch.empty_like(q)
+        ops.attention(q, k, v, o, H, 128 ** -0.5)
+        e = (o.double() - ref)
+        print(f"thr={thr}: max|err| {e.abs().max():.3e}  rms err {e.pow(2).mean().sqrt():.3e}  (rms ref {ref.pow(2).mean().sqrt():.3e})")
+    ops.lib.icv_set_option(b"attn_defer_max_log2", int(os.environ.get("ATTN_THR", "8")))
+variants = [int(x) for x in os.environ.get("ATTN_VARIANTS", "5").split(",")]
+rounds = int(os.environ.get("ATTN_ROUNDS", "3"))
+for name, Sq, Skv, H in cases:
+    d = H * 128
+    q = torch.randn((Sq, d), device="cuda").to(torch.bfloat16)
+    k = torch.randn((Skv, d), device="cuda").to(torch.bfloat16)
+    v = torch.randn((Skv, d), device="cuda").to(torch.bfloat16)
+    o = torch.empty_like(q)
+    best = {vv: [] for vv in variants}
+    for rd in range(rounds):           # interleaved rounds: within-process A/B
+        for vv in variants:
+            # variant codes: <100 -> attn.hip variant; 1000+x -> attn2.hip variant x
+            if vv >= 1000:
+                ops.lib.icv_set_option(b"attn_kernel", 2); ops.lib.icv_set_option(b"attn2_variant", vv - 1000)
+            else:
+                ops.lib.icv_set_option(b"attn_kernel", 1); ops.lib.icv_set_option(b"attn_variant", vv)
+            ops.attention(q, k, v, o, H, 128 ** -0.5)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                ops.attention(q, k, v, o, H, 128 ** -0.5)
+            e1.record(); torch.cuda.synchronize()
+            best[vv].append(e0.elapsed_time(e1) / n)
+    fl = 4.0 * Sq * Skv * d
+    print(f"{name:10s} Sq={Sq} Skv={Skv} H={H}: " + " | ".join(
+        f"v{vv}: {fl / sorted(best[vv])[len(best[vv]) // 2] / 1e9:6.1f} TF (min {min(best[vv]):.3f} ms)" for vv in variants))
+ops.lib.icv_set_option(b"attn_variant", 5); ops.lib.icv_set_option(b"attn_kernel", 2); ops.lib.icv_set_option(b"attn2_variant", 4)

@@ -1,4 +1,2 @@
-set -x
-mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_kernels_gpu.py -q -x -k "gemm" 2>&1 | tail -15
-timeout 300 python tools/gemm_bench.py 2>&1 | tail -12
+mkdir -p gpurun_out; export TMPDIR=/tmp
+ATTN_VARIANTS=5,37,69,133,229,253 ATTN_ROUNDS=3 ATTN_ITERS=2 python tools/attn_bench.py 14b 2>&1 | grep -v amdgpu.ids
