@@ -31,7 +31,7 @@ import torch
 from .config import TokenGrid, WanDiTConfig
 from .ops import BF16, EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_F32, F32, RopeTable
 from .scheduler import FlowMatchScheduler
-from .seqpar import KVGather, ShardPlan
+from .seqpar import KVGather, ShardPlan, chunk_bounds
 
 ACT_SILU = 1
 
@@ -123,7 +123,7 @@ class WanDiT:
         self.buffer_embedder = convs
 
     # ------------------------------------------------------------------------------------
-    def prepare(self, grid: TokenGrid, plan: Optional[ShardPlan] = None, kv_gather=None):
+    def prepare(self, grid: TokenGrid, plan: Optional[ShardPlan] = None, kv_gather=None, sp_chunks: int = 4):
         """Allocate the per-generation workspace for this token grid / shard."""
         cfg, ops = self.cfg, self.ops
         self.grid = grid
@@ -148,11 +148,36 @@ class WanDiT:
         self.t_mod = a((1, 6 * d), F32)
         self._t_cached = None
         if self.plan.world > 1:
-            self.kv_full = a((2, S, d), BF16)
+            self.kv_full = a((2, S, d), BF16)                      # gathered K, V (chunk-major, rank-major inside)
+            self.sp_acc = a((n, d), F32)                           # carried O accumulator between key chunks
+            self.sp_ml = a((n, cfg.num_heads, 2), F32)             # carried (running max, row sum)
+            self.sp_bounds = chunk_bounds(n, sp_chunks)
             self.kv_gather = kv_gather or KVGather(self.plan)
         else:
             self.kv_full, self.kv_gather = None, None
         return self
+
+    def _sp_start_gather(self, k, v):
+        """K13: enqueue the all-gather of every K/V row-chunk (RCCL runs them back to back on its own
+        stream; chunk c = rows [r0, r1) of EVERY rank's shard, rank-major)."""
+        world, b = self.plan.world, self.sp_bounds
+        handles, bufs = [], []
+        for c in range(len(b) - 1):
+            r0, r1 = b[c], b[c + 1]
+            kf, vf = self.kv_full[0, world * r0: world * r1], self.kv_full[1, world * r0: world * r1]
+            bufs.append((kf, vf))
+            handles.append(self.kv_gather.start(k[r0:r1], v[r0:r1], kf, vf))
+        return handles, bufs
+
+    def _sp_attention(self, q, handles, bufs, H, scale):
+        """K6 pipelined with K13: attention consumes chunk c as soon as it has landed, carrying the
+        online-softmax state in fp32 between launches, while later chunks are still in flight."""
+        ops = self.ops
+        C = len(bufs)
+        for c in range(C):
+            self.kv_gather.wait(handles[c])
+            ops.attention_chunk(q, bufs[c][0], bufs[c][1], self.att, self.sp_acc, self.sp_ml, H, scale,
+                                first=(c == 0), last=(c == C - 1))
 
     # ------------------------------------------------------------------------------------
     def encode_context(self, context: torch.Tensor) -> ContextKV:
@@ -230,12 +255,17 @@ class WanDiT:
             sh2, sc2, g2 = m[3 * d:4 * d], m[4 * d:5 * d], m[5 * d:6 * d]
             # --- self-attention ---
             ops.ln_modulate(self.x, self.h, shift=sh1, scale=sc1, eps=eps)                  # K3
-            ops.gemm(self.h, lw["wqkv"], lw["bqkv"], self.qkv, EPI_BF16, nsplit=d)          # K4
-            ops.rmsnorm_rope(q, lw["nq"], k, lw["nk"], eps=eps, rope=self.rope, tok0=plan.tok0)  # K5
             if plan.world > 1:
-                self.kv_gather(k, v, self.kv_full[0], self.kv_full[1])                      # K13
-                ops.attention(q, self.kv_full[0], self.kv_full[1], self.att, H, scale)      # K6
+                # K and V first, so their all-gather (K13) is already moving while Q is projected
+                ops.gemm(self.h, lw["wqkv"][d:], lw["bqkv"][d:], self.qkv[1:], EPI_BF16, nsplit=d)   # K4 (k, v)
+                ops.rmsnorm_rope(k, lw["nk"], eps=eps, rope=self.rope, tok0=plan.tok0)               # K5 (k)
+                handles, bufs = self._sp_start_gather(k, v)
+                ops.gemm(self.h, lw["wqkv"][:d], lw["bqkv"][:d], q, EPI_BF16)                        # K4 (q)
+                ops.rmsnorm_rope(q, lw["nq"], eps=eps, rope=self.rope, tok0=plan.tok0)               # K5 (q)
+                self._sp_attention(q, handles, bufs, H, scale)                                       # K6
             else:
+                ops.gemm(self.h, lw["wqkv"], lw["bqkv"], self.qkv, EPI_BF16, nsplit=d)      # K4
+                ops.rmsnorm_rope(q, lw["nq"], k, lw["nk"], eps=eps, rope=self.rope, tok0=plan.tok0)  # K5
                 ops.attention(q, k, v, self.att, H, scale)                                  # K6
             ops.gemm(self.att, lw["wo"], lw["bo"], self.x, EPI_RESID_F32, resid=self.x, gate=g1)  # K7
             # --- cross-attention to text (no gate) ---

@@ -36,7 +36,14 @@ class ShardPlan:
 
 
 class KVGather:
-    """All-gather of the local K and V shards [n_tok, d] into full [S, d] buffers."""
+    """Chunked, asynchronous all-gather of the local K and V shards.
+
+    ``start(k_rows, v_rows, k_out, v_out)`` enqueues the all-gather of ONE row-chunk of the local
+    shard ([m, d] from every rank -> [world*m, d], rank-major) and returns a handle; ``wait(handle)``
+    makes the compute stream wait for that chunk only.  With the ``nccl`` backend (= RCCL over xGMI) the
+    collectives run on RCCL's own stream, so chunk c+1 is in flight while attention consumes chunk c
+    (dit.WanDiT._sp_attention).  Attention is invariant to key order, so a chunk does not have to be a
+    contiguous range of global tokens."""
 
     def __init__(self, plan: ShardPlan, group=None):
         self.plan = plan
@@ -47,13 +54,31 @@ class KVGather:
                 raise RuntimeError("KVGather with world>1 needs torch.distributed to be initialised")
             self.dist = dist
 
-    def __call__(self, k_loc: torch.Tensor, v_loc: torch.Tensor, k_full: torch.Tensor, v_full: torch.Tensor):
+    def start(self, k_rows: torch.Tensor, v_rows: torch.Tensor, k_out: torch.Tensor, v_out: torch.Tensor):
         if self.plan.world == 1:
-            raise RuntimeError("KVGather called with world == 1 (attend over the local buffers directly)")
-        assert k_loc.is_contiguous() and v_loc.is_contiguous() and k_full.is_contiguous() and v_full.is_contiguous()
-        # rank-major concatenation == global token order because shards are contiguous token ranges
-        self.dist.all_gather_into_tensor(k_full, k_loc, group=self.group)
-        self.dist.all_gather_into_tensor(v_full, v_loc, group=self.group)
+            raise RuntimeError("KVGather used with world == 1 (attend over the local buffers directly)")
+        assert k_rows.is_contiguous() and v_rows.is_contiguous() and k_out.is_contiguous() and v_out.is_contiguous()
+        assert k_out.shape[0] == self.plan.world * k_rows.shape[0]
+        return (self.dist.all_gather_into_tensor(k_out, k_rows, group=self.group, async_op=True),
+                self.dist.all_gather_into_tensor(v_out, v_rows, group=self.group, async_op=True))
+
+    def wait(self, handle) -> None:
+        for w in handle:
+            w.wait()   # nccl: the CURRENT STREAM waits (host does not block); gloo: host blocks
+
+
+def chunk_bounds(n_rows: int, chunks: int):
+    """Row boundaries of the K/V gather chunks of one shard (identical on every rank).  The sizes RAMP
+    (weights 1, 3, 6, 6, ...): only the first chunk's transfer is exposed before attention can start,
+    so it is small; later chunks are large so launches stay efficient and each transfer hides under the
+    previous chunk's attention."""
+    chunks = max(1, min(chunks, n_rows))
+    w = [1.0, 3.0][:chunks] + [6.0] * max(0, chunks - 2)
+    tot, acc, out = sum(w), 0.0, [0]
+    for c in range(chunks):
+        acc += w[c]
+        out.append(n_rows if c == chunks - 1 else max(out[-1] + 1, int(round(n_rows * acc / tot))))
+    return out
 
 
 def gather_latent(latent: torch.Tensor, plan: ShardPlan, grid, group=None) -> torch.Tensor:

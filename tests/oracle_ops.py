@@ -85,6 +85,32 @@ class OracleOps:
         assert abs(scale - 1.0 / math.sqrt(q.shape[1] // heads)) < 1e-9
         o.copy_(R.attention(q.float(), k.float(), v.float(), heads).to(BF16))
 
+    def attention_chunk(self, q, k, v, o, acc, ml, heads, scale, first, last):
+        """Online-softmax over one chunk of keys with carried (acc, m, l) state, fp32."""
+        Sq, d = q.shape
+        qh = q.float().reshape(Sq, heads, -1).transpose(0, 1)
+        kh = k.float().reshape(k.shape[0], heads, -1).transpose(0, 1)
+        vh = v.float().reshape(v.shape[0], heads, -1).transpose(0, 1)
+        s = qh @ kh.transpose(1, 2) * scale                                  # [H, Sq, Sk]
+        if first:
+            m_old = torch.full((heads, Sq), -1e30)
+            l_old = torch.zeros((heads, Sq))
+            a_old = torch.zeros((heads, Sq, d // heads))
+        else:
+            m_old, l_old = ml[:, :, 0].t().clone(), ml[:, :, 1].t().clone()
+            a_old = acc.reshape(Sq, heads, -1).transpose(0, 1).clone()
+        m_new = torch.maximum(m_old, s.max(dim=-1).values)
+        alpha = torch.exp(m_old - m_new)
+        pmat = torch.exp(s - m_new[:, :, None])
+        l_new = l_old * alpha + pmat.sum(-1)
+        a_new = a_old * alpha[:, :, None] + pmat @ vh
+        if last:
+            o.copy_((a_new / l_new[:, :, None]).transpose(0, 1).reshape(Sq, d).to(BF16))
+        else:
+            acc.copy_(a_new.transpose(0, 1).reshape(Sq, d))
+            ml[:, :, 0] = m_new.t()
+            ml[:, :, 1] = l_new.t()
+
     def patchify(self, latent, out, tok0, n_tok):
         C, T, H8, W8 = latent.shape
         Hp, Wp = H8 // 2, W8 // 2

@@ -62,7 +62,8 @@ def test_loop_matches_oracle_and_time_cache():
     assert R.psnr(lat1, ref1) > 50.0
 
 
-def test_inprocess_two_shards_equal_unsharded():
+@pytest.mark.parametrize("chunks", [1, 3])
+def test_inprocess_two_shards_equal_unsharded(chunks):
     """Simulate world=2 in one process: run both shards with a gather that concatenates their K/V."""
     sd, bsd, noise, c1, _, bl = _inputs()
     full = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID)
@@ -82,22 +83,40 @@ def test_inprocess_two_shards_equal_unsharded():
     outs = []
     for r in range(2):
         plan = ShardPlan.make(GRID.S, 2, r)
-        layer = {"i": 0}
+        n = plan.n_tok
 
-        def fake_gather(k_loc, v_loc, k_full, v_full, plan=plan, layer=layer):
-            kf, vf = rec["kv"][layer["i"]]
-            # this rank's own rows must equal what it computed locally (RoPE offsets, shard indexing)
-            assert torch.equal(kf[plan.tok0: plan.tok0 + plan.n_tok], k_loc)
-            assert torch.equal(vf[plan.tok0: plan.tok0 + plan.n_tok], v_loc)
-            k_full.copy_(kf); v_full.copy_(vf)
-            layer["i"] += 1
+        class FakeGather:
+            """Stands in for RCCL: serves chunk (r0, r1) of every rank's shard from the recorded full K/V."""
+            def __init__(self):
+                self.layer, self.calls = 0, 0
+
+            def start(self, k_rows, v_rows, k_out, v_out):
+                kf, vf = rec["kv"][self.layer]
+                m = k_rows.shape[0]
+                # locate this chunk inside the local shard by matching rows (RoPE offsets, shard indexing)
+                for r0 in range(0, n - m + 1):
+                    if torch.equal(kf[plan.tok0 + r0: plan.tok0 + r0 + m], k_rows):
+                        break
+                else:
+                    raise AssertionError("local K rows do not match the unsharded run")
+                assert torch.equal(vf[plan.tok0 + r0: plan.tok0 + r0 + m], v_rows)
+                k_out.copy_(torch.cat([kf[rk * n + r0: rk * n + r0 + m] for rk in range(2)], 0))
+                v_out.copy_(torch.cat([vf[rk * n + r0: rk * n + r0 + m] for rk in range(2)], 0))
+                self.calls += 1
+                if self.calls % chunks == 0:
+                    self.layer += 1
+                return ()
+
+            def wait(self, handle):
+                pass
 
         m = WanDiT(CFG, sd, OracleOps(), bsd)
-        # world>1 without torch.distributed: inject the gather
-        m.prepare(GRID, plan, kv_gather=fake_gather)
+        m.prepare(GRID, plan, kv_gather=FakeGather(), sp_chunks=chunks)   # world>1 without torch.distributed
         m.forward_tokens(noise.clone(), m.encode_context(c1), 300.0, m.embed_buffers(bl), m.head_out[0])
         outs.append(m.head_out[0].clone())
-    assert torch.equal(torch.cat(outs, 0), full.head_out[0])
+    got, want = torch.cat(outs, 0), full.head_out[0]
+    # chunked online softmax reorders fp32 sums (and a flipped bf16 rounding can propagate): rounding-level
+    assert float((got - want).norm() / want.norm()) < 2e-3
 
 
 def _sp_worker(rank, world, port, q):

@@ -53,3 +53,26 @@ for name, Sq, Skv, H in cases:
     print(f"{name:10s} Sq={Sq} Skv={Skv} H={H}: " + " | ".join(
         f"v{vv}: {fl / sorted(best[vv])[len(best[vv]) // 2] / 1e9:6.1f} TF (min {min(best[vv]):.3f} ms)" for vv in variants))
 ops.lib.icv_set_option(b"attn_variant", 5); ops.lib.icv_set_option(b"attn_kernel", 2); ops.lib.icv_set_option(b"attn2_variant", 4)
+
+# cost of splitting one self-attention over C key chunks with carried state (sequence-parallel path)
+if os.environ.get("ATTN_CHUNKS"):
+    for world in (8, 2):
+        Sq, Skv, H = 37440 // world, 37440, 40
+        d = H * 128
+        q = torch.randn((Sq, d), device="cuda").to(torch.bfloat16)
+        k = torch.randn((Skv, d), device="cuda").to(torch.bfloat16)
+        v = torch.randn((Skv, d), device="cuda").to(torch.bfloat16)
+        o = torch.empty_like(q); acc = torch.empty((Sq, d), device="cuda"); ml = torch.empty((Sq, H, 2), device="cuda")
+        for C in (1, 2, 4, 8):
+            b = [(Skv * c) // C for c in range(C + 1)]
+            def run():
+                for c in range(C):
+                    ops.attention_chunk(q, k[b[c]:b[c + 1]], v[b[c]:b[c + 1]], o, acc, ml, H, 128 ** -0.5, first=(c == 0), last=(c == C - 1))
+            run(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                run()
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 3
+            print(f"world={world} Sq={Sq}: {C} chunk(s): {ms:7.3f} ms  {4.0 * Sq * Skv * d / ms / 1e9:7.1f} TF")
