@@ -200,6 +200,13 @@ def main():
     attn_tflops = attn_flops / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
     f_step = 2.0 * dit_forward_flops(cfg, grid.S)
 
+    traffic = None
+    try:   # HBM bytes per self-attention launch, measured offline with rocprofv3 PMC passes (see profiles/)
+        tj = json.load(open(os.path.join(ROOT, "profiles", "attn_traffic.json")))
+        if world == 1 and args.model in tj and (args.frames, args.height, args.width) == (93, 480, 832):
+            traffic = tj[args.model]["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
     if rank == 0:
         out = {
             "metric": "denoise steps/sec, 93-frame 480p Wan2.1 buffer-conditioned DiT loop",
@@ -226,7 +233,7 @@ def main():
             "roofline": {
                 "kernel": "att2::attn2_kernel (self-attention, K6)",
                 "bound": "mfma", "achieved": attn_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": attn_tflops / PEAK_BF16_TFLOPS, "traffic": None,
+                "frac": attn_tflops / PEAK_BF16_TFLOPS, "traffic": traffic,
                 "avg_launch_ms": attn_ms, "launches_timed": len(attn_events),
                 "algorithmic_flop_per_launch": attn_flops,
             },
