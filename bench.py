@@ -91,9 +91,11 @@ def cpu_baseline(cfg, grid, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--model", default=os.environ.get("ICV_BENCH_MODEL", "1.3b"), choices=["1.3b", "14b", "small", "tiny"])
+    # default = Wan2.1-14B: BASELINE.json quotes its metric/target (>= 1.0 step/s on 8 GPUs, >= 6x scaling) and
+    # its multi-GPU config on the 14B model, and 14B (28 GB bf16) fits one 288 GB MI355X
+    ap.add_argument("--model", default=os.environ.get("ICV_BENCH_MODEL", "14b"), choices=["1.3b", "14b", "small", "tiny"])
     ap.add_argument("--frames", type=int, default=GRID_480P.num_frames)
     ap.add_argument("--height", type=int, default=GRID_480P.height)
     ap.add_argument("--width", type=int, default=GRID_480P.width)

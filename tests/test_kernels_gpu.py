@@ -253,8 +253,58 @@ def test_attention2_variants(hip_ops, variant):
         hip_ops.lib.icv_set_option(b"attn2_variant", 4)
 
 
+@pytest.mark.parametrize("variant", [0, 4])
+def test_attention3_variants(hip_ops, variant):
+    """attn3.hip (one wave per SIMD, 64 query rows per wave, shared K/V fragments)."""
+    H = 2
+    d = H * 128
+    hip_ops.lib.icv_set_option(b"attn_kernel", 3)
+    hip_ops.lib.icv_set_option(b"attn3_variant", variant)
+    try:
+        for Sq, Skv in ((300, 1100), (64, 64), (257, 65), (33, 129), (513, 640), (1000, 3000)):
+            q, k, v = (rnd((Sq, d), 191).to(torch.bfloat16), rnd((Skv, d), 192).to(torch.bfloat16), rnd((Skv, d), 193).to(torch.bfloat16))
+            k[Skv - 1] = q[3] * 5.0
+            k[Skv // 2] = q[min(40, Sq - 1)] * 5.0
+            ref = R.attention(q.float(), k.float(), v.float(), H)
+            o = torch.zeros((Sq, d), dtype=torch.bfloat16, device=DEV)
+            hip_ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), o, H, 1.0 / math.sqrt(128))
+            o2 = torch.zeros_like(o)
+            hip_ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), o2, H, 1.0 / math.sqrt(128))
+            assert torch.equal(o, o2), "non-deterministic attention output (LDS staging race?)"
+            assert_bf16_close(o, ref, f"attn3 variant {variant} Sq={Sq} Skv={Skv}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
+    finally:
+        hip_ops.lib.icv_set_option(b"attn_kernel", 2)
+        hip_ops.lib.icv_set_option(b"attn3_variant", 0)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 4, 5, 6, 7])
+def test_attention4_variants(hip_ops, variant):
+    """attn4.hip (LDS-DMA staged 4-stage ring, counted vmcnt, optional stagger)."""
+    H = 2
+    d = H * 128
+    hip_ops.lib.icv_set_option(b"attn_kernel", 4)
+    hip_ops.lib.icv_set_option(b"attn4_variant", variant)
+    try:
+        for Sq, Skv in ((300, 1100), (64, 64), (257, 65), (33, 129), (513, 640), (1000, 3000), (40, 1), (256, 128), (256, 192)):
+            q, k, v = (rnd((Sq, d), 201).to(torch.bfloat16), rnd((Skv, d), 202).to(torch.bfloat16), rnd((Skv, d), 203).to(torch.bfloat16))
+            k[Skv - 1] = q[3] * 5.0
+            k[Skv // 2] = q[min(40, Sq - 1)] * 5.0
+            ref = R.attention(q.float(), k.float(), v.float(), H)
+            outs = []
+            for _ in range(3):
+                o = torch.zeros((Sq, d), dtype=torch.bfloat16, device=DEV)
+                hip_ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), o, H, 1.0 / math.sqrt(128))
+                outs.append(o)
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "non-deterministic output (DMA ring race?)"
+            assert_bf16_close(outs[0], ref, f"attn4 variant {variant} Sq={Sq} Skv={Skv}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
+    finally:
+        hip_ops.lib.icv_set_option(b"attn_kernel", 2)
+        hip_ops.lib.icv_set_option(b"attn4_variant", 4)
+
+
+@pytest.mark.parametrize("kernel", [2, 3, 4])
 @pytest.mark.parametrize("chunks", [[700], [128, 572], [300, 100, 300], [64, 64, 64, 508]])
-def test_attention_chunked_state(hip_ops, chunks):
+def test_attention_chunked_state(hip_ops, chunks, kernel):
     """Splitting the KEY axis over several launches with carried (O, m, l) state must reproduce the
     single-launch result: this is the kernel path the sequence-parallel K/V pipeline uses.  Chunks are
     also fed in a permuted order (key order is irrelevant to attention)."""
@@ -271,10 +321,15 @@ def test_attention_chunked_state(hip_ops, chunks):
     for c in chunks:
         bounds.append(bounds[-1] + c)
     order = list(range(len(chunks)))[::-1]     # reversed chunk order
-    for j, ci in enumerate(order):
-        lo, hi = bounds[ci], bounds[ci + 1]
-        hip_ops.attention_chunk(q, k[lo:hi], v[lo:hi], o, acc, ml, H, 1.0 / math.sqrt(128),
-                                first=(j == 0), last=(j == len(order) - 1))
+    hip_ops.lib.icv_set_option(b"attn_kernel", kernel)
+    try:
+        for j, ci in enumerate(order):
+            lo, hi = bounds[ci], bounds[ci + 1]
+            hip_ops.attention_chunk(q, k[lo:hi], v[lo:hi], o, acc, ml, H, 1.0 / math.sqrt(128),
+                                    first=(j == 0), last=(j == len(order) - 1))
+        torch.cuda.synchronize()
+    finally:
+        hip_ops.lib.icv_set_option(b"attn_kernel", 2)
     assert_bf16_close(o, ref, f"chunked attention {chunks}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
 
 

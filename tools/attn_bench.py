@@ -32,12 +32,18 @@ for name, Sq, Skv, H in cases:
     q = torch.randn((Sq, d), device="cuda").to(torch.bfloat16)
     k = torch.randn((Skv, d), device="cuda").to(torch.bfloat16)
     v = torch.randn((Skv, d), device="cuda").to(torch.bfloat16)
+    if os.environ.get("ATTN_ZERO"):
+        q.zero_(); k.zero_(); v.zero_()
     o = torch.empty_like(q)
     best = {vv: [] for vv in variants}
     for rd in range(rounds):           # interleaved rounds: within-process A/B
         for vv in variants:
             # variant codes: <100 -> attn.hip variant; 1000+x -> attn2.hip variant x
-            if vv >= 1000:
+            if vv >= 4000:
+                ops.lib.icv_set_option(b"attn_kernel", 4); ops.lib.icv_set_option(b"attn4_variant", vv - 4000)
+            elif vv >= 3000:
+                ops.lib.icv_set_option(b"attn_kernel", 3); ops.lib.icv_set_option(b"attn3_variant", vv - 3000)
+            elif vv >= 1000:
                 ops.lib.icv_set_option(b"attn_kernel", 2); ops.lib.icv_set_option(b"attn2_variant", vv - 1000)
             else:
                 ops.lib.icv_set_option(b"attn_kernel", 1); ops.lib.icv_set_option(b"attn_variant", vv)

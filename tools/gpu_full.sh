@@ -1,8 +1,8 @@
 # full GPU check: all -m gpu tests + both bench configs; results under gpurun_out/
 mkdir -p gpurun_out; export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -5
-python bench.py --model 1.3b --steps 3 --warmup 1 ${BENCH_EXTRA:-} > gpurun_out/bench_1p3b.json 2> gpurun_out/bench_1p3b.err || tail -5 gpurun_out/bench_1p3b.err
-python bench.py --model 14b --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_14b.json 2> gpurun_out/bench_14b.err || tail -5 gpurun_out/bench_14b.err
+python bench.py --model 1.3b --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_EXTRA:-} > gpurun_out/bench_1p3b.json 2> gpurun_out/bench_1p3b.err || tail -5 gpurun_out/bench_1p3b.err
+python bench.py --model 14b --steps 2 --warmup 1 > gpurun_out/bench_14b.json 2> gpurun_out/bench_14b.err || tail -5 gpurun_out/bench_14b.err
 python - <<'PY'
 import json
 for m in ("1p3b", "14b"):
