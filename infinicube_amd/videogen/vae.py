@@ -1,15 +1,272 @@
-"""Wan2.1 3-D VAE loader (outside the hot loop; stock PyTorch-ROCm).
+"""Wan2.1 3-D causal VAE on stock PyTorch-ROCm (outside the hot loop; north star: "Wan 3D-VAE decode
+run on stock PyTorch-ROCm").
 
-[R infinicube/videogen/inference.py:69,79] names the file ``Wan2.1_VAE.pth``.  Tiled encode/decode of
-the VAE is SURVEY.md §8f row 4 ("next"): not restated in round 1.  ``from_pretrained`` fails loudly."""
+The reference names the checkpoint ``Wan2.1_VAE.pth`` [R infinicube/videogen/inference.py:69,79] and
+passes ``tiled=True`` [R infinicube/videogen/inference.py:225]; the module itself lives in the absent
+diffsynth fork.  This restates the PUBLIC Wan2.1 VAE ([EXT], unverifiable offline): 4x temporal / 8x
+spatial compression, z_dim 16, base dim 96, dim_mult (1,2,4,4), 2 residual blocks per level, causal
+3-D convolutions, RMS norms, one single-head attention block in the middle, per-channel latent
+mean/std.  Module / parameter names mirror the public checkpoint layout (``encoder.downsamples.N...``,
+``decoder.upsamples.N...``, ``conv1``, ``conv2``) so ``load_state_dict(strict=True)`` verifies the
+restatement against real weights on first contact.
+
+MI355X-first difference: upstream streams the video through the network one 4-frame chunk at a time
+with a feature cache to fit an 80 GB GPU.  A causal convolution over the whole clip with zero left
+padding is exactly the same function, so with 288 GB of HBM the whole clip is processed at once (the two
+first-frame special cases of the temporal resamplers are kept: the first frame is never time-convolved).
+Spatial tiling (``tiled=True``: tile 30x52 latent, stride 15x26, linear-ramp blend) is kept because it
+changes the numbers (each tile sees only its own receptive field) and the reference asks for it.
+"""
+
+from __future__ import annotations
 
 import glob
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+LATENT_MEAN = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508,
+               0.4134, -0.0715, 0.5517, -0.3632, -0.1922, -0.9497, 0.2503, -0.2921]
+LATENT_STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743,
+              3.2687, 2.1526, 2.8652, 1.5579, 1.6382, 1.1253, 2.8251, 1.9160]
 
 
-def load_wan_vae(pattern, device):
+class CausalConv3d(nn.Conv3d):
+    """Conv3d with symmetric spatial padding and all temporal padding on the left (zeros)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._pad = (self.padding[2], self.padding[2], self.padding[1], self.padding[1], 2 * self.padding[0], 0)
+        self.padding = (0, 0, 0)
+
+    def forward(self, x):
+        return super().forward(F.pad(x, self._pad))
+
+
+class RMS_norm(nn.Module):
+    def __init__(self, dim: int, channel_first: bool = True, images: bool = True):
+        super().__init__()
+        bdims = (1, 1, 1) if not images else (1, 1)
+        self.channel_first = channel_first
+        self.scale = dim ** 0.5
+        self.gamma = nn.Parameter(torch.ones((dim, *bdims) if channel_first else (dim,)))
+
+    def forward(self, x):
+        return F.normalize(x, dim=(1 if self.channel_first else -1)) * self.scale * self.gamma
+
+
+class Upsample(nn.Upsample):
+    def forward(self, x):
+        return super().forward(x.float()).type_as(x)
+
+
+def _per_frame(fn, x):
+    b, c, t, h, w = x.shape
+    y = fn(x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w))
+    return y.reshape(b, t, y.shape[1], y.shape[2], y.shape[3]).permute(0, 2, 1, 3, 4)
+
+
+class Resample(nn.Module):
+    def __init__(self, dim: int, mode: str):
+        super().__init__()
+        self.dim, self.mode = dim, mode
+        if mode in ("upsample2d", "upsample3d"):
+            self.resample = nn.Sequential(Upsample(scale_factor=(2.0, 2.0), mode="nearest-exact"),
+                                          nn.Conv2d(dim, dim // 2, 3, padding=1))
+            if mode == "upsample3d":
+                self.time_conv = CausalConv3d(dim, dim * 2, (3, 1, 1), padding=(1, 0, 0))
+        elif mode in ("downsample2d", "downsample3d"):
+            self.resample = nn.Sequential(nn.ZeroPad2d((0, 1, 0, 1)), nn.Conv2d(dim, dim, 3, stride=(2, 2)))
+            if mode == "downsample3d":
+                self.time_conv = CausalConv3d(dim, dim, (3, 1, 1), stride=(2, 1, 1), padding=(0, 0, 0))
+        else:
+            raise ValueError(mode)
+
+    def forward(self, x):
+        b, c, t, h, w = x.shape
+        if self.mode == "upsample3d" and t > 1:
+            # frame 0 is never time-convolved; frames 1.. form their own causal sequence (zero left pad)
+            rest = self.time_conv(x[:, :, 1:])                                   # [b, 2c, t-1, h, w]
+            rest = rest.reshape(b, 2, c, t - 1, h, w)
+            rest = torch.stack((rest[:, 0], rest[:, 1]), dim=3).reshape(b, c, 2 * (t - 1), h, w)
+            x = torch.cat([x[:, :, :1], rest], dim=2)
+        x = _per_frame(self.resample, x)
+        if self.mode == "downsample3d" and x.shape[2] > 1:
+            # frame 0 passes through; o_j = conv3(x_2j, x_2j+1, x_2j+2), stride 2, no padding
+            x = torch.cat([x[:, :, :1], self.time_conv(x)], dim=2)   # padding (0,0,0): plain strided conv
+        return x
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, in_dim: int, out_dim: int, dropout: float = 0.0):
+        super().__init__()
+        self.residual = nn.Sequential(
+            RMS_norm(in_dim, images=False), nn.SiLU(), CausalConv3d(in_dim, out_dim, 3, padding=1),
+            RMS_norm(out_dim, images=False), nn.SiLU(), nn.Dropout(dropout), CausalConv3d(out_dim, out_dim, 3, padding=1))
+        self.shortcut = CausalConv3d(in_dim, out_dim, 1) if in_dim != out_dim else nn.Identity()
+
+    def forward(self, x):
+        return self.residual(x) + self.shortcut(x)
+
+
+class AttentionBlock(nn.Module):
+    """Single-head self-attention over the h*w positions of each frame."""
+
+    def __init__(self, dim: int):
+        super().__init__()
+        self.norm = RMS_norm(dim)
+        self.to_qkv = nn.Conv2d(dim, dim * 3, 1)
+        self.proj = nn.Conv2d(dim, dim, 1)
+
+    def forward(self, x):
+        def attn(f):
+            n, c, h, w = f.shape
+            q, k, v = self.to_qkv(self.norm(f)).reshape(n, 1, c * 3, h * w).permute(0, 1, 3, 2).chunk(3, dim=-1)
+            y = F.scaled_dot_product_attention(q, k, v)
+            return self.proj(y.squeeze(1).permute(0, 2, 1).reshape(n, c, h, w))
+        return x + _per_frame(attn, x)
+
+
+class Encoder3d(nn.Module):
+    def __init__(self, dim=96, z_dim=32, dim_mult=(1, 2, 4, 4), num_res_blocks=2, temperal_downsample=(False, True, True)):
+        super().__init__()
+        dims = [dim * u for u in (1,) + tuple(dim_mult)]
+        self.conv1 = CausalConv3d(3, dims[0], 3, padding=1)
+        layers: List[nn.Module] = []
+        for i, (in_dim, out_dim) in enumerate(zip(dims[:-1], dims[1:])):
+            for _ in range(num_res_blocks):
+                layers.append(ResidualBlock(in_dim, out_dim))
+                in_dim = out_dim
+            if i != len(dim_mult) - 1:
+                layers.append(Resample(out_dim, "downsample3d" if temperal_downsample[i] else "downsample2d"))
+        self.downsamples = nn.Sequential(*layers)
+        self.middle = nn.Sequential(ResidualBlock(out_dim, out_dim), AttentionBlock(out_dim), ResidualBlock(out_dim, out_dim))
+        self.head = nn.Sequential(RMS_norm(out_dim, images=False), nn.SiLU(), CausalConv3d(out_dim, z_dim, 3, padding=1))
+
+    def forward(self, x):
+        return self.head(self.middle(self.downsamples(self.conv1(x))))
+
+
+class Decoder3d(nn.Module):
+    def __init__(self, dim=96, z_dim=16, dim_mult=(1, 2, 4, 4), num_res_blocks=2, temperal_upsample=(True, True, False)):
+        super().__init__()
+        dims = [dim * u for u in (dim_mult[-1],) + tuple(dim_mult[::-1])]
+        self.conv1 = CausalConv3d(z_dim, dims[0], 3, padding=1)
+        self.middle = nn.Sequential(ResidualBlock(dims[0], dims[0]), AttentionBlock(dims[0]), ResidualBlock(dims[0], dims[0]))
+        layers: List[nn.Module] = []
+        for i, (in_dim, out_dim) in enumerate(zip(dims[:-1], dims[1:])):
+            if i in (1, 2, 3):
+                in_dim = in_dim // 2
+            for _ in range(num_res_blocks + 1):
+                layers.append(ResidualBlock(in_dim, out_dim))
+                in_dim = out_dim
+            if i != len(dim_mult) - 1:
+                layers.append(Resample(out_dim, "upsample3d" if temperal_upsample[i] else "upsample2d"))
+        self.upsamples = nn.Sequential(*layers)
+        self.head = nn.Sequential(RMS_norm(out_dim, images=False), nn.SiLU(), CausalConv3d(out_dim, 3, 3, padding=1))
+
+    def forward(self, z):
+        return self.head(self.upsamples(self.middle(self.conv1(z))))
+
+
+class WanVAENet(nn.Module):
+    """Parameter layout of the public ``Wan2.1_VAE.pth``: encoder, conv1, conv2, decoder."""
+
+    def __init__(self, dim=96, z_dim=16, dim_mult=(1, 2, 4, 4), num_res_blocks=2, temperal_downsample=(False, True, True)):
+        super().__init__()
+        self.z_dim = z_dim
+        self.encoder = Encoder3d(dim, z_dim * 2, dim_mult, num_res_blocks, temperal_downsample)
+        self.conv1 = CausalConv3d(z_dim * 2, z_dim * 2, 1)
+        self.conv2 = CausalConv3d(z_dim, z_dim, 1)
+        self.decoder = Decoder3d(dim, z_dim, dim_mult, num_res_blocks, tuple(temperal_downsample[::-1]))
+        self.register_buffer("mean", torch.tensor(LATENT_MEAN[:z_dim]).view(1, z_dim, 1, 1, 1), persistent=False)
+        self.register_buffer("inv_std", (1.0 / torch.tensor(LATENT_STD[:z_dim])).view(1, z_dim, 1, 1, 1), persistent=False)
+
+    def encode(self, x):       # [b, 3, 1+4k, H, W] in [-1,1] -> normalised mu [b, z, 1+k, H/8, W/8]
+        mu, _ = self.conv1(self.encoder(x)).chunk(2, dim=1)
+        return (mu - self.mean) * self.inv_std
+
+    def decode(self, z):       # -> [b, 3, 1+4(T-1), 8h, 8w]
+        return self.decoder(self.conv2(z / self.inv_std + self.mean)).clamp(-1, 1)
+
+
+def _ramp_mask(h: int, w: int, bound: Tuple[bool, bool, bool, bool], border: Tuple[int, int], device, dtype):
+    def one(n, left, right, b):
+        m = torch.ones(n, device=device, dtype=dtype)
+        if b > 0:
+            r = (torch.arange(b, device=device, dtype=dtype) + 1) / b
+            if not left:
+                m[:b] = r
+            if not right:
+                m[-b:] = r.flip(0)
+        return m
+    mh, mw = one(h, bound[0], bound[1], border[0]), one(w, bound[2], bound[3], border[1])
+    return torch.minimum(mh[:, None].expand(h, w), mw[None, :].expand(h, w))[None, None, None]
+
+
+def _tile_tasks(H, W, size, stride):
+    tasks = []
+    for h in range(0, H, stride[0]):
+        if h - stride[0] >= 0 and h - stride[0] + size[0] >= H:
+            continue
+        for w in range(0, W, stride[1]):
+            if w - stride[1] >= 0 and w - stride[1] + size[1] >= W:
+                continue
+            tasks.append((h, h + size[0], w, w + size[1]))
+    return tasks
+
+
+class WanVAE:
+    """The two-call interface the pipeline uses: ``encode(video[3,F,H,W]) -> latent[16,T,H/8,W/8]`` and
+    ``decode(latent) -> video[3,F,H,W]``, optionally spatially tiled like diffsynth's WanVideoVAE."""
+
+    def __init__(self, net: WanVAENet, device, dtype=torch.bfloat16):
+        self.net, self.device, self.dtype = net.to(device=device, dtype=dtype).eval(), device, dtype
+
+    @torch.no_grad()
+    def encode(self, video, tiled=True, tile_size=(30, 52), tile_stride=(15, 26), **unused):
+        x = video[None].to(device=self.device, dtype=self.dtype)
+        _, _, F_, H, W = x.shape
+        if not tiled:
+            return self.net.encode(x)[0].float()
+        size, stride = (tile_size[0] * 8, tile_size[1] * 8), (tile_stride[0] * 8, tile_stride[1] * 8)
+        T = (F_ - 1) // 4 + 1
+        vals = torch.zeros((1, self.net.z_dim, T, H // 8, W // 8), device=self.device, dtype=torch.float32)
+        wts = torch.zeros((1, 1, T, H // 8, W // 8), device=self.device, dtype=torch.float32)
+        for h0, h1, w0, w1 in _tile_tasks(H, W, size, stride):
+            z = self.net.encode(x[:, :, :, h0:h1, w0:w1]).float()
+            m = _ramp_mask(z.shape[3], z.shape[4], (h0 == 0, h1 >= H, w0 == 0, w1 >= W),
+                           ((size[0] - stride[0]) // 8, (size[1] - stride[1]) // 8), self.device, torch.float32)
+            vals[:, :, :, h0 // 8: h0 // 8 + z.shape[3], w0 // 8: w0 // 8 + z.shape[4]] += z * m
+            wts[:, :, :, h0 // 8: h0 // 8 + z.shape[3], w0 // 8: w0 // 8 + z.shape[4]] += m
+        return (vals / wts)[0]
+
+    @torch.no_grad()
+    def decode(self, latent, tiled=True, tile_size=(30, 52), tile_stride=(15, 26), **unused):
+        z = latent[None].to(device=self.device, dtype=self.dtype)
+        _, _, T, H, W = z.shape
+        if not tiled:
+            return self.net.decode(z)[0].float()
+        vals = torch.zeros((1, 3, T * 4 - 3, H * 8, W * 8), device=self.device, dtype=torch.float32)
+        wts = torch.zeros((1, 1, T * 4 - 3, H * 8, W * 8), device=self.device, dtype=torch.float32)
+        for h0, h1, w0, w1 in _tile_tasks(H, W, tile_size, tile_stride):
+            y = self.net.decode(z[:, :, :, h0:h1, w0:w1]).float()
+            m = _ramp_mask(y.shape[3], y.shape[4], (h0 == 0, h1 >= H, w0 == 0, w1 >= W),
+                           ((tile_size[0] - tile_stride[0]) * 8, (tile_size[1] - tile_stride[1]) * 8), self.device, torch.float32)
+            vals[:, :, :, h0 * 8: h0 * 8 + y.shape[3], w0 * 8: w0 * 8 + y.shape[4]] += y * m
+            wts[:, :, :, h0 * 8: h0 * 8 + y.shape[3], w0 * 8: w0 * 8 + y.shape[4]] += m
+        return (vals / wts).clamp(-1, 1)[0]
+
+
+def load_wan_vae(pattern, device, dtype=torch.bfloat16) -> WanVAE:
     files = sorted(glob.glob(pattern))
     if not files:
         raise FileNotFoundError(f"Wan VAE checkpoint not found: {pattern!r} (skip_download=True: nothing is fetched)")
-    raise NotImplementedError(
-        "Wan-VAE on stock PyTorch-ROCm is a 'next' row (SURVEY.md §8f-4) and not built yet; construct "
-        "WanVideoPipeline(vae=...) with any object exposing encode(video)/decode(latent)")
+    sd = torch.load(files[0], map_location="cpu", weights_only=True)
+    if all(k.startswith("model.") for k in sd):
+        sd = {k[len("model."):]: v for k, v in sd.items()}
+    net = WanVAENet()
+    net.load_state_dict(sd, strict=True)
+    return WanVAE(net, device, dtype)
