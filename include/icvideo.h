@@ -117,6 +117,26 @@ int icv_unpatchify_cfg_euler(float* latent, float* vel_out, const float* hc, con
                              int64_t ldh, float cfg_scale, float dsigma, int64_t C, int64_t T,
                              int64_t H8, int64_t W8, int64_t tok0, int64_t n_tok, void* stream);
 
+/* ---- coordinate guidance buffer (producer of the hot path's input) ---------------
+ * Replaces `generate_coordinate_buffer_from_memory_global_norm` [R infinicube/utils/buffer_utils.py:180-265]
+ * (+ `unproject_depth_torch` [R infinicube/utils/depth_utils.py:402-466]).  depth f32 [N,H,W] on device
+ * (0 = infinitely far); kinv_host9 = K^-1 row-major (HOST pointer, 9 floats); cam_to_cam0 f32 [N,16] on
+ * device = pose_0^-1 pose_n row-major.  Three passes, the [N,H,W,3] point map is never stored:
+ *   valid_mask:    mask[i] = depth != 0 && z_cam0 < 1e6                       (u8 [N*H*W])
+ *   gather_points: out[j,:] = point of pixel pixel_index[j]                   (the <=100000-point quantile sample)
+ *   normalize:     out = sky ? 1 : (clip((P - mins)/ranges*2-1, -1, 1)+1)/2  -> f32 [N,H,W,3] and/or
+ *                  u8 [N,H,W,3] = trunc(out*255) (what the caller feeds WanVideoGenerator);
+ *                  has_valid == 0 reproduces the reference's "no finite point" branch (P * 0.5). */
+int icv_coord_valid_mask(const float* depth, const float* kinv_host9, const float* cam_to_cam0,
+                         int64_t N, int64_t H, int64_t W, unsigned char* mask, void* stream);
+int icv_coord_gather_points(const float* depth, const float* kinv_host9, const float* cam_to_cam0,
+                            int64_t N, int64_t H, int64_t W, const int64_t* pixel_index, int64_t n,
+                            float* out, void* stream);
+int icv_coord_normalize(const float* depth, const float* kinv_host9, const float* cam_to_cam0,
+                        int64_t N, int64_t H, int64_t W, const float* mins_host3,
+                        const float* ranges_host3, int has_valid, float* out_f32,
+                        unsigned char* out_u8, void* stream);
+
 /* ---- dtype plumbing: f32 -> bf16 (round-to-nearest-even), n elements ---------------------- */
 int icv_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 

@@ -1,0 +1,4 @@
+"""`infinicube.utils.buffer_utils` names served by the MI355X-native implementation."""
+from infinicube_amd.utils.buffer_utils import generate_coordinate_buffer_from_memory_global_norm
+
+__all__ = ["generate_coordinate_buffer_from_memory_global_norm"]

@@ -1,0 +1,65 @@
+"""Coordinate guidance buffer on MI355X.
+
+`generate_coordinate_buffer_from_memory_global_norm` keeps the reference's name, arguments and result
+[R infinicube/utils/buffer_utils.py:180-265]; the per-pixel work (unprojection with
+`unproject_depth_torch` [R infinicube/utils/depth_utils.py:402-466], camera-0 transform, normalisation,
+sky fill) runs in libicvideo's HIP kernels (csrc/buffers.hip) on the depth map resident in HBM.  Host-side
+PyTorch only does what the reference does on a handful of numbers: K^-1, pose_0^-1 pose_n, the random
+sample of <= 100000 finite points (same global-RNG `torch.randperm` call, so a seeded run matches the
+reference's sample) and `torch.quantile` on that sample.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from .. import native
+
+
+def _f32_host(t: torch.Tensor):
+    a = t.detach().to("cpu", torch.float32).contiguous().reshape(-1)
+    return (ctypes.c_float * a.numel())(*a.tolist())
+
+
+def generate_coordinate_buffer_from_memory_global_norm(depth_buffer: torch.Tensor, camera_model,
+                                                       camera_poses: torch.Tensor, percentile: float = 0.05,
+                                                       *, device="cuda:0", return_uint8: bool = False):
+    """depth_buffer [N,H,W] metres (0 = infinitely far), camera_model with ``get_intrinsics_matrix()`` -> [3,3],
+    camera_poses [N,4,4] camera-to-world  ->  [N,H,W,3] float32 in [0,1] (on ``device``), or with
+    ``return_uint8=True`` the uint8 buffer ``(coord * 255).astype(uint8)`` the video generator consumes."""
+    lib = native.lib()
+    if not torch.cuda.is_available():
+        raise native.NativeError("coordinate buffer: no GPU visible to PyTorch-ROCm; there is no CPU fallback")
+    dev = torch.device(device)
+    depth = depth_buffer.detach().to(device=dev, dtype=torch.float32).contiguous()
+    if depth.dim() != 3:
+        raise ValueError(f"depth_buffer must be [N, H, W], got {tuple(depth.shape)}")
+    n, h, w = depth.shape
+    k = camera_model.get_intrinsics_matrix().detach().to("cpu", torch.float32)
+    poses = camera_poses.detach().to("cpu", torch.float32)
+    kinv = _f32_host(torch.inverse(k))
+    to_cam0 = torch.einsum("ij,bjk->bik", torch.inverse(poses[0]), poses).contiguous().to(dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    total = n * h * w
+    mask = torch.empty((total,), dtype=torch.uint8, device=dev)
+    native.check(lib.icv_coord_valid_mask(depth.data_ptr(), kinv, to_cam0.data_ptr(), n, h, w, mask.data_ptr(), stream),
+                 "icv_coord_valid_mask")
+    valid_idx = torch.nonzero(mask, as_tuple=False).reshape(-1)          # flattened-order compaction
+    has_valid = int(valid_idx.numel() > 0)
+    mins = ranges = None
+    if has_valid:
+        pick = torch.randperm(valid_idx.numel())[:100000].to(dev)        # same global-RNG draw as the reference
+        sample_idx = valid_idx[pick].contiguous()
+        sample = torch.empty((sample_idx.numel(), 3), dtype=torch.float32, device=dev)
+        native.check(lib.icv_coord_gather_points(depth.data_ptr(), kinv, to_cam0.data_ptr(), n, h, w,
+                                                 sample_idx.data_ptr(), sample_idx.numel(), sample.data_ptr(), stream),
+                     "icv_coord_gather_points")
+        lo = torch.quantile(sample, percentile, dim=0)
+        hi = torch.quantile(sample, 1 - percentile, dim=0)
+        mins, ranges = _f32_host(lo), _f32_host(torch.clamp(hi - lo, min=1e-7))
+    out_f32 = None if return_uint8 else torch.empty((n, h, w, 3), dtype=torch.float32, device=dev)
+    out_u8 = torch.empty((n, h, w, 3), dtype=torch.uint8, device=dev) if return_uint8 else None
+    native.check(lib.icv_coord_normalize(depth.data_ptr(), kinv, to_cam0.data_ptr(), n, h, w, mins, ranges, has_valid,
+                                         native.ptr(out_f32), native.ptr(out_u8), stream), "icv_coord_normalize")
+    return out_u8 if return_uint8 else out_f32

@@ -1,0 +1,83 @@
+"""SURVEY.md §8f row 1 — coordinate guidance buffer.  This oracle IS pinned: the golden arrays in
+tests/golden/coord_buffer_cases.npz are outputs of the reference's own function (generator:
+tests/golden/make_coord_buffer_golden.py).  CPU: oracle vs reference golden.  GPU: HIP path (C ABI) vs
+golden and vs the oracle at the full 93x480x832 size through size-independent properties."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import buffer_ref as B
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "coord_buffer_cases.npz"))
+CASES = ("small", "allsky", "big")
+
+
+class Cam:
+    def __init__(self, fx, fy, cx, cy):
+        self.fx, self.fy, self.cx, self.cy = float(fx), float(fy), float(cx), float(cy)
+
+    def get_intrinsics_matrix(self):
+        return torch.tensor([[self.fx, 0, self.cx], [0, self.fy, self.cy], [0, 0, 1]], dtype=torch.float32)
+
+
+def _case(name):
+    return (torch.from_numpy(G[f"{name}_depth"]), torch.from_numpy(G[f"{name}_poses"]), Cam(*G[f"{name}_intr"]),
+            int(G[f"{name}_seed"][0]), torch.from_numpy(G[f"{name}_coord"]), G[f"{name}_coord_u8"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_reference_golden(name):
+    depth, poses, cam, seed, want, _ = _case(name)
+    torch.manual_seed(seed)
+    got = B.coordinate_buffer_global_norm(depth, cam.get_intrinsics_matrix(), poses, 0.05)
+    assert float((got - want).abs().max()) < 1e-6
+
+
+def test_oracle_unproject_identity_pose():
+    depth = torch.full((1, 4, 6), 2.0)
+    k = torch.tensor([[10.0, 0, 3.0], [0, 10.0, 2.0], [0, 0, 1]])
+    pts = B.unproject_depth(depth, torch.eye(4)[None], k[None])
+    assert torch.allclose(pts[0, 2, 3], torch.tensor([0.0, 0.0, 2.0]))          # principal point -> on the optical axis
+    assert torch.allclose(pts[0, 2, 5], torch.tensor([0.4, 0.0, 2.0]))          # 2 px right at depth 2, f = 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_matches_reference_golden(name):
+    from infinicube.utils.buffer_utils import generate_coordinate_buffer_from_memory_global_norm as gen
+    depth, poses, cam, seed, want, want_u8 = _case(name)
+    torch.manual_seed(seed)
+    got = gen(depth, cam, poses, percentile=0.05).cpu()
+    assert got.shape == want.shape and got.dtype == torch.float32
+    assert float((got - want).abs().max()) < 2e-5, float((got - want).abs().max())
+    torch.manual_seed(seed)
+    u8 = gen(depth, cam, poses, percentile=0.05, return_uint8=True).cpu().numpy()
+    diff = np.abs(u8.astype(np.int16) - want_u8.astype(np.int16))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3        # truncation can flip at exact 1/255 boundaries only
+
+
+@pytest.mark.gpu
+def test_hip_full_size_properties():
+    """93 x 480 x 832 (the BASELINE configs' buffer size): range, sky, monotonicity in depth along the optical
+    axis, and invariance to a rigid motion applied to ALL poses (only relative poses matter)."""
+    from infinicube_amd.utils.buffer_utils import generate_coordinate_buffer_from_memory_global_norm as gen
+    n, h, w = 93, 480, 832
+    g = torch.Generator().manual_seed(0)
+    depth = torch.rand((n, h, w), generator=g) * 60 + 2
+    depth[:, :100] = 0                                                       # sky rows
+    poses = torch.eye(4).repeat(n, 1, 1)
+    poses[:, 2, 3] = torch.arange(n) * 0.5
+    cam = Cam(700.0, 700.0, w / 2, h / 2)
+    torch.manual_seed(5)
+    a = gen(depth, cam, poses)
+    assert a.shape == (n, h, w, 3) and float(a.min()) >= 0.0 and float(a.max()) <= 1.0
+    assert bool((a[:, :100] == 1.0).all())
+    rigid = torch.tensor([[0.0, -1.0, 0.0, 5.0], [1.0, 0.0, 0.0, -3.0], [0.0, 0.0, 1.0, 2.0], [0.0, 0.0, 0.0, 1.0]])
+    torch.manual_seed(5)
+    b = gen(depth, cam, torch.einsum("ij,njk->nik", rigid, poses))
+    assert float((a - b).abs().max()) < 1e-4
+    torch.manual_seed(5)
+    u8 = gen(depth, cam, poses, return_uint8=True)
+    assert u8.dtype == torch.uint8 and int((u8.int() - (a * 255).to(torch.uint8).int()).abs().max()) <= 1
