@@ -35,7 +35,8 @@ const char* icv_last_error(void);
  * out[3]=warp (wavefront) size.  Replaces nothing in the reference (device probing). */
 int icv_device_info(int device, int64_t out[4]);
 
-/* Kernel-variant switch for A/B measurement ("gemm256" = 0/1, ...); defaults = shipped config. */
+/* Kernel-variant switches for A/B measurement ("gemm256" = 0 | 1 | 2 = heuristic, "attn_kernel" = 1..4,
+ * "attn_defer_max_log2", ...); defaults = shipped configuration. */
 int icv_set_option(const char* name, int value);
 
 /* ---- GEMM with fused epilogues (K1, K2, K4, K7, K9, K10, K11 of SURVEY §8a-3) ------------

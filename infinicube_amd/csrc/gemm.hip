@@ -14,6 +14,8 @@
 //     lane ends up with 4 CONSECUTIVE n for one m: epilogue loads/stores are 8/16-byte vectors.
 //   * 1-D grid, XCD-aware remap (block b runs on XCD b%8 -> give each XCD a contiguous chunk of
 //     tiles) + grouped (8 m-tiles x all n-tiles) ordering so co-resident blocks share panels in L2.
+#include <math.h>
+
 #include "icv_common.h"
 
 namespace {
@@ -182,10 +184,34 @@ extern "C" int icv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t 
   if (nsplit <= 0) nsplit = N;
   ICV_REQUIRE(nsplit % 4 == 0 && N % nsplit == 0, "icv_gemm_bf16: nsplit must divide N and be a multiple of 4");
   ICV_REQUIRE(epilogue != ICV_EPI_RESID_F32 || (resid && ldr % 4 == 0 && nsplit == N), "icv_gemm_bf16: RESID epilogue needs resid, ldr%%4==0, no split");
-  // large problems: 256x256 tile, 8 waves, 4-phase staggered schedule (gemm256.hip)
-  if (N % 256 == 0 && M >= 256 && icv_get_option_int("gemm256", 1))
-    return icv_gemm256_dispatch(A, lda, W, ldw, bias, M, N, K, epilogue, out, ldo, nsplit, split_stride,
-                                resid, ldr, gate, (hipStream_t)stream);
+  // Kernel choice.  The 256x256 8-wave 4-phase kernel (gemm256.hip) is ~1.35x faster per tile-FLOP than the
+  // 128x128 kernel below, but runs 1 block per CU: with few tiles the last wave of blocks is mostly empty
+  // (e.g. M=4680, N=5120 at 8-way sequence parallel = 380 tiles = 1.48 rounds of 256 CUs).  Pick by
+  // quantisation-adjusted throughput; option gemm256 = 0 / 1 forces one kernel, 2 (default) = heuristic.
+  if (N % 256 == 0 && M >= 256) {
+    const int mode = icv_get_option_int("gemm256", 2);
+    bool use256 = mode == 1;
+    if (mode == 2) {
+      static int n_cu = 0;
+      if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+      }
+      const double t256 = (double)((M + 255) / 256) * (double)(N / 256);
+      const double t128 = (double)((M + 127) / 128) * (double)((N + 127) / 128);
+      const double slots256 = n_cu, slots128 = 2.0 * n_cu;     // blocks resident per round
+      const double eff256 = t256 / (ceil(t256 / slots256) * slots256) * 1.35;
+      const double eff128 = t128 / (ceil(t128 / slots128) * slots128) * 1.00;
+      // padding waste of the partial last m-tile
+      const double use_m256 = (double)M / (double)(((M + 255) / 256) * 256), use_m128 = (double)M / (double)(((M + 127) / 128) * 128);
+      use256 = eff256 * use_m256 >= eff128 * use_m128;
+    }
+    if (use256)
+      return icv_gemm256_dispatch(A, lda, W, ldw, bias, M, N, K, epilogue, out, ldo, nsplit, split_stride,
+                                  resid, ldr, gate, (hipStream_t)stream);
+  }
   GemmParams p;
   p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.bias = bias;
   p.M = M; p.N = N; p.K = K; p.out = out; p.ldo = ldo; p.nsplit = nsplit; p.split_stride = split_stride;

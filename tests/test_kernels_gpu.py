@@ -129,7 +129,7 @@ def test_gemm_variants_agree_and_race_screen(hip_ops, variant):
             outs.append(out)
         torch.cuda.synchronize()
     finally:
-        hip_ops.lib.icv_set_option(b"gemm256", 1)
+        hip_ops.lib.icv_set_option(b"gemm256", 2)
     assert_f32_close(outs[0], ref, what=f"gemm variant {variant}")
     for o in outs[1:]:
         assert torch.equal(o, outs[0]), "non-deterministic GEMM result (race in the pipelined schedule?)"

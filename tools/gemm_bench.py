@@ -8,14 +8,16 @@ ops = HipOps("cuda:0")
 S = 37440
 shapes = [("1.3b qkv", S, 4608, 1536, EPI_BF16), ("1.3b o", S, 1536, 1536, EPI_RESID_F32), ("1.3b ffn1", S, 8960, 1536, EPI_GELU_BF16),
           ("1.3b ffn2", S, 1536, 8960, EPI_RESID_F32), ("14b qkv", S, 15360, 5120, EPI_BF16), ("14b o", S, 5120, 5120, EPI_RESID_F32),
-          ("14b ffn1", S, 13824, 5120, EPI_GELU_BF16), ("14b ffn2", S, 5120, 13824, EPI_RESID_F32), ("sp8 14b ffn1", 4680, 13824, 5120, EPI_GELU_BF16)]
+          ("14b ffn1", S, 13824, 5120, EPI_GELU_BF16), ("14b ffn2", S, 5120, 13824, EPI_RESID_F32), ("sp8 14b ffn1", 4680, 13824, 5120, EPI_GELU_BF16),
+          ("sp8 14b o", 4680, 5120, 5120, EPI_RESID_F32), ("sp8 14b kv", 4680, 10240, 5120, EPI_BF16), ("sp8 14b ffn2", 4680, 5120, 13824, EPI_RESID_F32),
+          ("sp4 14b o", 9360, 5120, 5120, EPI_RESID_F32), ("sp8 1.3b o", 4680, 1536, 1536, EPI_RESID_F32), ("sp8 1.3b ffn1", 4680, 8960, 1536, EPI_GELU_BF16)]
 for name, M, N, K, epi in shapes:
     a = (torch.randn((M, K), device="cuda") ).to(torch.bfloat16)
     w = (torch.randn((N, K), device="cuda") / math.sqrt(K)).to(torch.bfloat16)
     bias = torch.randn((N,), device="cuda")
     out = torch.empty((M, N), device="cuda", dtype=torch.float32 if epi == EPI_RESID_F32 else torch.bfloat16)
     res = {}
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         ops.lib.icv_set_option(b"gemm256", variant)
         kw = dict(resid=out, gate=bias) if epi == EPI_RESID_F32 else {}
         for _ in range(2):
@@ -29,5 +31,5 @@ for name, M, N, K, epi in shapes:
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
         res[variant] = 2.0 * M * N * K / ms / 1e9
-    print(f"{name:14s} M={M} N={N} K={K}: 128-tile {res[0]:7.1f} TF | 256-tile {res[1]:7.1f} TF")
-ops.lib.icv_set_option(b"gemm256", 1)
+    print(f"{name:14s} M={M} N={N} K={K}: 128-tile {res[0]:7.1f} TF | 256-tile {res[1]:7.1f} TF | heuristic {res[2]:7.1f} TF")
+ops.lib.icv_set_option(b"gemm256", 2)
