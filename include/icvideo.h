@@ -138,6 +138,18 @@ int icv_coord_normalize(const float* depth, const float* kinv_host9, const float
                         const float* ranges_host3, int has_valid, float* out_f32,
                         unsigned char* out_u8, void* stream);
 
+/* ---- semantic / instance colour buffer -----------------------------------------
+ * icv_semantic_to_color replaces `semantic_to_color` [R infinicube/utils/semantic_utils.py:88-101]:
+ *   semantics i32 [n] (class index), class_rgb_lut f32 [n_classes,3] on device (= PALETTE[MAPPING]);
+ *   writes f32 [n,3] and/or u8 [n,3] = trunc(colour*255) (the caller's conversion).
+ * icv_instance_overlay_u8 replaces `generate_rgb_semantic_buffer` [R infinicube/utils/semantic_utils.py:104-131]:
+ *   out = instance > 0 ? instance_rgb_lut65536[instance] : semantics_rgb   (all u8 RGB; instance i32 [n],
+ *   low 16 bits used, like the reference's uint16 cast). */
+int icv_semantic_to_color(const int* semantics, int64_t n, const float* class_rgb_lut, int n_classes,
+                          float* out_f32, unsigned char* out_u8, void* stream);
+int icv_instance_overlay_u8(const unsigned char* semantics_rgb, const int* instance, int64_t n,
+                            const unsigned char* instance_rgb_lut65536, unsigned char* out, void* stream);
+
 /* ---- dtype plumbing: f32 -> bf16 (round-to-nearest-even), n elements ---------------------- */
 int icv_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 

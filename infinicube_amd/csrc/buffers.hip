@@ -127,3 +127,53 @@ extern "C" int icv_coord_normalize(const float* depth, const float* kinv_host9, 
                      mn[0], mn[1], mn[2], rg[0], rg[1], rg[2], has_valid, out_f32, out_u8, total);
   return icv_check_launch("icv_coord_normalize");
 }
+
+// ---------------------------------------------------------------------------------------------
+// semantic / instance colour buffer — two LUT passes over the pixels.
+//   semantic_to_color [R infinicube/utils/semantic_utils.py:88-101]: colour = PALETTE[MAPPING[class]]
+//   generate_rgb_semantic_buffer [R infinicube/utils/semantic_utils.py:104-131]: instance colour where
+//   instance > 0 (table built on the host from the reference's random colormap samples), else semantic.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void semantic_color_kernel(const int* __restrict__ sem, int64_t n,
+                                                             const float* __restrict__ lut, int n_classes,
+                                                             float* __restrict__ out_f32,
+                                                             unsigned char* __restrict__ out_u8) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int c = sem[i];
+  c = c < 0 ? 0 : (c >= n_classes ? n_classes - 1 : c);
+  const float r = lut[c * 3 + 0], g = lut[c * 3 + 1], b = lut[c * 3 + 2];
+  if (out_f32) { out_f32[i * 3 + 0] = r; out_f32[i * 3 + 1] = g; out_f32[i * 3 + 2] = b; }
+  if (out_u8) {   // the caller's (colour * 255).astype(uint8)
+    out_u8[i * 3 + 0] = (unsigned char)(int)(r * 255.0f);
+    out_u8[i * 3 + 1] = (unsigned char)(int)(g * 255.0f);
+    out_u8[i * 3 + 2] = (unsigned char)(int)(b * 255.0f);
+  }
+}
+
+__global__ __launch_bounds__(256) void instance_overlay_kernel(const unsigned char* __restrict__ sem_rgb,
+                                                               const int* __restrict__ inst, int64_t n,
+                                                               const unsigned char* __restrict__ inst_lut,
+                                                               unsigned char* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int id = inst[i] & 0xffff;
+  const unsigned char* src = id > 0 ? inst_lut + (int64_t)id * 3 : sem_rgb + i * 3;
+  out[i * 3 + 0] = src[0]; out[i * 3 + 1] = src[1]; out[i * 3 + 2] = src[2];
+}
+
+extern "C" int icv_semantic_to_color(const int* semantics, int64_t n, const float* class_rgb_lut, int n_classes,
+                                     float* out_f32, unsigned char* out_u8, void* stream) {
+  ICV_REQUIRE(semantics && class_rgb_lut && n > 0 && n_classes > 0 && (out_f32 || out_u8), "icv_semantic_to_color: bad arguments");
+  hipLaunchKernelGGL(semantic_color_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     semantics, n, class_rgb_lut, n_classes, out_f32, out_u8);
+  return icv_check_launch("icv_semantic_to_color");
+}
+
+extern "C" int icv_instance_overlay_u8(const unsigned char* semantics_rgb, const int* instance, int64_t n,
+                                       const unsigned char* instance_rgb_lut65536, unsigned char* out, void* stream) {
+  ICV_REQUIRE(semantics_rgb && instance && instance_rgb_lut65536 && out && n > 0, "icv_instance_overlay_u8: bad arguments");
+  hipLaunchKernelGGL(instance_overlay_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     semantics_rgb, instance, n, instance_rgb_lut65536, out);
+  return icv_check_launch("icv_instance_overlay_u8");
+}

@@ -81,3 +81,42 @@ def test_hip_full_size_properties():
     torch.manual_seed(5)
     u8 = gen(depth, cam, poses, return_uint8=True)
     assert u8.dtype == torch.uint8 and int((u8.int() - (a * 255).to(torch.uint8).int()).abs().max()) <= 1
+
+
+# ---------------------------------------------------------------------------------------------------
+# §8f row 2: semantic / instance colour buffer (golden = the reference's own outputs, generator:
+# tests/golden/make_semantic_golden.py; palette under the documented pycg == matplotlib assumption)
+# ---------------------------------------------------------------------------------------------------
+S = np.load(os.path.join(os.path.dirname(__file__), "golden", "semantic_buffer_cases.npz"))
+
+
+def test_semantic_tables_match_reference():
+    from infinicube_amd.utils import semantic_utils as su
+    assert np.array_equal(su.WAYMO_MAPPING, S["mapping"]) and np.allclose(su.WAYMO_PALETTE, S["palette"])
+    assert len(su.WAYMO_CATEGORY_NAMES) == 23
+
+
+def test_semantic_oracle_matches_reference_golden():
+    assert np.array_equal(B.semantic_to_color(S["sem"], S["mapping"], S["palette"]), S["colors"])
+    np.random.seed(int(S["np_seed"][0]))
+    assert np.array_equal(B.rgb_semantic_buffer(S["sem_rgb"], S["inst"]), S["rgb"])
+
+
+@pytest.mark.gpu
+def test_semantic_hip_matches_reference_golden():
+    from infinicube.utils.semantic_utils import generate_rgb_semantic_buffer, semantic_to_color
+    colors = semantic_to_color(S["sem"])
+    assert colors.dtype == np.float32 and np.array_equal(colors, S["colors"])
+    assert np.array_equal(semantic_to_color(torch.from_numpy(S["sem"])), S["colors"])     # tensor input, like the caller
+    np.random.seed(int(S["np_seed"][0]))
+    rgb = generate_rgb_semantic_buffer((colors * 255).astype(np.uint8), S["inst"])
+    assert rgb.dtype == np.uint8 and np.array_equal(rgb, S["rgb"])
+    # full-size property: pixels without an instance keep the semantic colour, bit for bit
+    g = np.random.default_rng(3)
+    sem_rgb = g.integers(0, 255, (93, 480, 832, 3), dtype=np.uint8)
+    inst = np.zeros((93, 480, 832), np.uint16)
+    inst[:, 100:200, 300:500] = 9
+    inst[5:, 300:350, 100:150] = 2 ** 15 + 1
+    out = generate_rgb_semantic_buffer(sem_rgb, inst)
+    assert np.array_equal(out[inst == 0], sem_rgb[inst == 0])
+    assert len(np.unique(out[inst == 9].reshape(-1, 3), axis=0)) == 1
