@@ -136,3 +136,34 @@ def test_sequence_parallel_path_on_one_gpu(hip_ops, chunks):
     got, want = torch.cat(outs, 0), full.head_out[0]
     rel = float((got - want).norm() / want.norm())
     assert rel < 5e-3, f"sharded vs unsharded forward rel-L2 {rel}"
+
+
+def test_config1_wan_1p3b_17f_256p_10_steps(hip_ops):
+    """BASELINE.json config #1 at the REAL Wan2.1-1.3B dimensions (d=1536, 12 heads, 30 layers, text 512x4096):
+    17 frames 256x448 (S = 2240 tokens), 10 flow-match steps with CFG, guidance-buffer tokens from the dummy
+    buffers' stand-in latents; HIP loop vs the fp32 CPU oracle fed the same bf16-rounded weights.
+    Bar: final-latent PSNR >= 40 dB (north star), per-step velocity cosine >= 0.999."""
+    import time
+    from infinicube_amd.videogen.config import GRID_CFG1
+    cfg, grid = preset("1.3b"), GRID_CFG1
+    sd = syn.make_dit_state_dict(cfg, seed=0, dtype=torch.bfloat16)
+    bsd = syn.make_buffer_embedder_state_dict(cfg, dtype=torch.bfloat16)
+    sdr = {k: v.float() for k, v in sd.items()}
+    bsdr = {k: v.float() for k, v in bsd.items()}
+    noise = syn.make_latent_noise(grid)
+    c1, c2, bl = syn.make_text_context(cfg, 1), syn.make_text_context(cfg, 2), syn.make_buffer_latents(cfg, grid)
+    steps = 10
+    m = WanDiT(cfg, sd, hip_ops, bsd).prepare(grid)
+    lat = noise.clone().to("cuda:0")
+    t0 = time.time()
+    m.denoise(lat, m.encode_context(c1), m.encode_context(c2), m.embed_buffers(bl), FlowMatchScheduler(steps), 5.0)
+    torch.cuda.synchronize()
+    t_gpu = time.time() - t0
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    t0 = time.time()
+    ref = R.denoise_loop(sdr, bsdr, cfg, noise, c1, c2, bl, num_steps=steps)
+    t_cpu = time.time() - t0
+    p = R.psnr(lat.cpu(), ref)
+    cos = float(torch.nn.functional.cosine_similarity((lat.cpu() - noise).flatten(), (ref - noise).flatten(), dim=0))
+    print(f"config #1: GPU {t_gpu:.2f}s, CPU oracle {t_cpu:.1f}s, PSNR {p:.1f} dB, update cosine {cos:.5f}")
+    assert p >= 40.0 and cos >= 0.999, f"config #1 parity: PSNR {p:.1f} dB, cosine {cos}"
