@@ -63,7 +63,8 @@ __device__ __forceinline__ void dma_unit(const char* __restrict__ base, const un
   }
 }
 
-template <int EPI>
+// MF = 16: v_mfma_f32_16x16x32_bf16 fragments (8x4 per wave);  MF = 32: v_mfma_f32_32x32x16_bf16 (4x2 per wave)
+template <int EPI, int MF>
 __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -111,23 +112,36 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
   const int nt = (int)(p.K / BK);
   auto kbyte = [&](int t) -> int64_t { return (int64_t)(t < nt ? t : nt - 1) * (BK * 2); };
 
-  f32x4 acc[8][4];
+  f32x4 acc[8][4];     // MF == 16
+  f32x16 acc32[4][2];  // MF == 32
+  if (MF == 16) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
+  }
 
   // ---- fragment read addressing: lane (fr = row in 16-row frag, kq = 8-wide k chunk) ----
-  const int fr = lane & 15, kq = lane >> 4;
+  const int fr = (MF == 16) ? (lane & 15) : (lane & 31), kq = (MF == 16) ? (lane >> 4) : (lane >> 5);
   // a-frag i (0..3) of a-half: unit row = wr*64 + i*16 + fr ; b-frag j (0..1): unit row = wc*32 + j*16 + fr
-  int a_off[2], b_off[2];  // byte offset within a unit for ks = 0,1 minus the i/j row term
+  // MF 16: k-step = 32 (4 chunks, kq = 0..3), 2 k-steps;  MF 32: k-step = 16 (2 chunks, kq = 0..1), 4 k-steps
+  constexpr int NKS = (MF == 16) ? 2 : 4, CPK = (MF == 16) ? 4 : 2;
+  int a_off[NKS], b_off[NKS];  // byte offset within a unit per k-step, minus the i/j row term
   const int ar = wr * 64 + fr, br = wc * 32 + fr;
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    // (row + 16*i) keeps ((row>>1)&7) ^ pattern: (16*i)>>1 = 8*i does not touch bits 0..2 -> same swizzle
-    a_off[ks] = ar * 128 + (((ks * 4 + kq) ^ ((ar >> 1) & 7)) << 4);
-    b_off[ks] = br * 128 + (((ks * 4 + kq) ^ ((br >> 1) & 7)) << 4);
+  for (int ks = 0; ks < NKS; ++ks) {
+    // (row + 16*i) keeps ((row>>1)&7): (16*i)>>1 = 8*i does not touch bits 0..2 -> same swizzle
+    a_off[ks] = ar * 128 + (((ks * CPK + kq) ^ ((ar >> 1) & 7)) << 4);
+    b_off[ks] = br * 128 + (((ks * CPK + kq) ^ ((br >> 1) & 7)) << 4);
   }
+  constexpr int NAF = (MF == 16) ? 4 : 2, NBF = (MF == 16) ? 2 : 1, FROWS = MF * 128;  // frags per half, bytes per frag row block
 
   // ---- prologue: tile 0 complete + A0,B0 of tile 1 ----
   dma_unit(Ab, offA[0], kbyte(0), smem + U_A0 * UNIT_BYTES, wave);
@@ -140,17 +154,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
   G256_BARRIER();
   if (wr == 1) G256_BARRIER();  // stagger: group 1 runs one barrier behind group 0
 
-  bf16x8 af[4][2], b0f[2][2], b1f[2][2];
+  bf16x8 af[NAF][NKS], b0f[NBF][NKS], b1f[NBF][NKS];
 
 #define G256_MFMA(AH, BF, BH)                                                                   \
   {                                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                          \
     __builtin_amdgcn_s_setprio(1);                                                              \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                            \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                               \
-      acc[(AH) * 4 + i][(BH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                \
-          BF[j][ks], af[i][ks], acc[(AH) * 4 + i][(BH) * 2 + j], 0, 0, 0);                      \
+    _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks)                                          \
+    _Pragma("unroll") for (int i = 0; i < NAF; ++i)                                             \
+    _Pragma("unroll") for (int j = 0; j < NBF; ++j) {                                           \
+      if (MF == 16)                                                                             \
+        acc[(AH) * 4 + i][(BH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(              \
+            BF[j][ks], af[i][ks], acc[(AH) * 4 + i][(BH) * 2 + j], 0, 0, 0);                    \
+      else                                                                                      \
+        acc32[(AH) * 2 + i][(BH)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                    \
+            BF[j][ks], af[i][ks], acc32[(AH) * 2 + i][(BH)], 0, 0, 0);                          \
+    }                                                                                           \
     __builtin_amdgcn_s_setprio(0);                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                          \
   }
@@ -160,13 +179,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
     char* oth = smem + ((t + 1) & 1) * STAGE_BYTES;
     // ---------------- phase 1: a0 x b0 ----------------
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        b0f[j][ks] = *reinterpret_cast<const bf16x8*>(cur + U_B0 * UNIT_BYTES + b_off[ks] + j * 2048);
+      for (int j = 0; j < NBF; ++j)
+        b0f[j][ks] = *reinterpret_cast<const bf16x8*>(cur + U_B0 * UNIT_BYTES + b_off[ks] + j * FROWS);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        af[i][ks] = *reinterpret_cast<const bf16x8*>(cur + U_A0 * UNIT_BYTES + a_off[ks] + i * 2048);
+      for (int i = 0; i < NAF; ++i)
+        af[i][ks] = *reinterpret_cast<const bf16x8*>(cur + U_A0 * UNIT_BYTES + a_off[ks] + i * FROWS);
     }
     dma_unit(Wb, offB[1], kbyte(t + 1), oth + U_B1 * UNIT_BYTES, wave);
     G256_VMCNT8();
@@ -175,10 +194,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
     G256_BARRIER();
     // ---------------- phase 2: a0 x b1 ----------------
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        b1f[j][ks] = *reinterpret_cast<const bf16x8*>(cur + U_B1 * UNIT_BYTES + b_off[ks] + j * 2048);
+      for (int j = 0; j < NBF; ++j)
+        b1f[j][ks] = *reinterpret_cast<const bf16x8*>(cur + U_B1 * UNIT_BYTES + b_off[ks] + j * FROWS);
     dma_unit(Ab, offA[1], kbyte(t + 1), oth + U_A1 * UNIT_BYTES, wave);
     G256_VMCNT8();
     G256_BARRIER();
@@ -186,10 +205,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
     G256_BARRIER();
     // ---------------- phase 3: a1 x b1 ----------------
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        af[i][ks] = *reinterpret_cast<const bf16x8*>(cur + U_A1 * UNIT_BYTES + a_off[ks] + i * 2048);
+      for (int i = 0; i < NAF; ++i)
+        af[i][ks] = *reinterpret_cast<const bf16x8*>(cur + U_A1 * UNIT_BYTES + a_off[ks] + i * FROWS);
     dma_unit(Ab, offA[0], kbyte(t + 2), cur + U_A0 * UNIT_BYTES, wave);
     G256_BARRIER();
     G256_MFMA(1, b1f, 1);
@@ -205,50 +224,64 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain tail DMA before the LDS is released
   if (wr == 0) G256_BARRIER();                       // re-balance the stagger
 
-  // ---- epilogue: lane owns m = fr, n = kq*4 + 0..3 of each 16x16 fragment ----
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int64_t m = m0 + wr * 128 + (i >> 2) * 64 + (i & 3) * 16 + fr;
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t n = n0 + wc * 64 + (j >> 1) * 32 + (j & 1) * 16 + kq * 4;
-      if (n >= p.N) continue;
-      f32x4 v = acc[i][j];
-      if (p.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-      }
-      const int64_t sub = n / p.nsplit, col = n - sub * p.nsplit;
-      const int64_t off = sub * p.split_stride + m * p.ldo + col;
-      if (EPI == ICV_EPI_BF16 || EPI == ICV_EPI_GELU_BF16) {
-        if (EPI == ICV_EPI_GELU_BF16) {
-          v[0] = gelu_tanh(v[0]); v[1] = gelu_tanh(v[1]); v[2] = gelu_tanh(v[2]); v[3] = gelu_tanh(v[3]);
-        }
-        *reinterpret_cast<uint2*>((bf16_t*)p.out + off) =
-            make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-      } else if (EPI == ICV_EPI_RESID_F32) {
-        const float4 r = *reinterpret_cast<const float4*>(p.resid + m * p.ldr + n);
-        float4 o;
-        if (p.gate) {
-          const float4 gt = *reinterpret_cast<const float4*>(p.gate + n);
-          o = make_float4(r.x + gt.x * v[0], r.y + gt.y * v[1], r.z + gt.z * v[2], r.w + gt.w * v[3]);
-        } else {
-          o = make_float4(r.x + v[0], r.y + v[1], r.z + v[2], r.w + v[3]);
-        }
-        *reinterpret_cast<float4*>((float*)p.out + off) = o;
-      } else {
-        *reinterpret_cast<float4*>((float*)p.out + off) = make_float4(v[0], v[1], v[2], v[3]);
-      }
-    }
+  // ---- epilogue: a lane owns ONE row m and runs of 4 consecutive n (swapped MFMA operands) ----
+#define G256_EMIT(M_, N_, V0_, V1_, V2_, V3_)                                                          \
+  {                                                                                                    \
+    const int64_t m = (M_), n = (N_);                                                                  \
+    if (m < p.M && n < p.N) {                                                                          \
+      float v0 = (V0_), v1 = (V1_), v2 = (V2_), v3 = (V3_);                                            \
+      if (p.bias) {                                                                                    \
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);                                 \
+        v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;                                                    \
+      }                                                                                                \
+      const int64_t sub = n / p.nsplit, col = n - sub * p.nsplit;                                      \
+      const int64_t off = sub * p.split_stride + m * p.ldo + col;                                      \
+      if (EPI == ICV_EPI_BF16 || EPI == ICV_EPI_GELU_BF16) {                                           \
+        if (EPI == ICV_EPI_GELU_BF16) {                                                                \
+          v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3);              \
+        }                                                                                              \
+        *reinterpret_cast<uint2*>((bf16_t*)p.out + off) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)); \
+      } else if (EPI == ICV_EPI_RESID_F32) {                                                           \
+        const float4 r = *reinterpret_cast<const float4*>(p.resid + m * p.ldr + n);                    \
+        float4 o;                                                                                      \
+        if (p.gate) {                                                                                  \
+          const float4 gt = *reinterpret_cast<const float4*>(p.gate + n);                              \
+          o = make_float4(r.x + gt.x * v0, r.y + gt.y * v1, r.z + gt.z * v2, r.w + gt.w * v3);         \
+        } else {                                                                                       \
+          o = make_float4(r.x + v0, r.y + v1, r.z + v2, r.w + v3);                                     \
+        }                                                                                              \
+        *reinterpret_cast<float4*>((float*)p.out + off) = o;                                           \
+      } else {                                                                                         \
+        *reinterpret_cast<float4*>((float*)p.out + off) = make_float4(v0, v1, v2, v3);                 \
+      }                                                                                                \
+    }                                                                                                  \
   }
+  if (MF == 16) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        G256_EMIT(m0 + wr * 128 + (i >> 2) * 64 + (i & 3) * 16 + fr, n0 + wc * 64 + (j >> 1) * 32 + (j & 1) * 16 + kq * 4,
+                  acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3])
+  } else {
+    // 32x32 C layout: col = lane&31 (-> m), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (-> n)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+          G256_EMIT(m0 + wr * 128 + (i >> 1) * 64 + (i & 1) * 32 + fr, n0 + wc * 64 + j * 32 + rr * 8 + kq * 4,
+                    acc32[i][j][rr * 4 + 0], acc32[i][j][rr * 4 + 1], acc32[i][j][rr * 4 + 2], acc32[i][j][rr * 4 + 3])
+  }
+#undef G256_EMIT
 }
 
-template <int EPI>
+template <int EPI, int MF>
 int launch(const Params& p, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI, MF>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) {
       icv_set_error("gemm256: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -257,7 +290,7 @@ int launch(const Params& p, hipStream_t st) {
     attr_set = true;
   }
   const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p);
+  hipLaunchKernelGGL((gemm256_kernel<EPI, MF>), dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p);
   return icv_check_launch("icv_gemm_bf16(256)");
 }
 
@@ -274,11 +307,12 @@ int icv_gemm256_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw,
   p.resid = resid; p.ldr = ldr; p.gate = gate;
   p.tiles_m = (int)((M + g256::BM - 1) / g256::BM);
   p.tiles_n = (int)((N + g256::BN - 1) / g256::BN);
+  const bool m32 = icv_get_option_int("gemm256_mfma", 16) == 32;
   switch (epilogue) {
-    case ICV_EPI_BF16: return g256::launch<ICV_EPI_BF16>(p, st);
-    case ICV_EPI_GELU_BF16: return g256::launch<ICV_EPI_GELU_BF16>(p, st);
-    case ICV_EPI_RESID_F32: return g256::launch<ICV_EPI_RESID_F32>(p, st);
-    case ICV_EPI_F32: return g256::launch<ICV_EPI_F32>(p, st);
+    case ICV_EPI_BF16: return m32 ? g256::launch<ICV_EPI_BF16, 32>(p, st) : g256::launch<ICV_EPI_BF16, 16>(p, st);
+    case ICV_EPI_GELU_BF16: return m32 ? g256::launch<ICV_EPI_GELU_BF16, 32>(p, st) : g256::launch<ICV_EPI_GELU_BF16, 16>(p, st);
+    case ICV_EPI_RESID_F32: return m32 ? g256::launch<ICV_EPI_RESID_F32, 32>(p, st) : g256::launch<ICV_EPI_RESID_F32, 16>(p, st);
+    case ICV_EPI_F32: return m32 ? g256::launch<ICV_EPI_F32, 32>(p, st) : g256::launch<ICV_EPI_F32, 16>(p, st);
   }
   icv_set_error("icv_gemm_bf16: unknown epilogue %d", epilogue);
   return 1;

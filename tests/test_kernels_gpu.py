@@ -111,6 +111,51 @@ def test_gemm(hip_ops, M, N, K, epi):
         assert_f32_close(out, acc, what="gemm f32")
 
 
+@pytest.mark.parametrize("epi", [EPI_BF16, EPI_GELU_BF16, EPI_RESID_F32, EPI_F32])
+def test_gemm256_mfma32_variant(hip_ops, epi):
+    """gemm256 with v_mfma_f32_32x32x16_bf16 fragments (option gemm256_mfma = 32) against the oracle, incl.
+    an M tail, a split-plane output and a transposition-detecting identity case."""
+    hip_ops.lib.icv_set_option(b"gemm256", 1)
+    hip_ops.lib.icv_set_option(b"gemm256_mfma", 32)
+    try:
+        for M, N, K in ((777, 512, 256), (1500, 1024, 2048), (256, 256, 64)):
+            a = rnd((M, K), 221).to(torch.bfloat16)
+            w = rnd((N, K), 222, 1.0 / math.sqrt(K)).to(torch.bfloat16)
+            bias = rnd((N,), 223, 0.1)
+            acc = a.float() @ w.float().t() + bias
+            if epi in (EPI_BF16, EPI_GELU_BF16):
+                out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+                hip_ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out, epi)
+                assert_bf16_close(out, F.gelu(acc, approximate="tanh") if epi == EPI_GELU_BF16 else acc, f"gemm256/32 {M}x{N}x{K}")
+            elif epi == EPI_RESID_F32:
+                resid, gate = rnd((M, N), 224), rnd((N,), 225)
+                x = resid.clone().to(DEV)
+                hip_ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), x, epi, resid=x, gate=gate.to(DEV))
+                assert_f32_close(x, resid + gate * acc, what="gemm256/32 resid")
+            else:
+                out = torch.empty((M, N), device=DEV)
+                hip_ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out, epi)
+                assert_f32_close(out, acc, what="gemm256/32 f32")
+        if epi == EPI_F32:
+            n = 256
+            eye = torch.eye(n).to(torch.bfloat16)
+            w = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251 - 125).to(torch.bfloat16)
+            out = torch.empty((n, n), device=DEV)
+            hip_ops.gemm(eye.to(DEV), w.to(DEV), None, out, EPI_F32)
+            assert torch.equal(out.cpu(), w.float().t())
+        if epi == EPI_BF16:
+            M, d, K = 333, 256, 512
+            a = rnd((M, K), 231).to(torch.bfloat16)
+            w = rnd((3 * d, K), 232, 0.05).to(torch.bfloat16)
+            bias = rnd((3 * d,), 233, 0.1)
+            out = torch.full((3, M, d), 7.0, dtype=torch.bfloat16, device=DEV)
+            hip_ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out, EPI_BF16, nsplit=d)
+            assert_bf16_close(out, (a.float() @ w.float().t() + bias).reshape(M, 3, d).permute(1, 0, 2), "gemm256/32 split")
+    finally:
+        hip_ops.lib.icv_set_option(b"gemm256", 2)
+        hip_ops.lib.icv_set_option(b"gemm256_mfma", 16)
+
+
 @pytest.mark.parametrize("variant", [0, 1])
 def test_gemm_variants_agree_and_race_screen(hip_ops, variant):
     """128-tile kernel vs 256-tile 4-phase kernel on the same problem (compare both to the oracle),
