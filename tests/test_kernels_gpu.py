@@ -443,3 +443,63 @@ def test_error_reporting(hip_ops):
     w = torch.zeros((8, 100), dtype=torch.bfloat16, device=DEV)
     with pytest.raises(native.NativeError, match="multiple of 64"):
         hip_ops.gemm(a, w, None, torch.empty((8, 8), dtype=torch.bfloat16, device=DEV), EPI_BF16)
+
+
+# ---------------------------------------------------------------------------------------------------
+# edge cases: minimum / ragged sizes through every kernel family (tails, clamps, masks)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kernel", [1, 2, 3, 4])
+def test_attention_minimum_sizes(hip_ops, kernel):
+    hip_ops.lib.icv_set_option(b"attn_kernel", kernel)
+    try:
+        for Sq, Skv, H in ((1, 1, 1), (1, 513, 2), (257, 1, 1), (31, 63, 3), (32, 64, 1), (255, 127, 2)):
+            d = H * 128
+            q, k, v = (rnd((Sq, d), 301).to(torch.bfloat16), rnd((Skv, d), 302).to(torch.bfloat16), rnd((Skv, d), 303).to(torch.bfloat16))
+            ref = R.attention(q.float(), k.float(), v.float(), H)
+            o = torch.full((Sq + 2, d), 9.0, dtype=torch.bfloat16, device=DEV)      # guard rows after the output
+            hip_ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), o[:Sq], H, 1.0 / math.sqrt(128))
+            assert_bf16_close(o[:Sq], ref, f"attention kernel {kernel} Sq={Sq} Skv={Skv}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
+            assert bool((o[Sq:] == 9.0).all()), "wrote past the last query row"
+    finally:
+        hip_ops.lib.icv_set_option(b"attn_kernel", 2)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 4, 64), (3, 68, 64), (255, 252, 192), (257, 260, 128), (513, 256, 64)])
+def test_gemm_ragged_shapes(hip_ops, M, N, K):
+    a = rnd((M, K), 311).to(torch.bfloat16)
+    w = rnd((N, K), 312, 1.0 / math.sqrt(K)).to(torch.bfloat16)
+    bias = rnd((N,), 313, 0.1)
+    out = torch.full((M + 1, N), 5.0, device=DEV)
+    hip_ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out[:M], EPI_F32)
+    assert_f32_close(out[:M], a.float() @ w.float().t() + bias, what=f"gemm ragged {M}x{N}x{K}")
+    assert bool((out[M:] == 5.0).all()), "wrote past the last row"
+
+
+def test_norm_kernels_single_row(hip_ops):
+    x = rnd((1, 1536), 321, 3.0)
+    out = torch.empty((1, 1536), dtype=torch.bfloat16, device=DEV)
+    hip_ops.ln_modulate(x.to(DEV), out, eps=1e-6)
+    assert_bf16_close(out, R.layer_norm(x, None, None, 1e-6), "ln single row")
+    q = rnd((1, 1536), 322).to(torch.bfloat16)
+    w = 1 + rnd((1536,), 323, 0.1)
+    rope = RopeTable.build(2, 2, 2, DEV)
+    g = q.clone().to(DEV)
+    hip_ops.rmsnorm_rope(g, w.to(DEV), eps=1e-6, rope=rope, tok0=7)        # last token of the grid
+    ref = R.rope_apply(R.rms_norm(q.float(), w, 1e-6), R.rope_freqs_3d(128, 2, 2, 2)[7:8], 12)
+    assert_bf16_close(g, ref, "rmsnorm+rope single row at the last token")
+
+
+def test_single_frame_generation_grid(hip_ops):
+    """num_frames = 1 (T = 1) is legal (1 mod 4): the whole forward must work on a 1-frame token grid."""
+    from infinicube_amd.videogen import synthetic as syn
+    from infinicube_amd.videogen.config import TokenGrid, preset
+    from infinicube_amd.videogen.dit import WanDiT
+    cfg, grid = preset("tiny"), TokenGrid(1, 32, 48)
+    sd, bsd = syn.make_dit_state_dict(cfg), syn.make_buffer_embedder_state_dict(cfg)
+    noise, ctx, bl = syn.make_latent_noise(grid), syn.make_text_context(cfg, 1), syn.make_buffer_latents(cfg, grid)
+    m = WanDiT(cfg, sd, hip_ops, bsd).prepare(grid)
+    m.forward_tokens(noise.to(DEV), m.encode_context(ctx), 500.0, m.embed_buffers(bl), m.head_out[0])
+    torch.cuda.synchronize()
+    v = R.unpatchify(m.head_out[0].cpu(), (grid.T, grid.Hp, grid.Wp), cfg.out_dim)
+    ref = R.dit_forward(R.round_state_dict_to_bf16(sd), cfg, noise, ctx, 500.0, R.buffer_embed(R.round_state_dict_to_bf16(bsd), bl))
+    assert float((v - ref).norm() / ref.norm()) < 2e-2
