@@ -9,40 +9,20 @@
 //   * optional carried softmax state (fp32 O accumulator + running max / sum per row) so that one
 //     attention can be split over several launches along the KEY axis — the sequence-parallel path
 //     consumes K/V chunks as the RCCL all-gather delivers them (seqpar.py).
-#include "icv_common.h"
+#include "attn_common.h"
 
 namespace att2 {
 
-constexpr int D = 128;
+using attc::D;
+using attc::NEG_BIG;
+using attc::Params;
+using attc::lds_read_tr16;
 constexpr int KVB = 128;                 // keys per staged tile
 constexpr int QB = 256;                  // query rows per block (8 waves x 32)
 constexpr int KT_BYTES = KVB * D * 2;    // 32 KiB (K or V part of a stage)
 constexpr int STAGE_BYTES = 2 * KT_BYTES;
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;  // 128 KiB
 constexpr int HALF_BYTES = 64 * D * 2;      // 16 KiB
-constexpr float NEG_BIG = -1.0e30f;
-
-struct Params {
-  const bf16_t* q; int64_t ldq;
-  const bf16_t* k; int64_t ldk;
-  const bf16_t* v; int64_t ldv;
-  bf16_t* o; int64_t ldo;
-  float* acc; int64_t ldacc;   // carried O^T state, f32 [Sq, heads*128] (may be NULL)
-  float* ml;                   // carried (m, l) per (row, head): f32 [Sq, heads, 2]
-  int64_t Sq, Skv;
-  int heads, nqb;
-  int state_in, state_out;
-  float sc;   // scale * log2(e)
-  float thr;  // defer-max threshold, log2 units
-};
-
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-
-__device__ __forceinline__ bf16x4 lds_read_tr16(const char* p) {
-  s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
-  return __builtin_bit_cast(bf16x4, r);
-}
-
 // VAR bit flags: 1 = stagger wave groups, 4 = s_setprio(1) around MFMA clusters
 template <int VAR>
 __global__ __launch_bounds__(512) void attn2_kernel(Params p) {
@@ -54,16 +34,8 @@ __global__ __launch_bounds__(512) void attn2_kernel(Params p) {
   const int hi = lane >> 5;
   const int l31 = lane & 31;
 
-  const int nwg = p.heads * p.nqb;
-  int wg;
-  {
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, local = bid >> 3;
-    const int qn = nwg >> 3, r = nwg & 7;
-    wg = (xcd < r ? xcd * (qn + 1) : r * (qn + 1) + (xcd - r) * qn) + local;
-  }
-  const int head = wg / p.nqb;
-  const int qb = wg - head * p.nqb;
+  int head, qb;
+  attc::work_item(p, head, qb);
   const int64_t q0 = (int64_t)qb * QB + wave * 32;
 
   const bf16_t* qh = p.q + (int64_t)head * D;
@@ -124,26 +96,7 @@ __global__ __launch_bounds__(512) void attn2_kernel(Params p) {
   // ---- softmax state: O^T accumulator (query in the lane), running max, partial row sum ----
   f32x16 ot[4];
   float m_run, l_run;
-  if (p.state_in) {
-    const float* ap = p.acc + qr_c * p.ldacc + (int64_t)head * D + 4 * hi;
-#pragma unroll
-    for (int d0 = 0; d0 < 4; ++d0)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const float4 a = *reinterpret_cast<const float4*>(ap + d0 * 32 + rr * 8);
-        ot[d0][rr * 4 + 0] = a.x; ot[d0][rr * 4 + 1] = a.y; ot[d0][rr * 4 + 2] = a.z; ot[d0][rr * 4 + 3] = a.w;
-      }
-    const float2 mlv = *reinterpret_cast<const float2*>(p.ml + (qr_c * p.heads + head) * 2);
-    m_run = mlv.x;
-    l_run = hi == 0 ? mlv.y : 0.f;   // the row sum is kept as two half-lane partials
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ot[i][r] = 0.f;
-    m_run = NEG_BIG;
-    l_run = 0.f;
-  }
+  attc::load_state(p, qr_c, head, hi, ot, m_run, l_run);
 
   const int nt = (int)((p.Skv + KVB - 1) / KVB);
   A2_LOAD_TILE(0);
@@ -246,32 +199,7 @@ __global__ __launch_bounds__(512) void attn2_kernel(Params p) {
   if (grp == 0) A2_BARRIER();
 #undef A2_HALF
 
-  // ---- epilogue ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const int64_t qr = q0 + l31;
-  if (qr < p.Sq) {
-    if (p.state_out) {
-      float* ap = p.acc + qr * p.ldacc + (int64_t)head * D + 4 * hi;
-#pragma unroll
-      for (int d0 = 0; d0 < 4; ++d0)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-          *reinterpret_cast<float4*>(ap + d0 * 32 + rr * 8) =
-              make_float4(ot[d0][rr * 4 + 0], ot[d0][rr * 4 + 1], ot[d0][rr * 4 + 2], ot[d0][rr * 4 + 3]);
-      if (hi == 0) *reinterpret_cast<float2*>(p.ml + (qr * p.heads + head) * 2) = make_float2(m_run, l_tot);
-    } else {
-      const float inv = 1.0f / l_tot;
-      bf16_t* op = p.o + qr * p.ldo + (int64_t)head * D + 4 * hi;
-#pragma unroll
-      for (int d0 = 0; d0 < 4; ++d0)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const float a = ot[d0][rr * 4 + 0] * inv, b = ot[d0][rr * 4 + 1] * inv;
-          const float c = ot[d0][rr * 4 + 2] * inv, d = ot[d0][rr * 4 + 3] * inv;
-          *reinterpret_cast<uint2*>(op + d0 * 32 + rr * 8) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
-        }
-    }
-  }
+  attc::store_result(p, q0 + l31, head, hi, ot, m_run, l_run);
 }
 
 template <int VAR>
@@ -298,13 +226,7 @@ int icv_attn2_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, c
                        int state_out, int64_t Sq, int64_t Skv, int64_t heads, float scale, int var,
                        hipStream_t st) {
   att2::Params p;
-  p.q = (const bf16_t*)q; p.ldq = ldq; p.k = (const bf16_t*)k; p.ldk = ldk;
-  p.v = (const bf16_t*)v; p.ldv = ldv; p.o = (bf16_t*)o; p.ldo = ldo;
-  p.acc = acc; p.ldacc = ldacc; p.ml = ml; p.state_in = state_in; p.state_out = state_out;
-  p.Sq = Sq; p.Skv = Skv; p.heads = (int)heads;
-  p.nqb = (int)((Sq + att2::QB - 1) / att2::QB);
-  p.sc = scale * 1.4426950408889634f;
-  p.thr = (float)icv_get_option_int("attn_defer_max_log2", 8);
+  attc::fill_params(p, q, ldq, k, ldk, v, ldv, o, ldo, acc, ldacc, ml, state_in, state_out, Sq, Skv, heads, scale, att2::QB);
   switch (var) {
     case 0: return att2::launch<0>(p, st);
     case 1: return att2::launch<1>(p, st);

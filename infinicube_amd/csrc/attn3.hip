@@ -13,37 +13,18 @@
 //   interleaves them; the matrix pipe is not shared with another wave), and each K/V fragment read from
 //   LDS feeds two MFMAs instead of one.  K/V tiles (64 keys) are staged HBM -> VGPR -> LDS one tile
 //   ahead, double-buffered, one barrier per tile.  Carried softmax state as in attn2.hip.
-#include "icv_common.h"
+#include "attn_common.h"
 
 namespace att3 {
 
-constexpr int D = 128;
+using attc::D;
+using attc::NEG_BIG;
+using attc::Params;
+using attc::lds_read_tr16;
 constexpr int KVB = 64;
 constexpr int QB = 256;                   // 4 waves x 64 rows
 constexpr int TILE_BYTES = KVB * D * 2;   // 16 KiB
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;
-constexpr float NEG_BIG = -1.0e30f;
-
-struct Params {
-  const bf16_t* q; int64_t ldq;
-  const bf16_t* k; int64_t ldk;
-  const bf16_t* v; int64_t ldv;
-  bf16_t* o; int64_t ldo;
-  float* acc; int64_t ldacc;
-  float* ml;
-  int64_t Sq, Skv;
-  int heads, nqb;
-  int state_in, state_out;
-  float sc, thr;
-};
-
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-
-__device__ __forceinline__ bf16x4 lds_read_tr16(const char* p) {
-  s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
-  return __builtin_bit_cast(bf16x4, r);
-}
-
 template <int VAR>
 __global__ __launch_bounds__(256, 1) void attn3_kernel(Params p) {
   constexpr bool SETPRIO = VAR & 4;
@@ -54,16 +35,8 @@ __global__ __launch_bounds__(256, 1) void attn3_kernel(Params p) {
   const int hi = lane >> 5;
   const int l31 = lane & 31;
 
-  const int nwg = p.heads * p.nqb;
-  int wg;
-  {
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, local = bid >> 3;
-    const int qn = nwg >> 3, r = nwg & 7;
-    wg = (xcd < r ? xcd * (qn + 1) : r * (qn + 1) + (xcd - r) * qn) + local;
-  }
-  const int head = wg / p.nqb;
-  const int qb = wg - head * p.nqb;
+  int head, qb;
+  attc::work_item(p, head, qb);
   const int64_t q0 = (int64_t)qb * QB + wave * 64;
 
   const bf16_t* qh = p.q + (int64_t)head * D;
@@ -116,29 +89,8 @@ __global__ __launch_bounds__(256, 1) void attn3_kernel(Params p) {
 
   f32x16 ot[2][4];
   float m_run[2], l_run[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    if (p.state_in) {
-      const float* ap = p.acc + qr_c[s] * p.ldacc + (int64_t)head * D + 4 * hi;
-#pragma unroll
-      for (int d0 = 0; d0 < 4; ++d0)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const float4 a = *reinterpret_cast<const float4*>(ap + d0 * 32 + rr * 8);
-          ot[s][d0][rr * 4 + 0] = a.x; ot[s][d0][rr * 4 + 1] = a.y; ot[s][d0][rr * 4 + 2] = a.z; ot[s][d0][rr * 4 + 3] = a.w;
-        }
-      const float2 mlv = *reinterpret_cast<const float2*>(p.ml + (qr_c[s] * p.heads + head) * 2);
-      m_run[s] = mlv.x;
-      l_run[s] = hi == 0 ? mlv.y : 0.f;
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ot[s][i][r] = 0.f;
-      m_run[s] = NEG_BIG;
-      l_run[s] = 0.f;
-    }
-  }
+  attc::load_state(p, qr_c[0], head, hi, ot[0], m_run[0], l_run[0]);
+  attc::load_state(p, qr_c[1], head, hi, ot[1], m_run[1], l_run[1]);
 
   const int nt = (int)((p.Skv + KVB - 1) / KVB);
   A3_LOAD_TILE(0);
@@ -250,35 +202,8 @@ __global__ __launch_bounds__(256, 1) void attn3_kernel(Params p) {
     if (t + 2 < nt) A3_LOAD_TILE(t + 2);
   }
 
-  // ---- epilogue ----
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const float l_tot = l_run[s] + __shfl_xor(l_run[s], 32, 64);
-    const int64_t qr = q0 + s * 32 + l31;
-    if (qr < p.Sq) {
-      if (p.state_out) {
-        float* ap = p.acc + qr * p.ldacc + (int64_t)head * D + 4 * hi;
-#pragma unroll
-        for (int d0 = 0; d0 < 4; ++d0)
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr)
-            *reinterpret_cast<float4*>(ap + d0 * 32 + rr * 8) =
-                make_float4(ot[s][d0][rr * 4 + 0], ot[s][d0][rr * 4 + 1], ot[s][d0][rr * 4 + 2], ot[s][d0][rr * 4 + 3]);
-        if (hi == 0) *reinterpret_cast<float2*>(p.ml + (qr * p.heads + head) * 2) = make_float2(m_run[s], l_tot);
-      } else {
-        const float inv = 1.0f / l_tot;
-        bf16_t* op = p.o + qr * p.ldo + (int64_t)head * D + 4 * hi;
-#pragma unroll
-        for (int d0 = 0; d0 < 4; ++d0)
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const float a = ot[s][d0][rr * 4 + 0] * inv, b = ot[s][d0][rr * 4 + 1] * inv;
-            const float c = ot[s][d0][rr * 4 + 2] * inv, d = ot[s][d0][rr * 4 + 3] * inv;
-            *reinterpret_cast<uint2*>(op + d0 * 32 + rr * 8) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
-          }
-      }
-    }
-  }
+  attc::store_result(p, q0 + l31, head, hi, ot[0], m_run[0], l_run[0]);
+  attc::store_result(p, q0 + 32 + l31, head, hi, ot[1], m_run[1], l_run[1]);
 }
 
 }  // namespace att3
@@ -288,13 +213,7 @@ int icv_attn3_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, c
                        int state_out, int64_t Sq, int64_t Skv, int64_t heads, float scale, int var,
                        hipStream_t st) {
   att3::Params p;
-  p.q = (const bf16_t*)q; p.ldq = ldq; p.k = (const bf16_t*)k; p.ldk = ldk;
-  p.v = (const bf16_t*)v; p.ldv = ldv; p.o = (bf16_t*)o; p.ldo = ldo;
-  p.acc = acc; p.ldacc = ldacc; p.ml = ml; p.state_in = state_in; p.state_out = state_out;
-  p.Sq = Sq; p.Skv = Skv; p.heads = (int)heads;
-  p.nqb = (int)((Sq + att3::QB - 1) / att3::QB);
-  p.sc = scale * 1.4426950408889634f;
-  p.thr = (float)icv_get_option_int("attn_defer_max_log2", 8);
+  attc::fill_params(p, q, ldq, k, ldk, v, ldv, o, ldo, acc, ldacc, ml, state_in, state_out, Sq, Skv, heads, scale, att3::QB);
   dim3 grid((unsigned)((int64_t)p.heads * p.nqb)), block(256);
   switch (var) {
     case 0: hipLaunchKernelGGL(att3::attn3_kernel<0>, grid, block, 0, st, p); break;

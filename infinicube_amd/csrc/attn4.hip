@@ -19,35 +19,20 @@
 //   vmcnt(4) = its share of tile t+1 has landed; the barrier ending I_t publishes it; tile t+1 is first
 //   read in I_{t+1}.  Tail tiles re-load the last tile (clamped) to keep the counted waits uniform.
 //   * carried softmax state as in attn2.hip (key-axis chunking for the sequence-parallel path).
-#include "icv_common.h"
+#include "attn_common.h"
 
 namespace att4 {
 
-constexpr int D = 128;
+using attc::D;
+using attc::NEG_BIG;
+using attc::Params;
+using attc::lds_read_tr16;
 constexpr int KVB = 64;
 constexpr int QB = 256;
 constexpr int TILE_BYTES = KVB * D * 2;      // 16 KiB (K or V)
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;  // 32 KiB
 constexpr int NSTAGE = 4;
 constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;  // 128 KiB
-constexpr float NEG_BIG = -1.0e30f;
-
-struct Params {
-  const bf16_t* q; int64_t ldq;
-  const bf16_t* k; int64_t ldk;
-  const bf16_t* v; int64_t ldv;
-  bf16_t* o; int64_t ldo;
-  float* acc; int64_t ldacc;
-  float* ml;
-  int64_t Sq, Skv;
-  int heads, nqb;
-  int state_in, state_out;
-  float sc, thr;
-};
-
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void gbl_void;
 
 // LDS-DMA through inline asm: hipcc does not count it, so it never guards the (alias-info-free)
 // ds_read_b64_tr_b16 reads with vmcnt(0); completion is tracked by our own counted s_waitcnt vmcnt.
@@ -66,11 +51,6 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
       : "memory");
 }
 
-__device__ __forceinline__ bf16x4 lds_read_tr16(const char* p) {
-  s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
-  return __builtin_bit_cast(bf16x4, r);
-}
-
 // VAR bit flags: 1 = stagger wave groups, 2 = issue all 16 K-fragment reads ahead of the QK^T MFMAs,
 //                4 = s_setprio(1) around MFMA clusters
 template <int VAR>
@@ -83,16 +63,8 @@ __global__ __launch_bounds__(512) void attn4_kernel(Params p) {
   const int hi = lane >> 5;
   const int l31 = lane & 31;
 
-  const int nwg = p.heads * p.nqb;
-  int wg;
-  {
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, local = bid >> 3;
-    const int qn = nwg >> 3, r = nwg & 7;
-    wg = (xcd < r ? xcd * (qn + 1) : r * (qn + 1) + (xcd - r) * qn) + local;
-  }
-  const int head = wg / p.nqb;
-  const int qb = wg - head * p.nqb;
+  int head, qb;
+  attc::work_item(p, head, qb);
   const int64_t q0 = (int64_t)qb * QB + wave * 32;
 
   const bf16_t* qh = p.q + (int64_t)head * D;
@@ -105,26 +77,7 @@ __global__ __launch_bounds__(512) void attn4_kernel(Params p) {
   // ---- softmax state ----
   f32x16 ot[4];
   float m_run, l_run;
-  if (p.state_in) {
-    const float* ap = p.acc + qr_c * p.ldacc + (int64_t)head * D + 4 * hi;
-#pragma unroll
-    for (int d0 = 0; d0 < 4; ++d0)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const float4 a = *reinterpret_cast<const float4*>(ap + d0 * 32 + rr * 8);
-        ot[d0][rr * 4 + 0] = a.x; ot[d0][rr * 4 + 1] = a.y; ot[d0][rr * 4 + 2] = a.z; ot[d0][rr * 4 + 3] = a.w;
-      }
-    const float2 mlv = *reinterpret_cast<const float2*>(p.ml + (qr_c * p.heads + head) * 2);
-    m_run = mlv.x;
-    l_run = hi == 0 ? mlv.y : 0.f;
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ot[i][r] = 0.f;
-    m_run = NEG_BIG;
-    l_run = 0.f;
-  }
+  attc::load_state(p, qr_c, head, hi, ot, m_run, l_run);
 
   bf16x8 qf[8];
   {
@@ -292,32 +245,7 @@ __global__ __launch_bounds__(512) void attn4_kernel(Params p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail DMAs before the LDS is released
   if (grp == 0 && STAGGER) A4_BARRIER();             // re-balance the stagger
 
-  // ---- epilogue ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const int64_t qr = q0 + l31;
-  if (qr < p.Sq) {
-    if (p.state_out) {
-      float* ap = p.acc + qr * p.ldacc + (int64_t)head * D + 4 * hi;
-#pragma unroll
-      for (int d0 = 0; d0 < 4; ++d0)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-          *reinterpret_cast<float4*>(ap + d0 * 32 + rr * 8) =
-              make_float4(ot[d0][rr * 4 + 0], ot[d0][rr * 4 + 1], ot[d0][rr * 4 + 2], ot[d0][rr * 4 + 3]);
-      if (hi == 0) *reinterpret_cast<float2*>(p.ml + (qr * p.heads + head) * 2) = make_float2(m_run, l_tot);
-    } else {
-      const float inv = 1.0f / l_tot;
-      bf16_t* op = p.o + qr * p.ldo + (int64_t)head * D + 4 * hi;
-#pragma unroll
-      for (int d0 = 0; d0 < 4; ++d0)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const float a = ot[d0][rr * 4 + 0] * inv, b = ot[d0][rr * 4 + 1] * inv;
-          const float c = ot[d0][rr * 4 + 2] * inv, d = ot[d0][rr * 4 + 3] * inv;
-          *reinterpret_cast<uint2*>(op + d0 * 32 + rr * 8) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
-        }
-    }
-  }
+  attc::store_result(p, q0 + l31, head, hi, ot, m_run, l_run);
 }
 
 template <int VAR>
@@ -344,13 +272,7 @@ int icv_attn4_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, c
                        int state_out, int64_t Sq, int64_t Skv, int64_t heads, float scale, int var,
                        hipStream_t st) {
   att4::Params p;
-  p.q = (const bf16_t*)q; p.ldq = ldq; p.k = (const bf16_t*)k; p.ldk = ldk;
-  p.v = (const bf16_t*)v; p.ldv = ldv; p.o = (bf16_t*)o; p.ldo = ldo;
-  p.acc = acc; p.ldacc = ldacc; p.ml = ml; p.state_in = state_in; p.state_out = state_out;
-  p.Sq = Sq; p.Skv = Skv; p.heads = (int)heads;
-  p.nqb = (int)((Sq + att4::QB - 1) / att4::QB);
-  p.sc = scale * 1.4426950408889634f;
-  p.thr = (float)icv_get_option_int("attn_defer_max_log2", 8);
+  attc::fill_params(p, q, ldq, k, ldk, v, ldv, o, ldo, acc, ldacc, ml, state_in, state_out, Sq, Skv, heads, scale, att4::QB);
   switch (var) {
     case 0: return att4::launch<0>(p, st);
     case 1: return att4::launch<1>(p, st);

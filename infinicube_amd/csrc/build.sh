@@ -12,7 +12,7 @@ pids=()
 mkdir -p "$here/build"
 for src in api elementwise gemm gemm256 attn attn2 attn3 attn4 buffers; do
   obj="$here/build/$src.o"
-  if [[ ! -f "$obj" || "$here/$src.hip" -nt "$obj" || "$here/icv_common.h" -nt "$obj" || "$root/include/icvideo.h" -nt "$obj" ]]; then
+  if [[ ! -f "$obj" || "$here/$src.hip" -nt "$obj" || "$here/icv_common.h" -nt "$obj" || "$here/attn_common.h" -nt "$obj" || "$root/include/icvideo.h" -nt "$obj" ]]; then
     "$HIPCC" "${FLAGS[@]}" "$@" -c "$here/$src.hip" -o "$obj" &
     pids+=($!)
   fi
