@@ -1,3 +1,2 @@
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_kernels_gpu.py -q -k "attention" 2>&1 | tail -3
-ATTN_VARIANTS=1004,4005 ATTN_ROUNDS=2 ATTN_ITERS=2 python tools/attn_bench.py 14b 2>&1 | grep -v amdgpu.ids | head -2
+python -m infinicube_amd.videogen.test_api --synthetic --model 1.3b --frames 17 --height 256 --width 448 --steps 10 2>&1 | grep -v amdgpu | tail -12
