@@ -5,36 +5,59 @@
 
 // ---------------------------------------------------------------------------------------------
 // K3 / K8  LayerNorm (+affine) (+modulate): x f32 [rows,d] -> out bf16 [rows,d]
-// NV = d / 256 float4 vectors per lane.
+// A row is owned by W waves of a 256-thread block (4/W rows per block); each lane keeps NV float4 of
+// its row in VGPRs (two-pass fp32 statistics), so d = 256 * W * NV.  W > 1 keeps the per-lane
+// footprint small for wide rows (d = 5120: W = 4, NV = 5 instead of 20 vectors per lane, which halved
+// the achieved bandwidth); the W partial sums meet through 16 bytes of LDS.
 // ---------------------------------------------------------------------------------------------
-template <int NV>
+template <int W>
+__device__ __forceinline__ float row_sum(float v, float* red, int wave) {
+  v = wave_sum(v);
+  if (W == 1) return v;
+  __syncthreads();                       // previous use of red[] is over
+  if ((threadIdx.x & 63) == 0) red[wave] = v;
+  __syncthreads();
+  const int base = (wave / W) * W;
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < W; ++i) t += red[base + i];
+  return t;
+}
+
+template <int NV, int W>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ weight,
     const float* __restrict__ bias, const float* __restrict__ shift,
     const float* __restrict__ scale, bf16_t* __restrict__ out, int64_t ldo, int64_t rows, int d,
     float eps) {
+  __shared__ float red[4];
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const int wave = threadIdx.x >> 6;
+  constexpr int RPB = 4 / W;             // rows per block
+  const int64_t row_raw = (int64_t)blockIdx.x * RPB + wave / W;
+  const bool live = row_raw < rows;      // dead rows still take part in the barriers of row_sum
+  const int64_t row = live ? row_raw : rows - 1;
+  const int sub = wave % W;              // which 1/W of the row this wave owns
   const float4* xr = reinterpret_cast<const float4*>(x + row * ldx);
   float4 v[NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) v[i] = xr[i * 64 + lane];
+  for (int i = 0; i < NV; ++i) v[i] = xr[(i * W + sub) * 64 + lane];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-  const float mean = wave_sum(s) / (float)d;
+  const float mean = row_sum<W>(s, red, wave) / (float)d;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
     q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
   }
-  const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+  const float rstd = rsqrtf(row_sum<W>(q, red, wave) / (float)d + eps);
+  if (!live) return;
   uint2* orow = reinterpret_cast<uint2*>(out + row * ldo);
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int c4 = i * 64 + lane;  // float4 index within the row
+    const int c4 = (i * W + sub) * 64 + lane;  // float4 index within the row
     float4 y = make_float4(v[i].x * rstd, v[i].y * rstd, v[i].z * rstd, v[i].w * rstd);
     if (weight) {
       const float4 w = reinterpret_cast<const float4*>(weight)[c4];
@@ -62,21 +85,25 @@ extern "C" int icv_ln_modulate(const float* x, int64_t ldx, const float* weight,
   ICV_REQUIRE(rows > 0 && d > 0 && d % 256 == 0 && d <= 8192, "icv_ln_modulate: d=%lld must be a multiple of 256 and <= 8192", (long long)d);
   ICV_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0, "icv_ln_modulate: ldx/ldo must be multiples of 4");
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-#define LAUNCH(NV)                                                                             \
-  case NV:                                                                                     \
-    hipLaunchKernelGGL(ln_modulate_kernel<NV>, grid, block, 0, st, x, ldx, weight, bias, shift, \
-                       scale, (bf16_t*)out, ldo, rows, (int)d, eps);                           \
-    break;
-  switch (d / 256) {
-    LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(8) LAUNCH(10) LAUNCH(12)
-    LAUNCH(16) LAUNCH(20) LAUNCH(24) LAUNCH(32)
-    default:
-      icv_set_error("icv_ln_modulate: unsupported d=%lld (d/256 not instantiated)", (long long)d);
-      return 1;
+  const int nvec = (int)(d / 256);                       // float4 per lane at one wave per row
+  int forced = icv_get_option_int("ln_waves_per_row", 0);
+  const int W = (forced == 1 || forced == 2 || forced == 4) && nvec % forced == 0 ? forced
+              : (nvec >= 16 && nvec % 4 == 0) ? 4 : (nvec >= 8 && nvec % 2 == 0) ? 2 : 1;
+  const int NV = nvec / W;
+  dim3 grid((unsigned)((rows * W + 3) / 4)), block(256);
+#define LAUNCH(NV_, W_)                                                                           \
+  if (NV == NV_ && W == W_) {                                                                     \
+    hipLaunchKernelGGL((ln_modulate_kernel<NV_, W_>), grid, block, 0, st, x, ldx, weight, bias, shift, \
+                       scale, (bf16_t*)out, ldo, rows, (int)d, eps);                              \
+    return icv_check_launch("icv_ln_modulate");                                                   \
   }
+  LAUNCH(1, 1) LAUNCH(2, 1) LAUNCH(3, 1) LAUNCH(4, 1) LAUNCH(5, 1) LAUNCH(6, 1) LAUNCH(7, 1)
+  LAUNCH(3, 2) LAUNCH(4, 2) LAUNCH(5, 2) LAUNCH(6, 2) LAUNCH(7, 2)
+  LAUNCH(4, 4) LAUNCH(5, 4) LAUNCH(6, 4) LAUNCH(7, 4) LAUNCH(8, 4)
+  LAUNCH(8, 1) LAUNCH(10, 1) LAUNCH(12, 1) LAUNCH(20, 1) LAUNCH(10, 2) LAUNCH(2, 4) LAUNCH(3, 4)
 #undef LAUNCH
-  return icv_check_launch("icv_ln_modulate");
+  icv_set_error("icv_ln_modulate: unsupported d=%lld (no instantiation for %d vectors x %d waves)", (long long)d, NV, W);
+  return 1;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,2 +1,3 @@
 mkdir -p gpurun_out; export TMPDIR=/tmp
-python -m infinicube_amd.videogen.test_api --synthetic --model 1.3b --frames 17 --height 256 --width 448 --steps 10 2>&1 | grep -v amdgpu | tail -12
+timeout 600 python -m pytest tests/test_kernels_gpu.py -q -k "ln_ or norm" 2>&1 | tail -2
+python tools/ew_bench.py 2>&1 | grep -v amdgpu
