@@ -162,7 +162,10 @@ class WanVideoPipeline:
         self.text_encoder = text_encoder
         self.vae = vae
         self.buffer_embedder: Optional[BufferEmbedder] = None
-        self.scheduler = FlowMatchScheduler(50, 5.0)
+        # sampling defaults of the fork's __call__ ([EXT]); the reference never
+        # overrides them [R infinicube/videogen/inference.py:216-226], so they are attributes here
+        self.num_inference_steps, self.cfg_scale, self.sigma_shift = 50, 5.0, 5.0
+        self.scheduler = FlowMatchScheduler(self.num_inference_steps, self.sigma_shift)
         self._ops = ops
         self._engine = None
         self._engine_key = None
@@ -226,12 +229,15 @@ class WanVideoPipeline:
     @torch.no_grad()
     def __call__(self, prompt: str, negative_prompt: str = "", semantic_buffer_video=None,
                  coordinate_buffer_video=None, height: int = 480, width: int = 832, num_frames: int = 81,
-                 seed: Optional[int] = None, tiled: bool = True, num_inference_steps: int = 50,
-                 cfg_scale: float = 5.0, sigma_shift: float = 5.0, rand_device: str = "cpu",
+                 seed: Optional[int] = None, tiled: bool = True, num_inference_steps: Optional[int] = None,
+                 cfg_scale: Optional[float] = None, sigma_shift: Optional[float] = None, rand_device: str = "cpu",
                  tile_size=(30, 52), tile_stride=(15, 26), progress_bar_cmd=None, return_latents: bool = False,
                  **unused):
         if self.text_encoder is None or self.vae is None:
             raise RuntimeError("WanVideoPipeline: text encoder / VAE not loaded")
+        num_inference_steps = self.num_inference_steps if num_inference_steps is None else num_inference_steps
+        cfg_scale = self.cfg_scale if cfg_scale is None else cfg_scale
+        sigma_shift = self.sigma_shift if sigma_shift is None else sigma_shift
         grid = TokenGrid(num_frames, height, width)
         engine = self._get_engine()
         ops = engine.ops

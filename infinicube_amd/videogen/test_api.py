@@ -82,8 +82,7 @@ def main(argv=None):
         def factory(torch_dtype, device, model_configs):
             pipe = WanVideoPipeline(device, torch_dtype, DiTHolder(sd, cfg), HashTextEncoder(cfg), PoolVAE())
             if args.steps:
-                call = pipe.__class__.__call__
-                pipe.__class__ = type("Pipe", (pipe.__class__,), {"__call__": lambda self, **kw: call(self, **{"num_inference_steps": args.steps, **kw})})
+                pipe.num_inference_steps = args.steps
             return pipe
     else:
         if not (args.checkpoint and args.semantic and args.coordinate):

@@ -63,10 +63,9 @@ def test_generate_frames_and_determinism(generator, monkeypatch, tmp_path):
     sem, co = syn.make_dummy_buffers(GRID)
     saved = {}
     monkeypatch.setattr(inf, "save_video", lambda fr, p, fps, quality: saved.update(n=len(fr), p=p, fps=fps, q=quality))
-    real_call = WanVideoPipeline.__call__
+    assert g.pipe.num_inference_steps == 50 and g.pipe.cfg_scale == 5.0 and g.pipe.sigma_shift == 5.0   # fork defaults
     with contextlib.redirect_stdout(io.StringIO()), monkeypatch.context() as mp:
-        # generate() exposes no step count (fork default 50): shorten it for the test only
-        mp.setattr(WanVideoPipeline, "__call__", lambda self, **kw: real_call(self, **{"num_inference_steps": 2, **kw}))
+        mp.setattr(g.pipe, "num_inference_steps", 2)    # generate() exposes no step count: shorten for the test only
         frames = g.generate(sem, co, seed=0, output_path=str(tmp_path / "video_480p_front.mp4"))
     assert len(frames) == GRID.num_frames and frames[0].size == (GRID.width, GRID.height) and frames[0].mode == "RGB"
     assert saved == {"n": GRID.num_frames, "p": str(tmp_path / "video_480p_front.mp4"), "fps": 10, "q": 8}
