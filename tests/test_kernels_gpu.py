@@ -347,7 +347,29 @@ def test_attention4_variants(hip_ops, variant):
         hip_ops.lib.icv_set_option(b"attn4_variant", 4)
 
 
-@pytest.mark.parametrize("kernel", [2, 3, 4])
+def test_attention5(hip_ops):
+    """attn5.hip: one wave per SIMD, asm PV MFMAs with AGPR accumulators, asm LDS-DMA ring."""
+    H = 2
+    d = H * 128
+    hip_ops.lib.icv_set_option(b"attn_kernel", 5)
+    try:
+        for Sq, Skv in ((300, 1100), (64, 64), (257, 65), (33, 129), (513, 640), (1000, 3000), (40, 1), (256, 128), (256, 192)):
+            q, k, v = (rnd((Sq, d), 401).to(torch.bfloat16), rnd((Skv, d), 402).to(torch.bfloat16), rnd((Skv, d), 403).to(torch.bfloat16))
+            k[Skv - 1] = q[3] * 5.0
+            k[Skv // 2] = q[min(40, Sq - 1)] * 5.0
+            ref = R.attention(q.float(), k.float(), v.float(), H)
+            outs = []
+            for _ in range(3):
+                o = torch.zeros((Sq, d), dtype=torch.bfloat16, device=DEV)
+                hip_ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), o, H, 1.0 / math.sqrt(128))
+                outs.append(o)
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "non-deterministic output (hazard / DMA race?)"
+            assert_bf16_close(outs[0], ref, f"attn5 Sq={Sq} Skv={Skv}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
+    finally:
+        hip_ops.lib.icv_set_option(b"attn_kernel", 2)
+
+
+@pytest.mark.parametrize("kernel", [2, 3, 4, 5])
 @pytest.mark.parametrize("chunks", [[700], [128, 572], [300, 100, 300], [64, 64, 64, 508]])
 def test_attention_chunked_state(hip_ops, chunks, kernel):
     """Splitting the KEY axis over several launches with carried (O, m, l) state must reproduce the
@@ -448,7 +470,7 @@ def test_error_reporting(hip_ops):
 # ---------------------------------------------------------------------------------------------------
 # edge cases: minimum / ragged sizes through every kernel family (tails, clamps, masks)
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("kernel", [1, 2, 3, 4])
+@pytest.mark.parametrize("kernel", [1, 2, 3, 4, 5])
 def test_attention_minimum_sizes(hip_ops, kernel):
     hip_ops.lib.icv_set_option(b"attn_kernel", kernel)
     try:

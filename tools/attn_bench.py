@@ -39,7 +39,9 @@ for name, Sq, Skv, H in cases:
     for rd in range(rounds):           # interleaved rounds: within-process A/B
         for vv in variants:
             # variant codes: <100 -> attn.hip variant; 1000+x -> attn2.hip variant x
-            if vv >= 4000:
+            if vv >= 5000:
+                ops.lib.icv_set_option(b"attn_kernel", 5)
+            elif vv >= 4000:
                 ops.lib.icv_set_option(b"attn_kernel", 4); ops.lib.icv_set_option(b"attn4_variant", vv - 4000)
             elif vv >= 3000:
                 ops.lib.icv_set_option(b"attn_kernel", 3); ops.lib.icv_set_option(b"attn3_variant", vv - 3000)

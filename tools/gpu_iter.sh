@@ -1,2 +1,3 @@
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_dit_gpu.py -q -k "generator_end or forward_parity" 2>&1 | tail -2
+timeout 600 python -m pytest tests/test_kernels_gpu.py -q -k "attention5 or chunked or minimum" 2>&1 | grep -E "passed|failed|outside|rms err|Error|determin" | head
+ATTN_VARIANTS=1004,5000 ATTN_ROUNDS=3 ATTN_ITERS=2 python tools/attn_bench.py 2>&1 | grep -v amdgpu.ids
