@@ -94,6 +94,14 @@ int icv_attention_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, co
                       int64_t ldv, void* o, int64_t ldo, int64_t Sq, int64_t Skv, int64_t heads,
                       float scale, void* stream);
 
+/* ---- K9, i2v branch: same as icv_attention_fwd but o += softmax(q k^T * scale) v (bf16 read-add-
+ * write).  Wan2.1 i2v sums the cross-attention over the 257 CLIP image tokens with the one over the
+ * text tokens (BASELINE.json config #5; [R infinicube/videogen/download_checkpoint.py:24-29] lists
+ * the I2V-14B DiT and its CLIP encoder). */
+int icv_attention_fwd_add(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
+                          int64_t ldv, void* o, int64_t ldo, int64_t Sq, int64_t Skv, int64_t heads,
+                          float scale, void* stream);
+
 /* ---- K6 split along the KEY axis (K13 overlap): attention over one chunk of keys with a carried
  * online-softmax state, so the sequence-parallel path can consume K/V chunks as the RCCL all-gather
  * delivers them.  State = acc f32 [Sq, H*128] (ldacc; un-normalised O) + ml f32 [Sq, H, 2] (running

@@ -374,3 +374,13 @@ extern "C" int icv_attention_fwd(const void* q, int64_t ldq, const void* k, int6
   }
   return icv_check_launch("icv_attention_fwd");
 }
+
+extern "C" int icv_attention_fwd_add(const void* q, int64_t ldq, const void* k, int64_t ldk,
+                                     const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
+                                     int64_t Skv, int64_t heads, float scale, void* stream) {
+  ICV_REQUIRE(q && k && v && o, "icv_attention_fwd_add: null pointer");
+  ICV_REQUIRE(Sq > 0 && Skv > 0 && heads > 0, "icv_attention_fwd_add: empty problem (Sq=%lld Skv=%lld heads=%lld)", (long long)Sq, (long long)Skv, (long long)heads);
+  ICV_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "icv_attention_fwd_add: leading dims must keep 16-byte row alignment");
+  return icv_attn2_dispatch(q, ldq, k, ldk, v, ldv, o, ldo, nullptr, 0, nullptr, 0, 2, Sq, Skv, heads, scale,
+                            icv_get_option_int("attn2_variant", 4), (hipStream_t)stream);
+}

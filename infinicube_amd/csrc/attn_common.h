@@ -21,7 +21,7 @@ struct Params {
   float* ml;                   // carried (m, l) per (row, head): f32 [Sq, heads, 2]
   int64_t Sq, Skv;
   int heads, nqb;
-  int state_in, state_out;
+  int state_in, state_out;   // state_out: 0 = normalise + store bf16, 1 = write the carried state, 2 = normalise + ADD into bf16 o
   float sc;   // scale * log2(e)
   float thr;  // defer-max threshold, log2 units
 };
@@ -89,7 +89,7 @@ __device__ __forceinline__ void store_result(const Params& p, int64_t qr, int he
                                              float m_run, float l_run) {
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (qr >= p.Sq) return;
-  if (p.state_out) {
+  if (p.state_out == 1) {
     float* ap = p.acc + qr * p.ldacc + (int64_t)head * D + 4 * hi;
 #pragma unroll
     for (int d0 = 0; d0 < 4; ++d0)
@@ -105,8 +105,13 @@ __device__ __forceinline__ void store_result(const Params& p, int64_t qr, int he
     for (int d0 = 0; d0 < 4; ++d0)
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        const float a = ot[d0][rr * 4 + 0] * inv, b = ot[d0][rr * 4 + 1] * inv;
-        const float c = ot[d0][rr * 4 + 2] * inv, d = ot[d0][rr * 4 + 3] * inv;
+        float a = ot[d0][rr * 4 + 0] * inv, b = ot[d0][rr * 4 + 1] * inv;
+        float c = ot[d0][rr * 4 + 2] * inv, d = ot[d0][rr * 4 + 3] * inv;
+        if (p.state_out == 2) {   // o += result (i2v: image cross-attention summed with the text one)
+          const uint2 prev = *reinterpret_cast<const uint2*>(op + d0 * 32 + rr * 8);
+          a += __uint_as_float(prev.x << 16); b += __uint_as_float(prev.x & 0xFFFF0000u);
+          c += __uint_as_float(prev.y << 16); d += __uint_as_float(prev.y & 0xFFFF0000u);
+        }
         *reinterpret_cast<uint2*>(op + d0 * 32 + rr * 8) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
       }
   }

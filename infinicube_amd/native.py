@@ -34,6 +34,7 @@ SIGNATURES = {
     "icv_ln_modulate": (c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "icv_rmsnorm_rope": (c_int, [_P, _P, _P, _P, _I, _I, _I, _F, _P, _I, _I, _I, _I, _P]),
     "icv_attention_fwd": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _F, _P]),
+    "icv_attention_fwd_add": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _F, _P]),
     "icv_attention_fwd_chunk": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _F, c_int, c_int, _P]),
     "icv_patchify": (c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
     "icv_unpatchify_cfg_euler": (c_int, [_P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _I, _I, _P]),

@@ -29,6 +29,19 @@ class WanDiTConfig:
     eps: float = 1e-6
     patch: Tuple[int, int, int] = (1, 2, 2)
     buffer_channels: int = 16  # per guidance buffer (semantic, coordinate) after VAE encode
+    # image-to-video branch (BASELINE.json config #5; [EXT] Wan2.1 i2v): in_dim = 16 noise + 4 mask + 16
+    # first-frame latent channels, and a second cross-attention over img_len CLIP tokens of width img_dim
+    img_dim: int = 0           # 0 = text-to-video (no image branch); 1280 for Wan2.1-I2V (CLIP ViT-H/14)
+    img_len: int = 257
+
+    @property
+    def has_image_input(self) -> bool:
+        return self.img_dim > 0
+
+    @property
+    def cond_channels(self) -> int:
+        """Channels of the step-invariant conditioning latent y concatenated under the noise (i2v: 20)."""
+        return self.in_dim - self.out_dim
 
     @property
     def head_dim(self) -> int:
@@ -43,6 +56,8 @@ class WanDiTConfig:
             raise ValueError(f"head_dim must be {HEAD_DIM}, got dim={self.dim} heads={self.num_heads}")
         if self.dim % 64 or self.ffn_dim % 64:
             raise ValueError("dim and ffn_dim must be multiples of 64")
+        if self.in_dim < self.out_dim:
+            raise ValueError(f"in_dim {self.in_dim} < out_dim {self.out_dim}")
         return self
 
 
@@ -54,7 +69,11 @@ WAN_TINY = WanDiTConfig("wan-tiny", dim=256, ffn_dim=512, num_heads=2, num_layer
 WAN_SMALL = WanDiTConfig("wan-small", dim=512, ffn_dim=1408, num_heads=4, num_layers=3,
                          text_dim=256, text_len=64)
 
-PRESETS = {"1.3b": WAN_1_3B, "14b": WAN_14B, "tiny": WAN_TINY, "small": WAN_SMALL}
+WAN_14B_I2V = replace(WAN_14B, name="wan2.1-i2v-14b", in_dim=36, img_dim=1280)
+WAN_TINY_I2V = replace(WAN_TINY, name="wan-tiny-i2v", in_dim=36, img_dim=64, img_len=257)
+
+PRESETS = {"1.3b": WAN_1_3B, "14b": WAN_14B, "tiny": WAN_TINY, "small": WAN_SMALL,
+           "14b-i2v": WAN_14B_I2V, "tiny-i2v": WAN_TINY_I2V}
 
 
 def preset(name: str, **overrides) -> WanDiTConfig:
@@ -72,12 +91,15 @@ def infer_config_from_state_dict(sd) -> WanDiTConfig:
     text_dim = int(sd["text_embedding.0.weight"].shape[1])
     freq_dim = int(sd["time_embedding.0.weight"].shape[1])
     out_dim = int(sd["head.head.weight"].shape[0]) // 4
+    img_dim = int(sd["img_emb.proj.1.weight"].shape[1]) if "img_emb.proj.1.weight" in sd else 0
     for c in (WAN_1_3B, WAN_14B):
         if (c.dim, c.ffn_dim, c.num_layers) == (dim, ffn, layers):
-            return replace(c, in_dim=in_dim, out_dim=out_dim, text_dim=text_dim, freq_dim=freq_dim)
+            name = c.name.replace("t2v", "i2v") if img_dim else c.name
+            return replace(c, name=name, in_dim=in_dim, out_dim=out_dim, text_dim=text_dim, freq_dim=freq_dim,
+                           img_dim=img_dim)
     return WanDiTConfig(f"wan-d{dim}-l{layers}", dim=dim, ffn_dim=ffn, num_heads=dim // HEAD_DIM,
                         num_layers=layers, in_dim=in_dim, out_dim=out_dim, text_dim=text_dim,
-                        freq_dim=freq_dim).validate()
+                        freq_dim=freq_dim, img_dim=img_dim).validate()
 
 
 @dataclass(frozen=True)
@@ -131,5 +153,8 @@ GRID_720P = TokenGrid(93, 720, 1280)
 def dit_forward_flops(cfg: WanDiTConfig, S: int) -> float:
     """Algorithmic FLOPs of one DiT forward (BASELINE.md §2 / SURVEY.md §8d formula)."""
     d, f, L, Tx = cfg.dim, cfg.ffn_dim, cfg.num_layers, cfg.text_len
-    return float(L) * (8.0 * S * d * d + 4.0 * S * S * d + 4.0 * S * d * d
-                       + 4.0 * Tx * d * d + 4.0 * S * Tx * d + 4.0 * S * d * f)
+    per_layer = (8.0 * S * d * d + 4.0 * S * S * d + 4.0 * S * d * d
+                 + 4.0 * Tx * d * d + 4.0 * S * Tx * d + 4.0 * S * d * f)
+    if cfg.has_image_input:   # i2v: K/V projection of and attention over the CLIP tokens
+        per_layer += 4.0 * cfg.img_len * d * d + 4.0 * S * cfg.img_len * d
+    return float(L) * per_layer

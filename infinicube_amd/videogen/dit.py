@@ -18,6 +18,10 @@ HBM layout, the step-invariant caches and the sequence-parallel schedule:
     weights  bf16 [N, K]        torch Linear layout == the K-contiguous B operand of the MFMA GEMM
   Step-invariant caches: guidance-buffer tokens f32 [n, d] (once per generation; K1), text
   embedding + per-layer cross-attention K/V bf16 [L, text_len, d] per CFG branch (K9), RoPE tables.
+  i2v (BASELINE.json config #5, [EXT] Wan2.1 i2v): the conditioning latent y (4 mask + 16 first-frame
+  channels) is step-invariant and the patch embedding is linear, so its tokens W[:,16:]·patch(y) are
+  computed ONCE and folded into the cached buffer tokens — the per-step patch GEMM stays 16-channel;
+  the CLIP tokens give a second cached K/V set [L, 257, d] whose attention is summed onto the text one.
 """
 
 from __future__ import annotations
@@ -41,6 +45,8 @@ class ContextKV:
     """Cross-attention keys/values of one prompt for all layers (step-invariant)."""
     k: torch.Tensor  # bf16 [L, text_len, d]
     v: torch.Tensor  # bf16 [L, text_len, d]
+    k_img: Optional[torch.Tensor] = None  # i2v: bf16 [L, img_len, d]
+    v_img: Optional[torch.Tensor] = None
 
 
 class WanDiT:
@@ -54,9 +60,20 @@ class WanDiT:
         V = lambda name: ops.to_device(sd[name], F32)    # noqa: E731  vectors: fp32
 
         kp = cfg.in_dim * cfg.patch_elems
-        self.k_patch = ((kp + 63) // 64) * 64            # GEMM K granularity (i2v in_dim=36 -> 144 -> 192)
-        self.patch_w = self._pad_k(W("patch_embedding.weight").reshape(d, kp), self.k_patch)
+        kx = cfg.out_dim * cfg.patch_elems               # columns of the noise channels (c-major: c*4 + y*2 + z)
+        pw = W("patch_embedding.weight").reshape(d, kp)
+        self.k_patch = ((kx + 63) // 64) * 64            # GEMM K granularity
+        self.patch_w = self._pad_k(pw[:, :kx], self.k_patch)
         self.patch_b = V("patch_embedding.bias")
+        self.cond_w = None
+        if kp > kx:                                      # i2v: columns of the step-invariant y channels
+            self.k_cond = ((kp - kx + 63) // 64) * 64
+            self.cond_w = self._pad_k(pw[:, kx:], self.k_cond)
+        if cfg.has_image_input:
+            self.img_ln0 = (V("img_emb.proj.0.weight"), V("img_emb.proj.0.bias"))
+            self.img1_w, self.img1_b = W("img_emb.proj.1.weight"), V("img_emb.proj.1.bias")
+            self.img3_w, self.img3_b = W("img_emb.proj.3.weight"), V("img_emb.proj.3.bias")
+            self.img_ln4 = (V("img_emb.proj.4.weight"), V("img_emb.proj.4.bias"))
         self.text0_w, self.text0_b = W("text_embedding.0.weight"), V("text_embedding.0.bias")
         self.text2_w, self.text2_b = W("text_embedding.2.weight"), V("text_embedding.2.bias")
         self.time0_w, self.time0_b = W("time_embedding.0.weight"), V("time_embedding.0.bias")
@@ -83,6 +100,10 @@ class WanDiT:
                 f0_w=W(f"{p}.ffn.0.weight"), f0_b=V(f"{p}.ffn.0.bias"),
                 f2_w=W(f"{p}.ffn.2.weight"), f2_b=V(f"{p}.ffn.2.bias"),
             )
+            if cfg.has_image_input:
+                lw["xkv_img_w"] = torch.cat([W(f"{ca}.k_img.weight"), W(f"{ca}.v_img.weight")], 0).contiguous()
+                lw["xkv_img_b"] = torch.cat([V(f"{ca}.k_img.bias"), V(f"{ca}.v_img.bias")], 0).contiguous()
+                lw["xnk_img"] = V(f"{ca}.norm_k_img.weight")
             self.layers.append(lw)
             mods.append(V(f"{p}.modulation").reshape(6 * d))
         self.modulation = torch.stack(mods, 0).contiguous()  # f32 [L, 6d]
@@ -180,9 +201,12 @@ class WanDiT:
                                 first=(c == 0), last=(c == C - 1))
 
     # ------------------------------------------------------------------------------------
-    def encode_context(self, context: torch.Tensor) -> ContextKV:
-        """text_embedding MLP + every layer's cross-attention K (RMS-normed) and V; once per prompt."""
+    def encode_context(self, context: torch.Tensor, clip_fea: Optional[torch.Tensor] = None) -> ContextKV:
+        """text_embedding MLP + every layer's cross-attention K (RMS-normed) and V; once per prompt.
+        i2v: ``clip_fea`` [img_len, img_dim] additionally yields the image K/V set."""
         cfg, ops = self.cfg, self.ops
+        if cfg.has_image_input != (clip_fea is not None):
+            raise ValueError("clip_fea must be given exactly when the DiT has the image branch (i2v)")
         d, L = cfg.dim, cfg.num_layers
         ctx = ops.to_device(context, BF16)
         n = ctx.shape[0]
@@ -194,7 +218,50 @@ class WanDiT:
         for i, lw in enumerate(self.layers):
             ops.gemm(emb, lw["xkv_w"], lw["xkv_b"], kv[i], EPI_BF16, nsplit=d)
             ops.rmsnorm_rope(kv[i, 0], lw["xnk"], eps=cfg.eps)
-        return ContextKV(kv[:, 0], kv[:, 1])
+        if clip_fea is None:
+            return ContextKV(kv[:, 0], kv[:, 1])
+        img = self._image_embed(clip_fea)
+        m = img.shape[0]
+        kvi = ops.alloc((L, 2, m, d), BF16)
+        for i, lw in enumerate(self.layers):
+            ops.gemm(img, lw["xkv_img_w"], lw["xkv_img_b"], kvi[i], EPI_BF16, nsplit=d)
+            ops.rmsnorm_rope(kvi[i, 0], lw["xnk_img"], eps=cfg.eps)
+        return ContextKV(kv[:, 0], kv[:, 1], kvi[:, 0], kvi[:, 1])
+
+    def _image_embed(self, clip_fea: torch.Tensor) -> torch.Tensor:
+        """img_emb ([EXT] Wan2.1 MLPProj): LayerNorm, Linear, GELU(erf), Linear, LayerNorm -> bf16 [img_len, d].
+        Once per generation on 257 rows: the two GEMMs run in libicvideo, the two LayerNorms (torch eps 1e-5)
+        and the erf-GELU are stock device-side torch ops like the encoders outside the loop."""
+        import torch.nn.functional as F
+        cfg, ops = self.cfg, self.ops
+        x = ops.to_device(clip_fea, F32)
+        if tuple(x.shape) != (cfg.img_len, cfg.img_dim):
+            raise ValueError(f"clip_fea shape {tuple(x.shape)} != {(cfg.img_len, cfg.img_dim)}")
+        h = F.layer_norm(x, (cfg.img_dim,), self.img_ln0[0], self.img_ln0[1], 1e-5).to(BF16)
+        t1 = ops.alloc((cfg.img_len, cfg.img_dim), F32)
+        ops.gemm(h, self.img1_w, self.img1_b, t1, EPI_F32)
+        t2 = ops.alloc((cfg.img_len, cfg.dim), F32)
+        ops.gemm(F.gelu(t1).to(BF16), self.img3_w, self.img3_b, t2, EPI_F32)
+        return F.layer_norm(t2, (cfg.dim,), self.img_ln4[0], self.img_ln4[1], 1e-5).to(BF16)
+
+    def embed_cond_latents(self, y: torch.Tensor, add_to: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """i2v: tokens of the step-invariant conditioning latent y [in_dim-16, T, H8, W8] under the y columns
+        of the patch embedding (no bias — that stays in the per-step GEMM), f32 [n, d]; ``add_to`` (e.g. the
+        guidance-buffer tokens) is accumulated so the result is the one cached additive term of K1."""
+        if self.cond_w is None:
+            raise RuntimeError("this DiT has no conditioning-latent channels (in_dim == out_dim)")
+        ops, plan, cfg = self.ops, self.plan, self.cfg
+        yl = ops.to_device(y, F32).contiguous()
+        if yl.shape[0] != cfg.cond_channels:
+            raise ValueError(f"conditioning latent has {yl.shape[0]} channels, expected {cfg.cond_channels}")
+        pt = torch.zeros((plan.n_tok, self.k_cond), dtype=BF16, device=ops.device)
+        ops.patchify(yl, pt, plan.tok0, plan.n_tok)
+        out = ops.alloc((plan.n_tok, cfg.dim), F32)
+        if add_to is None:
+            ops.gemm(pt, self.cond_w, None, out, EPI_F32)
+        else:
+            ops.gemm(pt, self.cond_w, None, out, EPI_RESID_F32, resid=add_to)
+        return out
 
     def embed_buffers(self, buffer_latents: torch.Tensor) -> torch.Tensor:
         """Guidance-buffer tokens f32 [n, d] for this shard (step-invariant)."""
@@ -239,6 +306,10 @@ class WanDiT:
         cfg, ops, plan = self.cfg, self.ops, self.plan
         d, H, n, eps = cfg.dim, cfg.num_heads, plan.n_tok, cfg.eps
         scale = 1.0 / math.sqrt(cfg.head_dim)
+        if (self.cond_w is not None) and buf_tokens is None:
+            raise ValueError("i2v DiT: pass the cached embed_cond_latents(y) tokens as buf_tokens")
+        if cfg.has_image_input != (ctx.k_img is not None):
+            raise ValueError("context was encoded without/with CLIP features but the DiT is/isn't i2v")
         self._time_state(timestep)
         # K1: patch embed (+ cached guidance-buffer tokens fused into the GEMM epilogue)
         ops.patchify(latent, self.patches, plan.tok0, n)
@@ -273,6 +344,8 @@ class WanDiT:
             ops.gemm(self.h, lw["xq_w"], lw["xq_b"], q, EPI_BF16)                           # K9
             ops.rmsnorm_rope(q, lw["xnq"], eps=eps)
             ops.attention(q, ctx.k[i], ctx.v[i], self.att, H, scale)
+            if ctx.k_img is not None:                                                      # i2v: + softmax over CLIP tokens
+                ops.attention_add(q, ctx.k_img[i], ctx.v_img[i], self.att, H, scale)
             ops.gemm(self.att, lw["xo_w"], lw["xo_b"], self.x, EPI_RESID_F32, resid=self.x)
             # --- FFN ---
             ops.ln_modulate(self.x, self.h, shift=sh2, scale=sc2, eps=eps)                  # K3

@@ -153,6 +153,15 @@ class HipOps:
             o.data_ptr(), o.stride(0), q.shape[0], k.shape[0], heads, scale, self._stream()),
             "icv_attention_fwd")
 
+    def attention_add(self, q, k, v, o, heads: int, scale: float):
+        """o += softmax(q k^T * scale) v  (i2v image cross-attention summed onto the text one)."""
+        for t, nm in ((q, "q"), (k, "k"), (v, "v"), (o, "o")):
+            _chk(t, BF16, f"attention_add.{nm}")
+        native.check(self.lib.icv_attention_fwd_add(
+            q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
+            o.data_ptr(), o.stride(0), q.shape[0], k.shape[0], heads, scale, self._stream()),
+            "icv_attention_fwd_add")
+
     def attention_chunk(self, q, k, v, o, acc, ml, heads: int, scale: float, first: bool, last: bool):
         """Attention over one chunk of keys with carried softmax state (acc f32 [Sq, H*128], ml f32
         [Sq, H, 2]); ``first`` starts from the empty state, ``last`` normalises into ``o``."""

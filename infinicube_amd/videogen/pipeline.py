@@ -155,8 +155,9 @@ def _tensor_to_video(video: torch.Tensor) -> List[Image.Image]:
 
 class WanVideoPipeline:
     def __init__(self, device="cuda:0", torch_dtype=torch.bfloat16, dit: Optional[DiTHolder] = None,
-                 text_encoder=None, vae=None, ops=None):
+                 text_encoder=None, vae=None, ops=None, image_encoder=None):
         self.device = device
+        self.image_encoder = image_encoder   # i2v only (CLIP ViT-H/14 tokens of the conditioning image)
         self.torch_dtype = torch_dtype
         self.dit = dit
         self.text_encoder = text_encoder
@@ -181,7 +182,10 @@ class WanVideoPipeline:
         for mc in model_configs:
             pattern = mc.resolve()
             base = os.path.basename(pattern)
-            if "t5" in base.lower():
+            if "clip" in base.lower():
+                from .clip_vision import load_clip_vision
+                pipe.image_encoder = load_clip_vision(pattern, device, torch_dtype)
+            elif "t5" in base.lower():
                 from .text_encoder import load_umt5_encoder
                 pipe.text_encoder = load_umt5_encoder(pattern, device, torch_dtype, tokenizer_config)
             elif "vae" in base.lower():
@@ -225,6 +229,19 @@ class WanVideoPipeline:
             self._engine_key = key
         return self._engine
 
+    def _image_cond_latents(self, image, grid: TokenGrid, tiled, tile_size, tile_stride) -> torch.Tensor:
+        """i2v conditioning latent y [4 + 16, T, H/8, W/8] ([EXT] Wan2.1 / diffsynth ``encode_image``): the
+        VAE encoding of [image, 0, 0, ...] under a 4-channel mask that marks the first latent frame."""
+        h, w, f = grid.height, grid.width, grid.num_frames
+        img = _video_to_tensor([image], h, w)                                   # [3, 1, H, W] in [-1, 1]
+        video = torch.cat([img, torch.zeros((3, f - 1, h, w), dtype=img.dtype)], dim=1)
+        lat = self.vae.encode(video, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride).to(torch.float32).cpu()
+        msk = torch.zeros((1, f, h // 8, w // 8))
+        msk[:, 0] = 1.0
+        msk = torch.cat([msk[:, :1].repeat_interleave(4, dim=1), msk[:, 1:]], dim=1)   # [1, 4T, h8, w8]
+        msk = msk.reshape(grid.T, 4, h // 8, w // 8).transpose(0, 1)                    # [4, T, h8, w8]
+        return torch.cat([msk, lat], dim=0)
+
     # ---- D5: the generation call -----------------------------------------------------------
     @torch.no_grad()
     def __call__(self, prompt: str, negative_prompt: str = "", semantic_buffer_video=None,
@@ -232,7 +249,7 @@ class WanVideoPipeline:
                  seed: Optional[int] = None, tiled: bool = True, num_inference_steps: Optional[int] = None,
                  cfg_scale: Optional[float] = None, sigma_shift: Optional[float] = None, rand_device: str = "cpu",
                  tile_size=(30, 52), tile_stride=(15, 26), progress_bar_cmd=None, return_latents: bool = False,
-                 **unused):
+                 input_image=None, **unused):
         if self.text_encoder is None or self.vae is None:
             raise RuntimeError("WanVideoPipeline: text encoder / VAE not loaded")
         num_inference_steps = self.num_inference_steps if num_inference_steps is None else num_inference_steps
@@ -251,9 +268,18 @@ class WanVideoPipeline:
         plan = ShardPlan.make(grid.S, world, rank)
         engine.prepare(grid, plan)
         self.scheduler = FlowMatchScheduler(num_inference_steps, sigma_shift)
+        # i2v (BASELINE.json config #5): CLIP tokens + conditioning latent of the first frame, once per call
+        i2v = engine.cfg.has_image_input
+        clip_fea = None
+        if i2v:
+            if input_image is None or self.image_encoder is None:
+                raise ValueError("this DiT is image-to-video: pass input_image= and load a CLIP image encoder")
+            clip_fea = self.image_encoder.encode_image(input_image)
+        elif input_image is not None:
+            raise ValueError("input_image given but the loaded DiT is text-to-video")
         # text (cond / uncond), once per prompt
-        ctx_c = engine.encode_context(self.text_encoder.encode(prompt))
-        ctx_u = engine.encode_context(self.text_encoder.encode(negative_prompt)) if cfg_scale != 1.0 else None
+        ctx_c = engine.encode_context(self.text_encoder.encode(prompt), clip_fea)
+        ctx_u = engine.encode_context(self.text_encoder.encode(negative_prompt), clip_fea) if cfg_scale != 1.0 else None
         # noise: CPU generator, fp32 (rand_device='cpu' upstream) -> identical across devices/ranks
         g = torch.Generator(device="cpu")
         if seed is not None:
@@ -270,6 +296,9 @@ class WanVideoPipeline:
                 lats.append(self.vae.encode(_video_to_tensor(vid, height, width), tiled=tiled,
                                             tile_size=tile_size, tile_stride=tile_stride).to(torch.float32))
             buf_tokens = engine.embed_buffers(torch.cat(lats, dim=0))
+        if i2v:
+            y = self._image_cond_latents(input_image, grid, tiled, tile_size, tile_stride)
+            buf_tokens = engine.embed_cond_latents(y, add_to=buf_tokens)
         # the hot loop (HIP)
         it = range(num_inference_steps)
         if progress_bar_cmd is not None:

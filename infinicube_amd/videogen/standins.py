@@ -1,4 +1,4 @@
-"""Deterministic stand-ins for the two components OUTSIDE the hot loop (UMT5 text encoder, Wan-VAE)
+"""Deterministic stand-ins for the components OUTSIDE the hot loop (UMT5 text encoder, Wan-VAE, CLIP image tower)
 so the full ``generate()`` path can be exercised without the 11 GB / 0.5 GB checkpoints (none exist
 offline).  They have the real components' interfaces and tensor geometry (4x temporal / 8x spatial
 compression, 16 latent channels, [text_len, text_dim] context) and no learned meaning.  Used by the
@@ -29,6 +29,18 @@ class HashTextEncoder:
         out = torch.zeros((self.text_len, self.text_dim), dtype=torch.float32)
         out[:n_tok] = torch.randn((n_tok, self.text_dim), generator=g) * 0.1
         return out
+
+
+class HashImageEncoder:
+    """PIL image -> seeded pseudo CLIP tokens [img_len, img_dim] (i2v branch), a function of the pixels."""
+
+    def __init__(self, cfg: WanDiTConfig):
+        self.img_len, self.img_dim = cfg.img_len, cfg.img_dim
+
+    def encode_image(self, image) -> torch.Tensor:
+        seed = int.from_bytes(hashlib.sha256(image.convert("RGB").tobytes()).digest()[:4], "little")
+        g = torch.Generator().manual_seed(seed)
+        return torch.randn((self.img_len, self.img_dim), generator=g)
 
 
 class PoolVAE:

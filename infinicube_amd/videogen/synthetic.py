@@ -54,6 +54,11 @@ def make_dit_state_dict(cfg: WanDiTConfig, seed: int = 0, device="cpu",
     lin("time_embedding.0", d, cfg.freq_dim)
     lin("time_embedding.2", d, d)
     lin("time_projection.1", 6 * d, d)
+    if cfg.has_image_input:      # img_emb = LayerNorm, Linear, GELU, Linear, LayerNorm ([EXT] Wan2.1 MLPProj)
+        affine("img_emb.proj.0", cfg.img_dim, with_bias=True)
+        lin("img_emb.proj.1", cfg.img_dim, cfg.img_dim)
+        lin("img_emb.proj.3", d, cfg.img_dim)
+        affine("img_emb.proj.4", d, with_bias=True)
     for i in range(cfg.num_layers):
         p = f"blocks.{i}"
         for attn in ("self_attn", "cross_attn"):
@@ -61,6 +66,10 @@ def make_dit_state_dict(cfg: WanDiTConfig, seed: int = 0, device="cpu",
                 lin(f"{p}.{attn}.{proj}", d, d)
             affine(f"{p}.{attn}.norm_q", d)
             affine(f"{p}.{attn}.norm_k", d)
+        if cfg.has_image_input:
+            lin(f"{p}.cross_attn.k_img", d, d)
+            lin(f"{p}.cross_attn.v_img", d, d)
+            affine(f"{p}.cross_attn.norm_k_img", d)
         affine(f"{p}.norm3", d, with_bias=True)
         lin(f"{p}.ffn.0", f, d)
         lin(f"{p}.ffn.2", d, f)
@@ -103,6 +112,23 @@ def make_latent_noise(grid: TokenGrid, seed: int = 0, channels: int = 16) -> tor
 def make_text_context(cfg: WanDiTConfig, seed: int) -> torch.Tensor:
     g = torch.Generator(device="cpu").manual_seed(seed)
     return torch.randn((cfg.text_len, cfg.text_dim), generator=g, dtype=torch.float32) * 0.1
+
+
+def make_clip_features(cfg: WanDiTConfig, seed: int = 5) -> torch.Tensor:
+    """Stand-in for the CLIP ViT-H/14 penultimate-layer tokens of the conditioning image [img_len, img_dim]."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randn((cfg.img_len, cfg.img_dim), generator=g, dtype=torch.float32)
+
+
+def make_cond_latents(cfg: WanDiTConfig, grid: TokenGrid, seed: int = 6) -> torch.Tensor:
+    """Stand-in for the i2v conditioning latent y [in_dim - 16, T, H/8, W/8]: 4 mask channels (first latent
+    frame = 1, rest 0) over the VAE encoding of [image, zeros...]."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    c = cfg.cond_channels
+    y = torch.randn(grid.latent_shape(c), generator=g, dtype=torch.float32)
+    y[:4] = 0.0
+    y[:4, 0] = 1.0
+    return y
 
 
 def make_buffer_latents(cfg: WanDiTConfig, grid: TokenGrid, seed: int = 3) -> torch.Tensor:

@@ -58,6 +58,16 @@ def text_embed(sd: Dict[str, Tensor], context: Tensor, dtype=torch.float32) -> T
     return F.linear(h, sd["text_embedding.2.weight"].to(dtype), sd["text_embedding.2.bias"].to(dtype))
 
 
+def image_embed(sd: Dict[str, Tensor], clip_fea: Tensor, dtype=torch.float32) -> Tensor:
+    """i2v ([EXT] Wan2.1 MLPProj): LayerNorm -> Linear -> GELU (erf) -> Linear -> LayerNorm on the CLIP
+    tokens [img_len, img_dim] -> [img_len, d]; LayerNorm eps is torch's default 1e-5."""
+    g = lambda n: sd[f"img_emb.proj.{n}"].to(dtype)   # noqa: E731
+    h = F.layer_norm(clip_fea.to(dtype), (clip_fea.shape[-1],), g("0.weight"), g("0.bias"), 1e-5)
+    h = F.gelu(F.linear(h, g("1.weight"), g("1.bias")))
+    h = F.linear(h, g("3.weight"), g("3.bias"))
+    return F.layer_norm(h, (h.shape[-1],), g("4.weight"), g("4.bias"), 1e-5)
+
+
 # --------------------------------------------------------------------------------------------
 # A.3 RoPE-3D
 # --------------------------------------------------------------------------------------------
@@ -122,7 +132,7 @@ def _lin(sd, name, x, dtype):
 
 
 def dit_block(sd: Dict[str, Tensor], cfg, i: int, x: Tensor, ctx: Tensor, t_mod: Tensor,
-              freqs: Tensor, dtype=torch.float32, kv_override=None) -> Tensor:
+              freqs: Tensor, dtype=torch.float32, kv_override=None, ctx_img: Optional[Tensor] = None) -> Tensor:
     p = f"blocks.{i}"
     mod = sd[f"{p}.modulation"].to(dtype).reshape(6, cfg.dim) + t_mod
     sh1, sc1, g1, sh2, sc2, g2 = mod.unbind(0)
@@ -140,7 +150,11 @@ def dit_block(sd: Dict[str, Tensor], cfg, i: int, x: Tensor, ctx: Tensor, t_mod:
     q = rms_norm(_lin(sd, f"{p}.cross_attn.q", h, dtype), sd[f"{p}.cross_attn.norm_q.weight"].to(dtype), eps)
     k = rms_norm(_lin(sd, f"{p}.cross_attn.k", ctx, dtype), sd[f"{p}.cross_attn.norm_k.weight"].to(dtype), eps)
     v = _lin(sd, f"{p}.cross_attn.v", ctx, dtype)
-    x = x + _lin(sd, f"{p}.cross_attn.o", attention(q, k, v, H), dtype)
+    a = attention(q, k, v, H)
+    if ctx_img is not None:   # i2v: a second softmax over the CLIP tokens, outputs summed before o
+        k_img = rms_norm(_lin(sd, f"{p}.cross_attn.k_img", ctx_img, dtype), sd[f"{p}.cross_attn.norm_k_img.weight"].to(dtype), eps)
+        a = a + attention(q, k_img, _lin(sd, f"{p}.cross_attn.v_img", ctx_img, dtype), H)
+    x = x + _lin(sd, f"{p}.cross_attn.o", a, dtype)
     # FFN
     h = modulate(layer_norm(x, None, None, eps), sh2, sc2)
     h = F.gelu(_lin(sd, f"{p}.ffn.0", h, dtype), approximate="tanh")
@@ -182,9 +196,14 @@ def head(sd: Dict[str, Tensor], cfg, x: Tensor, t: Tensor, dtype=torch.float32) 
 
 def dit_forward(sd: Dict[str, Tensor], cfg, latent: Tensor, context: Tensor, timestep: float,
                 buf_tokens: Optional[Tensor] = None, dtype=torch.float32,
-                num_layers: Optional[int] = None, return_tokens: bool = False) -> Tensor:
+                num_layers: Optional[int] = None, return_tokens: bool = False,
+                clip_fea: Optional[Tensor] = None, y: Optional[Tensor] = None) -> Tensor:
     """One DiT forward: latent [C,T,H8,W8], raw text context [text_len, text_dim] -> velocity
-    [out_dim, T, H8, W8]."""
+    [out_dim, T, H8, W8].  i2v: ``y`` [in_dim-C,T,H8,W8] is concatenated under the noise channels and
+    ``clip_fea`` [img_len, img_dim] feeds the image cross-attention."""
+    if y is not None:
+        latent = torch.cat([latent.to(dtype), y.to(dtype)], dim=0)
+    ctx_img = image_embed(sd, clip_fea, dtype) if clip_fea is not None else None
     C, T, H8, W8 = latent.shape
     grid = (T // cfg.patch[0], H8 // cfg.patch[1], W8 // cfg.patch[2])
     t, t_mod = time_embed(sd, cfg, timestep, dtype)
@@ -194,7 +213,7 @@ def dit_forward(sd: Dict[str, Tensor], cfg, latent: Tensor, context: Tensor, tim
         x = x + buf_tokens.to(dtype)
     freqs = rope_freqs_3d(cfg.head_dim, *grid)
     for i in range(cfg.num_layers if num_layers is None else num_layers):
-        x = dit_block(sd, cfg, i, x, ctx, t_mod, freqs, dtype)
+        x = dit_block(sd, cfg, i, x, ctx, t_mod, freqs, dtype, ctx_img=ctx_img)
     if return_tokens:
         return x
     return unpatchify(head(sd, cfg, x, t, dtype), grid, cfg.out_dim, cfg.patch)
@@ -210,16 +229,17 @@ def flow_match_sigmas(num_steps: int, shift: float = 5.0) -> Tensor:
 
 def denoise_loop(sd, bsd, cfg, noise: Tensor, ctx_cond: Tensor, ctx_uncond: Tensor,
                  buffer_latents: Optional[Tensor], num_steps: int = 50, cfg_scale: float = 5.0,
-                 shift: float = 5.0, dtype=torch.float32, trace: Optional[list] = None) -> Tensor:
+                 shift: float = 5.0, dtype=torch.float32, trace: Optional[list] = None,
+                 clip_fea: Optional[Tensor] = None, y: Optional[Tensor] = None) -> Tensor:
     """for sigma in sigmas: v = v_u + s (v_c - v_u); x += v (sigma_next - sigma)."""
     sig = flow_match_sigmas(num_steps, shift)
     buf = buffer_embed(bsd, buffer_latents, dtype) if buffer_latents is not None else None
     x = noise.to(dtype).clone()
     for i in range(num_steps):
         ts = float(sig[i]) * 1000.0
-        v_c = dit_forward(sd, cfg, x, ctx_cond, ts, buf, dtype)
+        v_c = dit_forward(sd, cfg, x, ctx_cond, ts, buf, dtype, clip_fea=clip_fea, y=y)
         if cfg_scale != 1.0:
-            v_u = dit_forward(sd, cfg, x, ctx_uncond, ts, buf, dtype)
+            v_u = dit_forward(sd, cfg, x, ctx_uncond, ts, buf, dtype, clip_fea=clip_fea, y=y)
             v = v_u + cfg_scale * (v_c - v_u)
         else:
             v = v_c

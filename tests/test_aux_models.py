@@ -1,6 +1,8 @@
 """Stock-PyTorch components outside the hot loop (Wan-VAE, UMT5 encoder): structural properties that
 hold for the published architectures regardless of weights.  [EXT]: no checkpoints exist offline, so
 these tests pin shapes, parameter naming, causality and masking — not learned behaviour."""
+import numpy as np
+import pytest
 import torch
 
 from infinicube_amd.videogen.text_encoder import T5RelativeEmbedding, UMT5Encoder, UMT5TextEncoder
@@ -114,3 +116,34 @@ def test_text_encoder_zero_pads_context():
     te = UMT5TextEncoder(enc, Tok(), "cpu", text_len=16)
     e = te.encode("a  driving   scene &amp; more")
     assert e.shape == (16, 32) and float(e[6:].abs().max()) == 0.0 and float(e[:6].abs().max()) > 0.0
+
+
+def test_clip_vision_tower_geometry(tmp_path):
+    """CLIP ViT vision tower (i2v conditioning, stock torch): 257 tokens for 224/14, penultimate-block output,
+    strict loading of the visual.* half of a checkpoint."""
+    from PIL import Image
+    from safetensors.torch import save_file
+    from infinicube_amd.videogen.clip_vision import ClipVisionEncoder, load_clip_vision
+    arch = dict(image_size=224, patch=14, dim=64, heads=2, layers=3, use_blocks=2)
+    torch.manual_seed(0)
+    enc = ClipVisionEncoder(**arch)
+    for p in enc.parameters():
+        torch.nn.init.normal_(p, std=0.05)
+    sd = {"visual." + k: v.contiguous() for k, v in enc.state_dict().items()}
+    sd["textual.junk"] = torch.zeros(3)
+    sd["visual.post_norm.weight"] = torch.ones(64)       # present upstream, unused by Wan
+    path = str(tmp_path / "clip.safetensors")
+    save_file(sd, path)
+    loaded = load_clip_vision(path, "cpu", torch.float32, **arch)
+    img = Image.fromarray(np.random.default_rng(1).integers(0, 255, (96, 160, 3), dtype=np.uint8), mode="RGB")
+    tok = loaded.encode_image(img)
+    assert tok.shape == (257, 64) and torch.isfinite(tok).all()
+    assert torch.allclose(tok, enc.eval().encode_image(img), atol=1e-6)
+    # the last block is NOT applied (use_blocks = layers - 1)
+    full = ClipVisionEncoder(**{**arch, "use_blocks": 3})
+    full.load_state_dict(enc.state_dict())
+    assert not torch.allclose(full.encode_image(img), tok)
+    del sd["visual.transformer.1.mlp.0.weight"]
+    save_file(sd, path)
+    with pytest.raises(KeyError, match="missing"):
+        load_clip_vision(path, "cpu", torch.float32, **arch)

@@ -74,6 +74,32 @@ def test_denoise_loop_psnr(hip_ops):
     assert torch.equal(lat, lat2)
 
 
+def test_i2v_forward_and_loop_parity(hip_ops):
+    """BASELINE.json config #5's image-conditioning branch at test size (in_dim 36, 257 CLIP tokens)."""
+    cfg, grid = preset("tiny-i2v"), TokenGrid(9, 64, 96)
+    sd, bsd = syn.make_dit_state_dict(cfg), syn.make_buffer_embedder_state_dict(cfg)
+    sdr, bsdr = R.round_state_dict_to_bf16(sd), R.round_state_dict_to_bf16(bsd)
+    noise, c1, c2 = syn.make_latent_noise(grid), syn.make_text_context(cfg, 1), syn.make_text_context(cfg, 2)
+    bl, clip, y = syn.make_buffer_latents(cfg, grid), syn.make_clip_features(cfg), syn.make_cond_latents(cfg, grid)
+    m = WanDiT(cfg, sd, hip_ops, bsd).prepare(grid)
+    ck, cu = m.encode_context(c1, clip), m.encode_context(c2, clip)
+    add = m.embed_cond_latents(y, add_to=m.embed_buffers(bl))
+    lat = noise.to("cuda:0")
+    m.forward_tokens(lat, ck, 731.0, add, m.head_out[0])
+    torch.cuda.synchronize()
+    v = R.unpatchify(m.head_out[0].cpu(), (grid.T, grid.Hp, grid.Wp), cfg.out_dim)
+    vref = R.dit_forward(sdr, cfg, noise, c1, 731.0, R.buffer_embed(bsdr, bl), clip_fea=clip, y=y)
+    rel = float((v - vref).norm() / vref.norm())
+    cos = float(torch.nn.functional.cosine_similarity(v.flatten(), vref.flatten(), dim=0))
+    assert cos >= 0.999 and rel <= 2e-2, f"i2v forward parity: cos={cos} rel-L2={rel}"
+    steps = 6
+    m.denoise(lat, ck, cu, add, FlowMatchScheduler(steps), 5.0)
+    torch.cuda.synchronize()
+    ref = R.denoise_loop(sdr, bsdr, cfg, noise, c1, c2, bl, num_steps=steps, clip_fea=clip, y=y)
+    p = R.psnr(lat.cpu(), ref)
+    assert p >= 40.0, f"i2v final-latent PSNR {p:.1f} dB < 40 dB"
+
+
 @pytest.mark.parametrize("chunks", [1, 3])
 def test_sequence_parallel_path_on_one_gpu(hip_ops, chunks):
     """The world>1 code path (token shards, RoPE offsets, chunked K/V gather feeding the carried-state
@@ -136,6 +162,72 @@ def test_sequence_parallel_path_on_one_gpu(hip_ops, chunks):
     got, want = torch.cat(outs, 0), full.head_out[0]
     rel = float((got - want).norm() / want.norm())
     assert rel < 5e-3, f"sharded vs unsharded forward rel-L2 {rel}"
+
+
+def test_sequence_parallel_gather_on_rccl_stream(hip_ops):
+    """The same sharded path, but each shard's OWN K/V rows travel through a real RCCL collective
+    (`nccl` backend, a one-rank group: the only RCCL this one-GPU box can run) issued async on RCCL's
+    stream while the compute stream keeps projecting Q; peer rows come from the unsharded run.  Checks
+    the stream hand-off KVGather relies on: the collective must see K/V written by earlier kernels on
+    the compute stream, and the chunk attention must not start before `wait()`."""
+    import torch.distributed as dist
+    from infinicube_amd.videogen.seqpar import ShardPlan
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29571", world_size=1, rank=0,
+                                device_id=torch.device("cuda", 0))
+    grid = TokenGrid(9, 64, 96)
+    cfg, sd, bsd, _, _ = _setup("tiny", grid)
+    noise, ctx, bl = syn.make_latent_noise(grid), syn.make_text_context(cfg, 1), syn.make_buffer_latents(cfg, grid)
+    rec = []
+    raw = hip_ops.attention
+
+    def recording_attention(q, k, v, o, heads, scale):
+        if k.shape[0] == grid.S:
+            rec.append((k.clone(), v.clone()))
+        raw(q, k, v, o, heads, scale)
+
+    hip_ops.attention = recording_attention
+    try:
+        full = WanDiT(cfg, sd, hip_ops, bsd).prepare(grid)
+        lat = noise.to("cuda:0")
+        full.forward_tokens(lat, full.encode_context(ctx), 300.0, full.embed_buffers(bl), full.head_out[0])
+        torch.cuda.synchronize()
+    finally:
+        hip_ops.attention = raw
+    chunks, outs = 3, []
+    for r in range(2):
+        plan = ShardPlan.make(grid.S, 2, r)
+        n = plan.n_tok
+
+        class RcclOwnRows:
+            def __init__(self):
+                self.layer, self.calls, self.r0 = 0, 0, 0
+
+            def start(self, k_rows, v_rows, k_out, v_out):
+                kf, vf = rec[self.layer]
+                m, r0, peer = k_rows.shape[0], self.r0, 1 - r
+                k_out[peer * m:(peer + 1) * m].copy_(kf[peer * n + r0: peer * n + r0 + m])
+                v_out[peer * m:(peer + 1) * m].copy_(vf[peer * n + r0: peer * n + r0 + m])
+                h = (dist.all_gather_into_tensor(k_out[r * m:(r + 1) * m], k_rows, async_op=True),
+                     dist.all_gather_into_tensor(v_out[r * m:(r + 1) * m], v_rows, async_op=True))
+                self.calls += 1
+                self.r0 += m
+                if self.calls % chunks == 0:
+                    self.layer, self.r0 = self.layer + 1, 0
+                return h
+
+            def wait(self, handle):
+                for w in handle:
+                    w.wait()
+
+        m = WanDiT(cfg, sd, hip_ops, bsd).prepare(grid, plan, kv_gather=RcclOwnRows(), sp_chunks=chunks)
+        m.forward_tokens(lat, m.encode_context(ctx), 300.0, m.embed_buffers(bl), m.head_out[0])
+        torch.cuda.synchronize()
+        outs.append(m.head_out[0].clone())
+    got, want = torch.cat(outs, 0), full.head_out[0]
+    rel = float((got - want).norm() / want.norm())
+    assert rel < 5e-3, f"sharded (RCCL own-rows) vs unsharded forward rel-L2 {rel}"
+
 
 
 def test_config1_wan_1p3b_17f_256p_10_steps(hip_ops):

@@ -113,3 +113,32 @@ def test_package_never_imports_oracle():
     for f in list((root / "infinicube_amd").rglob("*.py")) + list((root / "infinicube").rglob("*.py")) + list((root / "diffsynth").rglob("*.py")):
         src = f.read_text(encoding="utf-8")
         assert not re.search(r"^\s*(from|import)\s+(oracle|oracle_ops|tests)\b", src, flags=re.M), f
+
+
+def test_image_to_video_pipeline_branch():
+    """BASELINE.json config #5 plumbing: an i2v DiT (in_dim 36 + CLIP branch) through the pipeline's extra
+    ``input_image=`` keyword — the image must change the result, and misuse must fail loudly."""
+    from PIL import Image
+    from infinicube_amd.videogen.standins import HashImageEncoder
+    cfg = preset("tiny-i2v")
+    sd = syn.make_dit_state_dict(cfg)
+    pipe = WanVideoPipeline("cpu", torch.bfloat16, DiTHolder(sd), HashTextEncoder(cfg), PoolVAE(), ops=OracleOps(),
+                            image_encoder=HashImageEncoder(cfg))
+    assert pipe.dit.cfg.has_image_input and pipe.dit.cfg.in_dim == 36 and pipe.dit.cfg.img_dim == cfg.img_dim
+    pipe.initialize_buffer_embedder(16, zero_init=True)
+    rng = np.random.default_rng(0)
+    img_a = Image.fromarray(rng.integers(0, 255, (GRID.height, GRID.width, 3), dtype=np.uint8), mode="RGB")
+    img_b = Image.fromarray(rng.integers(0, 255, (48, 80, 3), dtype=np.uint8), mode="RGB")   # resized inside
+    kw = dict(prompt="a street", negative_prompt="bad", height=GRID.height, width=GRID.width,
+              num_frames=GRID.num_frames, seed=0, num_inference_steps=2, return_latents=True)
+    la, la2, lb = pipe(input_image=img_a, **kw), pipe(input_image=img_a, **kw), pipe(input_image=img_b, **kw)
+    assert la.shape == (16,) + GRID.latent_shape()[1:] and torch.isfinite(la).all()
+    assert torch.equal(la, la2) and not torch.equal(la, lb)
+    y = pipe._image_cond_latents(img_a, GRID, True, (30, 52), (15, 26))
+    assert y.shape == (20,) + GRID.latent_shape()[1:]
+    assert bool((y[:4, 0] == 1).all()) and bool((y[:4, 1:] == 0).all())
+    with pytest.raises(ValueError, match="image-to-video"):
+        pipe(**kw)
+    t2v = WanVideoPipeline("cpu", torch.bfloat16, DiTHolder(syn.make_dit_state_dict(CFG), CFG), HashTextEncoder(CFG), PoolVAE(), ops=OracleOps())
+    with pytest.raises(ValueError, match="text-to-video"):
+        t2v(input_image=img_a, **kw)

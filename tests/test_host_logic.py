@@ -48,6 +48,43 @@ def test_forward_matches_oracle(variant):
     assert float((v - ref).norm() / ref.norm()) < 1e-2      # only bf16 storage rounding separates them
 
 
+def test_i2v_branch_matches_oracle():
+    """BASELINE.json config #5's image-conditioning branch: y folded into the cached additive tokens,
+    CLIP tokens as a second cross-attention K/V set whose output is summed onto the text one."""
+    cfg = preset("tiny-i2v")
+    sd, bsd = syn.make_dit_state_dict(cfg), syn.make_buffer_embedder_state_dict(cfg)
+    noise, c1, c2, bl = syn.make_latent_noise(GRID), syn.make_text_context(cfg, 1), syn.make_text_context(cfg, 2), syn.make_buffer_latents(cfg, GRID)
+    clip, y = syn.make_clip_features(cfg), syn.make_cond_latents(cfg, GRID)
+    m = WanDiT(cfg, sd, OracleOps(), bsd).prepare(GRID)
+    ck = m.encode_context(c1, clip)
+    assert ck.k_img.shape == (cfg.num_layers, cfg.img_len, cfg.dim)
+    add = m.embed_cond_latents(y, add_to=m.embed_buffers(bl))
+    m.forward_tokens(noise.clone(), ck, 500.0, add, m.head_out[0])
+    v = R.unpatchify(m.head_out[0], (GRID.T, GRID.Hp, GRID.Wp), cfg.out_dim)
+    sdr, bsdr = R.round_state_dict_to_bf16(sd), R.round_state_dict_to_bf16(bsd)
+    ref = R.dit_forward(sdr, cfg, noise, c1, 500.0, R.buffer_embed(bsdr, bl), clip_fea=clip, y=y)
+    assert float((v - ref).norm() / ref.norm()) < 1e-2
+    # both conditioning inputs must matter
+    ref_noimg = R.dit_forward(sdr, cfg, noise, c1, 500.0, R.buffer_embed(bsdr, bl), clip_fea=clip * 0 + 1.0, y=y)
+    ref_noy = R.dit_forward(sdr, cfg, noise, c1, 500.0, R.buffer_embed(bsdr, bl), clip_fea=clip, y=y * 0)
+    assert float((ref - ref_noimg).norm() / ref.norm()) > 1e-3 and float((ref - ref_noy).norm() / ref.norm()) > 1e-3
+    # loop
+    lat = noise.clone()
+    m.denoise(lat, ck, m.encode_context(c2, clip), add, FlowMatchScheduler(3), 5.0)
+    refl = R.denoise_loop(sdr, bsdr, cfg, noise, c1, c2, bl, num_steps=3, clip_fea=clip, y=y)
+    assert R.psnr(lat, refl) > 50.0
+    # misuse fails loudly
+    with pytest.raises(ValueError, match="clip_fea"):
+        m.encode_context(c1)
+    with pytest.raises(ValueError, match="embed_cond_latents"):
+        m.forward_tokens(noise.clone(), ck, 500.0, None, m.head_out[0])
+    t2v = WanDiT(CFG, syn.make_dit_state_dict(CFG), OracleOps(), None).prepare(GRID)
+    with pytest.raises(ValueError, match="clip_fea"):
+        t2v.encode_context(c1, clip)
+    with pytest.raises(RuntimeError, match="no conditioning-latent"):
+        t2v.embed_cond_latents(y)
+
+
 def test_loop_matches_oracle_and_time_cache():
     sd, bsd, noise, c1, c2, bl = _inputs()
     m = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID)

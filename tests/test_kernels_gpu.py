@@ -486,6 +486,20 @@ def test_attention_minimum_sizes(hip_ops, kernel):
         hip_ops.lib.icv_set_option(b"attn_kernel", 2)
 
 
+@pytest.mark.parametrize("Sq,Skv,H", [(300, 257, 2), (1, 1, 1), (513, 64, 3)])
+def test_attention_add_into_output(hip_ops, Sq, Skv, H):
+    """icv_attention_fwd_add: o += softmax(q k^T) v (the i2v image cross-attention; 257 = CLIP tokens)."""
+    d = H * 128
+    q, k, v = (rnd((Sq, d), 331).to(torch.bfloat16), rnd((Skv, d), 332).to(torch.bfloat16), rnd((Skv, d), 333).to(torch.bfloat16))
+    prev = rnd((Sq, d), 334).to(torch.bfloat16)
+    ref = prev.float() + R.attention(q.float(), k.float(), v.float(), H)
+    o = torch.full((Sq + 2, d), 9.0, dtype=torch.bfloat16, device=DEV)
+    o[:Sq] = prev.to(DEV)
+    hip_ops.attention_add(q.to(DEV), k.to(DEV), v.to(DEV), o[:Sq], H, 1.0 / math.sqrt(128))
+    assert_bf16_close(o[:Sq], ref, f"attention_add Sq={Sq} Skv={Skv}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
+    assert bool((o[Sq:] == 9.0).all()), "wrote past the last query row"
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 4, 64), (3, 68, 64), (255, 252, 192), (257, 260, 128), (513, 256, 64)])
 def test_gemm_ragged_shapes(hip_ops, M, N, K):
     a = rnd((M, K), 311).to(torch.bfloat16)
