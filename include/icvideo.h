@@ -78,6 +78,28 @@ int icv_ln_modulate(const float* x, int64_t ldx, const float* weight, const floa
                     const float* shift, const float* scale, void* out, int64_t ldo,
                     int64_t rows, int64_t d, float eps, void* stream);
 
+/* ---- fp8 path (BASELINE.json config #5: "fp8 MFMA weights ... CDNA4 fp8 path") ---------------
+ * The reference names the I2V-14B checkpoint [R infinicube/videogen/download_checkpoint.py:24-29]; running its
+ * projections in fp8 is this build's option (WanDiT(gemm_dtype="fp8")), not a behaviour of the reference.
+ * Format: OCP e4m3 bytes + ONE f32 scale per row (token row of an activation, output-channel row of a
+ * weight): x[r,k] ~= q[r,k] * scale[r], scale[r] = max_k|x[r,k]| / 448 (1 for an all-zero row), RNE.
+ *
+ * icv_quantize_rows_fp8: src bf16 (src_is_f32 = 0) or f32 [rows, K] (ld elements) -> out e4m3 [rows, K]
+ *   (ldo bytes), scale f32 [rows].  K % 8 == 0.
+ * icv_ln_modulate_fp8: icv_ln_modulate whose output row is quantised in the same kernel.
+ * icv_gemm_fp8: out = epilogue((A . W^T) * a_scale[m] * w_scale[n] + bias), A e4m3 [M,K] (lda bytes),
+ *   W e4m3 [N,K] (ldw bytes), K % 128 == 0; epilogues and split output exactly as icv_gemm_bf16.
+ *   v_mfma_f32_16x16x128_f8f6f4: twice the bf16 MFMA rate. */
+int icv_quantize_rows_fp8(const void* src, int src_is_f32, int64_t ld, int64_t rows, int64_t K,
+                          void* out, int64_t ldo, float* scale, void* stream);
+int icv_ln_modulate_fp8(const float* x, int64_t ldx, const float* weight, const float* bias,
+                        const float* shift, const float* scale, void* out_fp8, int64_t ldo,
+                        float* out_scale, int64_t rows, int64_t d, float eps, void* stream);
+int icv_gemm_fp8(const void* A, int64_t lda, const float* a_scale, const void* W, int64_t ldw,
+                 const float* w_scale, const float* bias, int64_t M, int64_t N, int64_t K, int epilogue,
+                 void* out, int64_t ldo, int64_t nsplit, int64_t split_stride, const float* resid,
+                 int64_t ldr, const float* gate, void* stream);
+
 /* ---- K5: RMSNorm over the full model dim (+ 3-D RoPE), in place on bf16 -------------------
  * Up to two tensors per launch (q and k): x0/x1 bf16 [rows, d] (ld), w0/w1 f32 [d]; x1 may be
  * NULL.  RoPE is applied when rope_tab != NULL: rope_tab = f32 (cos,sin) pairs laid out

@@ -24,12 +24,30 @@ __device__ __forceinline__ float row_sum(float v, float* red, int wave) {
   return t;
 }
 
-template <int NV, int W>
+template <int W>
+__device__ __forceinline__ float row_max(float v, float* red, int wave) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  if (W == 1) return v;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[wave] = v;
+  __syncthreads();
+  const int base = (wave / W) * W;
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < W; ++i) t = fmaxf(t, red[base + i]);
+  return t;
+}
+
+// FP8 = true (fp8 GEMM path, BASELINE config #5): the modulated row is written as OCP e4m3 bytes with one
+// f32 scale per row (= row abs-max / 448) instead of bf16 — the abs-max is one more row reduction on values
+// that are already in registers, so the activation is quantised for free in the kernel that produces it.
+template <int NV, int W, bool FP8>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ weight,
     const float* __restrict__ bias, const float* __restrict__ shift,
-    const float* __restrict__ scale, bf16_t* __restrict__ out, int64_t ldo, int64_t rows, int d,
-    float eps) {
+    const float* __restrict__ scale, void* __restrict__ out_, int64_t ldo, float* __restrict__ out_scale,
+    int64_t rows, int d, float eps) {
   __shared__ float red[4];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -53,8 +71,10 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(
     q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
   }
   const float rstd = rsqrtf(row_sum<W>(q, red, wave) / (float)d + eps);
-  if (!live) return;
+  if (!FP8 && !live) return;
+  bf16_t* out = reinterpret_cast<bf16_t*>(out_);
   uint2* orow = reinterpret_cast<uint2*>(out + row * ldo);
+  float amax = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c4 = (i * W + sub) * 64 + lane;  // float4 index within the row
@@ -75,15 +95,35 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(
       const float4 sh = reinterpret_cast<const float4*>(shift)[c4];
       y.x += sh.x; y.y += sh.y; y.z += sh.z; y.w += sh.w;
     }
-    orow[c4] = make_uint2(pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
+    if (FP8) {
+      v[i] = y;
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w))));
+    } else {
+      orow[c4] = make_uint2(pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
+    }
+  }
+  if (FP8) {
+    amax = row_max<W>(amax, red, wave);
+    if (!live) return;
+    const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+    const float inv = 1.0f / sc;
+    if (sub == 0 && lane == 0) out_scale[row] = sc;
+    unsigned* qrow = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(out_) + row * ldo);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i].x * inv, v[i].y * inv, 0, false);
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i].z * inv, v[i].w * inv, w, true);
+      qrow[(i * W + sub) * 64 + lane] = (unsigned)w;
+    }
   }
 }
 
-extern "C" int icv_ln_modulate(const float* x, int64_t ldx, const float* weight, const float* bias,
-                               const float* shift, const float* scale, void* out, int64_t ldo,
-                               int64_t rows, int64_t d, float eps, void* stream) {
-  ICV_REQUIRE(rows > 0 && d > 0 && d % 256 == 0 && d <= 8192, "icv_ln_modulate: d=%lld must be a multiple of 256 and <= 8192", (long long)d);
-  ICV_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0, "icv_ln_modulate: ldx/ldo must be multiples of 4");
+template <bool FP8>
+static int ln_modulate_launch(const char* who, const float* x, int64_t ldx, const float* weight, const float* bias,
+                              const float* shift, const float* scale, void* out, int64_t ldo, float* out_scale,
+                              int64_t rows, int64_t d, float eps, void* stream) {
+  ICV_REQUIRE(rows > 0 && d > 0 && d % 256 == 0 && d <= 8192, "%s: d=%lld must be a multiple of 256 and <= 8192", who, (long long)d);
+  ICV_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0, "%s: ldx/ldo must be multiples of 4", who);
   hipStream_t st = (hipStream_t)stream;
   const int nvec = (int)(d / 256);                       // float4 per lane at one wave per row
   int forced = icv_get_option_int("ln_waves_per_row", 0);
@@ -93,17 +133,30 @@ extern "C" int icv_ln_modulate(const float* x, int64_t ldx, const float* weight,
   dim3 grid((unsigned)((rows * W + 3) / 4)), block(256);
 #define LAUNCH(NV_, W_)                                                                           \
   if (NV == NV_ && W == W_) {                                                                     \
-    hipLaunchKernelGGL((ln_modulate_kernel<NV_, W_>), grid, block, 0, st, x, ldx, weight, bias, shift, \
-                       scale, (bf16_t*)out, ldo, rows, (int)d, eps);                              \
-    return icv_check_launch("icv_ln_modulate");                                                   \
+    hipLaunchKernelGGL((ln_modulate_kernel<NV_, W_, FP8>), grid, block, 0, st, x, ldx, weight, bias, shift, \
+                       scale, out, ldo, out_scale, rows, (int)d, eps);                            \
+    return icv_check_launch(who);                                                                 \
   }
   LAUNCH(1, 1) LAUNCH(2, 1) LAUNCH(3, 1) LAUNCH(4, 1) LAUNCH(5, 1) LAUNCH(6, 1) LAUNCH(7, 1)
   LAUNCH(3, 2) LAUNCH(4, 2) LAUNCH(5, 2) LAUNCH(6, 2) LAUNCH(7, 2)
   LAUNCH(4, 4) LAUNCH(5, 4) LAUNCH(6, 4) LAUNCH(7, 4) LAUNCH(8, 4)
   LAUNCH(8, 1) LAUNCH(10, 1) LAUNCH(12, 1) LAUNCH(20, 1) LAUNCH(10, 2) LAUNCH(2, 4) LAUNCH(3, 4)
 #undef LAUNCH
-  icv_set_error("icv_ln_modulate: unsupported d=%lld (no instantiation for %d vectors x %d waves)", (long long)d, NV, W);
+  icv_set_error("%s: unsupported d=%lld (no instantiation for %d vectors x %d waves)", who, (long long)d, NV, W);
   return 1;
+}
+
+extern "C" int icv_ln_modulate(const float* x, int64_t ldx, const float* weight, const float* bias,
+                               const float* shift, const float* scale, void* out, int64_t ldo,
+                               int64_t rows, int64_t d, float eps, void* stream) {
+  return ln_modulate_launch<false>("icv_ln_modulate", x, ldx, weight, bias, shift, scale, out, ldo, nullptr, rows, d, eps, stream);
+}
+
+extern "C" int icv_ln_modulate_fp8(const float* x, int64_t ldx, const float* weight, const float* bias,
+                                   const float* shift, const float* scale, void* out_fp8, int64_t ldo,
+                                   float* out_scale, int64_t rows, int64_t d, float eps, void* stream) {
+  ICV_REQUIRE(out_scale, "icv_ln_modulate_fp8: null out_scale");
+  return ln_modulate_launch<true>("icv_ln_modulate_fp8", x, ldx, weight, bias, shift, scale, out_fp8, ldo, out_scale, rows, d, eps, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,277 @@
+// fp8 (OCP e4m3) GEMM for BASELINE.json config #5 ("fp8 MFMA weights ... CDNA4 fp8 path"):
+//   out = epilogue( (Aq[M,K] . Wq[N,K]^T) * a_scale[m] * w_scale[n] + bias )
+// Aq/Wq are e4m3 bytes with one f32 scale per row (per token / per output channel); accumulation is f32.
+//
+// Only the K = 128 MFMA (v_mfma_f32_16x16x128_f8f6f4, here with unit block scales = its unscaled form)
+// runs at twice the bf16 rate on gfx950 — the K = 32 fp8 MFMAs run at the bf16 rate — so this kernel
+// is gemm256.hip's schedule re-cut for it: the LDS image of a K-tile is byte-identical (128 rows x 128 B
+// per unit, same source-side XOR swizzle, same 4-phase counted-vmcnt DMA pipeline, same staggered wave
+// groups), but the 128 B of a row now hold 128 k values and feed ONE MFMA per 16x16 fragment pair
+// instead of two: lane (fr = lane & 15, g = lane >> 4) owns bytes [32g, 32g + 32) of its row
+// (operand layout probed on hardware: tools/probe_f8.hip).  Same MFMA time per tile, twice the flops.
+// Epilogues are those of icv_gemm_bf16 with the two row scales applied to the accumulator first.
+#include "icv_common.h"
+
+namespace gf8 {
+
+constexpr int BM = 256, BN = 256, BKB = 128;  // BKB = bytes (= fp8 elements) of K per tile
+constexpr int UNIT_BYTES = 128 * 128;
+constexpr int STAGE_BYTES = 4 * UNIT_BYTES;
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+constexpr int U_A0 = 0, U_A1 = 1, U_B0 = 2, U_B1 = 3;
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+struct Params {
+  const char* A; int64_t lda;      // bytes
+  const char* W; int64_t ldw;
+  const float* a_scale; const float* w_scale;
+  const float* bias;
+  int64_t M, N, K;
+  void* out; int64_t ldo; int64_t nsplit; int64_t split_stride;
+  const float* resid; int64_t ldr;
+  const float* gate;
+  int tiles_m, tiles_n;
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+#define GF8_BARRIER()                       \
+  do {                                      \
+    asm volatile("" ::: "memory");          \
+    __builtin_amdgcn_s_barrier();           \
+    asm volatile("" ::: "memory");          \
+  } while (0)
+#define GF8_VMCNT8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+
+__device__ __forceinline__ void dma_unit(const char* __restrict__ base, const unsigned (&off)[2],
+                                         int64_t kbyte, char* lds_unit, int wave) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const char* src = base + (int64_t)off[q] + kbyte;
+    char* dst = lds_unit + q * 8192 + wave * 1024;  // wave-uniform; HW adds lane*16
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ i32x8 read_frag(const char* p0, const char* p1) {
+  const i32x4 lo = *reinterpret_cast<const i32x4*>(p0);
+  const i32x4 hi = *reinterpret_cast<const i32x4*>(p1);
+  return (i32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_fp8_kernel(Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  // ---- block -> tile (bijective XCD remap + grouped order), as gemm256.hip ----
+  const int nwg = p.tiles_m * p.tiles_n;
+  int wg;
+  {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  constexpr int GM = 4;
+  const int group_size = GM * p.tiles_n;
+  const int g = wg / group_size;
+  const int first_m = g * GM;
+  const int gm = min(p.tiles_m - first_m, GM);
+  const int tm = first_m + (wg % group_size) % gm;
+  const int tn = (wg % group_size) / gm;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+  // ---- per-thread DMA source offsets (bytes, k = 0), 2 passes per unit ----
+  unsigned offA[2][2], offB[2][2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int u = q * 64 + (tid >> 3);            // unit row 0..127
+    const int pc = tid & 7;
+    const int c = pc ^ ((u >> 1) & 7);            // logical 16-B chunk held by physical chunk pc
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int64_t ra = m0 + (u >> 6) * 128 + h * 64 + (u & 63);
+      ra = ra < p.M ? ra : p.M - 1;
+      offA[h][q] = (unsigned)(ra * p.lda + c * 16);
+      int64_t rb = n0 + (u >> 5) * 64 + h * 32 + (u & 31);
+      rb = rb < p.N ? rb : p.N - 1;
+      offB[h][q] = (unsigned)(rb * p.ldw + c * 16);
+    }
+  }
+  const int nt = (int)(p.K / BKB);
+  auto kbyte = [&](int t) -> int64_t { return (int64_t)(t < nt ? t : nt - 1) * BKB; };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- fragment addressing: lane (fr, kg) reads logical chunks 2kg, 2kg+1 of its row ----
+  const int fr = lane & 15, kg = lane >> 4;
+  const int ar = wr * 64 + fr, br = wc * 32 + fr;   // (row + 16 i) keeps ((row >> 1) & 7)
+  const int a_lo = ar * 128 + (((2 * kg) ^ ((ar >> 1) & 7)) << 4), a_hi = ar * 128 + (((2 * kg + 1) ^ ((ar >> 1) & 7)) << 4);
+  const int b_lo = br * 128 + (((2 * kg) ^ ((br >> 1) & 7)) << 4), b_hi = br * 128 + (((2 * kg + 1) ^ ((br >> 1) & 7)) << 4);
+  constexpr int FROWS = 16 * 128;
+
+  // ---- prologue: tile 0 complete + A0,B0 of tile 1 ----
+  dma_unit(p.A, offA[0], kbyte(0), smem + U_A0 * UNIT_BYTES, wave);
+  dma_unit(p.W, offB[0], kbyte(0), smem + U_B0 * UNIT_BYTES, wave);
+  dma_unit(p.W, offB[1], kbyte(0), smem + U_B1 * UNIT_BYTES, wave);
+  dma_unit(p.A, offA[1], kbyte(0), smem + U_A1 * UNIT_BYTES, wave);
+  dma_unit(p.A, offA[0], kbyte(1), smem + STAGE_BYTES + U_A0 * UNIT_BYTES, wave);
+  dma_unit(p.W, offB[0], kbyte(1), smem + STAGE_BYTES + U_B0 * UNIT_BYTES, wave);
+  GF8_VMCNT8();
+  GF8_BARRIER();
+  if (wr == 1) GF8_BARRIER();  // stagger: group 1 runs one barrier behind group 0
+
+  i32x8 af[4], b0f[2], b1f[2];
+
+#define GF8_MFMA(AH, BF, BH)                                                                              \
+  {                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    __builtin_amdgcn_s_setprio(1);                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
+      acc[(AH) * 4 + i][(BH) * 2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                 \
+          BF[j], af[i], acc[(AH) * 4 + i][(BH) * 2 + j], 0, 0, 0, 0, 0, 0);                               \
+    __builtin_amdgcn_s_setprio(0);                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+  }
+
+  for (int t = 0; t < nt; ++t) {
+    char* cur = smem + (t & 1) * STAGE_BYTES;
+    char* oth = smem + ((t + 1) & 1) * STAGE_BYTES;
+    // ---------------- phase 1: a0 x b0 ----------------
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      b0f[j] = read_frag(cur + U_B0 * UNIT_BYTES + b_lo + j * FROWS, cur + U_B0 * UNIT_BYTES + b_hi + j * FROWS);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      af[i] = read_frag(cur + U_A0 * UNIT_BYTES + a_lo + i * FROWS, cur + U_A0 * UNIT_BYTES + a_hi + i * FROWS);
+    dma_unit(p.W, offB[1], kbyte(t + 1), oth + U_B1 * UNIT_BYTES, wave);
+    GF8_VMCNT8();
+    GF8_BARRIER();
+    GF8_MFMA(0, b0f, 0);
+    GF8_BARRIER();
+    // ---------------- phase 2: a0 x b1 ----------------
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      b1f[j] = read_frag(cur + U_B1 * UNIT_BYTES + b_lo + j * FROWS, cur + U_B1 * UNIT_BYTES + b_hi + j * FROWS);
+    dma_unit(p.A, offA[1], kbyte(t + 1), oth + U_A1 * UNIT_BYTES, wave);
+    GF8_VMCNT8();
+    GF8_BARRIER();
+    GF8_MFMA(0, b1f, 1);
+    GF8_BARRIER();
+    // ---------------- phase 3: a1 x b1 ----------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      af[i] = read_frag(cur + U_A1 * UNIT_BYTES + a_lo + i * FROWS, cur + U_A1 * UNIT_BYTES + a_hi + i * FROWS);
+    dma_unit(p.A, offA[0], kbyte(t + 2), cur + U_A0 * UNIT_BYTES, wave);
+    GF8_BARRIER();
+    GF8_MFMA(1, b1f, 1);
+    GF8_BARRIER();
+    // ---------------- phase 4: a1 x b0 ----------------
+    dma_unit(p.W, offB[0], kbyte(t + 2), cur + U_B0 * UNIT_BYTES, wave);
+    GF8_VMCNT8();
+    GF8_BARRIER();
+    GF8_MFMA(1, b0f, 0);
+    GF8_BARRIER();
+  }
+#undef GF8_MFMA
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain tail DMA before the LDS is released
+  if (wr == 0) GF8_BARRIER();                        // re-balance the stagger
+
+  // ---- epilogue: a lane owns ONE row m and runs of 4 consecutive n (swapped MFMA operands) ----
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int64_t m = m0 + wr * 128 + (i >> 2) * 64 + (i & 3) * 16 + fr;
+    const float sa = p.a_scale[m < p.M ? m : p.M - 1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + wc * 64 + (j >> 1) * 32 + (j & 1) * 16 + kg * 4;
+      if (m < p.M && n < p.N) {
+        const float4 sw = *reinterpret_cast<const float4*>(p.w_scale + n);
+        float v0 = acc[i][j][0] * (sa * sw.x), v1 = acc[i][j][1] * (sa * sw.y);
+        float v2 = acc[i][j][2] * (sa * sw.z), v3 = acc[i][j][3] * (sa * sw.w);
+        if (p.bias) {
+          const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+          v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
+        }
+        const int64_t sub = n / p.nsplit, col = n - sub * p.nsplit;
+        const int64_t off = sub * p.split_stride + m * p.ldo + col;
+        if (EPI == ICV_EPI_BF16 || EPI == ICV_EPI_GELU_BF16) {
+          if (EPI == ICV_EPI_GELU_BF16) {
+            v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3);
+          }
+          *reinterpret_cast<uint2*>((bf16_t*)p.out + off) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+        } else if (EPI == ICV_EPI_RESID_F32) {
+          const float4 r = *reinterpret_cast<const float4*>(p.resid + m * p.ldr + n);
+          float4 o;
+          if (p.gate) {
+            const float4 gt = *reinterpret_cast<const float4*>(p.gate + n);
+            o = make_float4(r.x + gt.x * v0, r.y + gt.y * v1, r.z + gt.z * v2, r.w + gt.w * v3);
+          } else {
+            o = make_float4(r.x + v0, r.y + v1, r.z + v2, r.w + v3);
+          }
+          *reinterpret_cast<float4*>((float*)p.out + off) = o;
+        } else {
+          *reinterpret_cast<float4*>((float*)p.out + off) = make_float4(v0, v1, v2, v3);
+        }
+      }
+    }
+  }
+}
+
+template <int EPI>
+int launch(const Params& p, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_fp8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) {
+      icv_set_error("icv_gemm_fp8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return 2;
+    }
+    attr_set = true;
+  }
+  const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
+  hipLaunchKernelGGL((gemm_fp8_kernel<EPI>), dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p);
+  return icv_check_launch("icv_gemm_fp8");
+}
+
+}  // namespace gf8
+
+extern "C" int icv_gemm_fp8(const void* A, int64_t lda, const float* a_scale, const void* W, int64_t ldw,
+                            const float* w_scale, const float* bias, int64_t M, int64_t N, int64_t K, int epilogue,
+                            void* out, int64_t ldo, int64_t nsplit, int64_t split_stride, const float* resid,
+                            int64_t ldr, const float* gate, void* stream) {
+  ICV_REQUIRE(A && W && a_scale && w_scale && out, "icv_gemm_fp8: null pointer");
+  ICV_REQUIRE(M > 0 && N > 0 && K > 0, "icv_gemm_fp8: empty problem");
+  ICV_REQUIRE(K % 128 == 0, "icv_gemm_fp8: K=%lld must be a multiple of 128", (long long)K);
+  ICV_REQUIRE(N % 4 == 0 && nsplit > 0 && nsplit % 4 == 0 && N % nsplit == 0, "icv_gemm_fp8: N=%lld / nsplit=%lld must be multiples of 4 with nsplit | N", (long long)N, (long long)nsplit);
+  ICV_REQUIRE(lda % 16 == 0 && ldw % 16 == 0 && ldo % 4 == 0, "icv_gemm_fp8: lda/ldw must be multiples of 16 bytes, ldo of 4 elements");
+  ICV_REQUIRE((uint64_t)M * (uint64_t)lda < (1ull << 32) && (uint64_t)N * (uint64_t)ldw < (1ull << 32), "icv_gemm_fp8: operand larger than 4 GiB");
+  ICV_REQUIRE(epilogue != ICV_EPI_RESID_F32 || (resid && ldr % 4 == 0), "icv_gemm_fp8: RESID epilogue needs resid with ldr %% 4 == 0");
+  gf8::Params p;
+  p.A = (const char*)A; p.lda = lda; p.W = (const char*)W; p.ldw = ldw; p.a_scale = a_scale; p.w_scale = w_scale;
+  p.bias = bias; p.M = M; p.N = N; p.K = K; p.out = out; p.ldo = ldo; p.nsplit = nsplit; p.split_stride = split_stride;
+  p.resid = resid; p.ldr = ldr; p.gate = gate;
+  p.tiles_m = (int)((M + gf8::BM - 1) / gf8::BM);
+  p.tiles_n = (int)((N + gf8::BN - 1) / gf8::BN);
+  hipStream_t st = (hipStream_t)stream;
+  switch (epilogue) {
+    case ICV_EPI_BF16: return gf8::launch<ICV_EPI_BF16>(p, st);
+    case ICV_EPI_GELU_BF16: return gf8::launch<ICV_EPI_GELU_BF16>(p, st);
+    case ICV_EPI_RESID_F32: return gf8::launch<ICV_EPI_RESID_F32>(p, st);
+    case ICV_EPI_F32: return gf8::launch<ICV_EPI_F32>(p, st);
+  }
+  icv_set_error("icv_gemm_fp8: unknown epilogue %d", epilogue);
+  return 1;
+}

@@ -33,6 +33,9 @@ SIGNATURES = {
     "icv_bcast_add_f32": (c_int, [_P, _P, _P, _I, _I, _P]),
     "icv_ln_modulate": (c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "icv_rmsnorm_rope": (c_int, [_P, _P, _P, _P, _I, _I, _I, _F, _P, _I, _I, _I, _I, _P]),
+    "icv_quantize_rows_fp8": (c_int, [_P, c_int, _I, _I, _I, _P, _I, _P, _P]),
+    "icv_ln_modulate_fp8": (c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _F, _P]),
+    "icv_gemm_fp8": (c_int, [_P, _I, _P, _P, _I, _P, _P, _I, _I, _I, c_int, _P, _I, _I, _I, _P, _I, _P, _P]),
     "icv_attention_fwd": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _F, _P]),
     "icv_attention_fwd_add": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _F, _P]),
     "icv_attention_fwd_chunk": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _F, c_int, c_int, _P]),

@@ -22,6 +22,11 @@ HBM layout, the step-invariant caches and the sequence-parallel schedule:
   channels) is step-invariant and the patch embedding is linear, so its tokens W[:,16:]·patch(y) are
   computed ONCE and folded into the cached buffer tokens — the per-step patch GEMM stays 16-channel;
   the CLIP tokens give a second cached K/V set [L, 257, d] whose attention is summed onto the text one.
+  fp8 (config #5's "fp8 MFMA weights", ``gemm_dtype="fp8"``): the six per-layer projections (QKV, O, cross-q,
+  cross-o, FFN1, FFN2 = 99.6 % of the GEMM flops) run on the K=128 fp8 MFMA at twice the bf16 rate.  Weights are
+  quantised once at load to e4m3 + one f32 scale per output channel (14 GB instead of 28); activations get one
+  scale per token: LN/modulate emits e4m3 directly (h8), the bf16 attention / GELU outputs take one
+  quantise pass (att8, ff8).  Residual stream, attention, norms, embeddings and the head stay as above.
 """
 
 from __future__ import annotations
@@ -33,7 +38,7 @@ from typing import Dict, Optional
 import torch
 
 from .config import TokenGrid, WanDiTConfig
-from .ops import BF16, EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_F32, F32, RopeTable
+from .ops import BF16, EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_F32, F32, FP8, RopeTable
 from .scheduler import FlowMatchScheduler
 from .seqpar import KVGather, ShardPlan, chunk_bounds
 
@@ -50,10 +55,17 @@ class ContextKV:
 
 
 class WanDiT:
+    FP8_WEIGHTS = ("wqkv", "wo", "xq_w", "xo_w", "f0_w", "f2_w")
+
     def __init__(self, cfg: WanDiTConfig, state_dict: Dict[str, torch.Tensor], ops,
-                 buffer_embedder_sd: Optional[Dict[str, torch.Tensor]] = None):
+                 buffer_embedder_sd: Optional[Dict[str, torch.Tensor]] = None, gemm_dtype: str = "bf16"):
         self.cfg = cfg.validate()
         self.ops = ops
+        if gemm_dtype not in ("bf16", "fp8"):
+            raise ValueError(f"gemm_dtype must be 'bf16' or 'fp8', got {gemm_dtype!r}")
+        self.fp8 = gemm_dtype == "fp8"
+        if self.fp8 and (cfg.dim % 128 or cfg.ffn_dim % 128):
+            raise ValueError("fp8 GEMMs need dim and ffn_dim to be multiples of 128")
         d = cfg.dim
         sd = state_dict
         W = lambda name: ops.to_device(sd[name], BF16)   # noqa: E731  matrices: bf16 in HBM
@@ -100,6 +112,9 @@ class WanDiT:
                 f0_w=W(f"{p}.ffn.0.weight"), f0_b=V(f"{p}.ffn.0.bias"),
                 f2_w=W(f"{p}.ffn.2.weight"), f2_b=V(f"{p}.ffn.2.bias"),
             )
+            if self.fp8:                                  # e4m3 rows + per-output-channel scale; bf16 copy dropped
+                for nm in self.FP8_WEIGHTS:
+                    lw[nm] = self._quantize_weight(lw[nm])
             if cfg.has_image_input:
                 lw["xkv_img_w"] = torch.cat([W(f"{ca}.k_img.weight"), W(f"{ca}.v_img.weight")], 0).contiguous()
                 lw["xkv_img_b"] = torch.cat([V(f"{ca}.k_img.bias"), V(f"{ca}.v_img.bias")], 0).contiguous()
@@ -113,6 +128,39 @@ class WanDiT:
         self.plan: Optional[ShardPlan] = None
 
     # ------------------------------------------------------------------------------------
+    def _quantize_weight(self, w: torch.Tensor):
+        q = torch.empty(w.shape, dtype=FP8, device=w.device)
+        sc = torch.empty((w.shape[0],), dtype=F32, device=w.device)
+        self.ops.quantize_rows(w, q, sc)
+        return (q, sc)
+
+    # GEMM operands are either a bf16 tensor or an (e4m3 rows, f32 row scales) pair; these three helpers keep
+    # forward_tokens identical for both GEMM dtypes.
+    def _norm(self, **kw):
+        """K3 / K8: LayerNorm(+affine)(+modulate) of the residual stream into the next GEMM's A operand."""
+        if self.fp8:
+            self.ops.ln_modulate_fp8(self.x, self.h8, self.h8s, **kw)
+            return (self.h8, self.h8s)
+        self.ops.ln_modulate(self.x, self.h, **kw)
+        return self.h
+
+    def _operand(self, t: torch.Tensor, q8: Optional[torch.Tensor], s8: Optional[torch.Tensor]):
+        """bf16 activation produced by attention / the GELU epilogue -> GEMM A operand."""
+        if self.fp8:
+            self.ops.quantize_rows(t, q8, s8)
+            return (q8, s8)
+        return t
+
+    def _mm(self, a, w, bias, out, epi, rows: Optional[slice] = None, **kw):
+        """out = epilogue(a @ w[rows].T + bias[rows])."""
+        if rows is not None:
+            w = (w[0][rows], w[1][rows]) if isinstance(w, tuple) else w[rows]
+            bias = bias[rows]
+        if isinstance(w, tuple):
+            self.ops.gemm_fp8(a[0], a[1], w[0], w[1], bias, out, epi, **kw)
+        else:
+            self.ops.gemm(a, w, bias, out, epi, **kw)
+
     @staticmethod
     def _pad_k(w: torch.Tensor, k_to: int) -> torch.Tensor:
         if w.shape[1] == k_to:
@@ -159,6 +207,11 @@ class WanDiT:
         self.qkv = a((3, n, d), BF16)
         self.att = a((n, d), BF16)
         self.ff = a((n, cfg.ffn_dim), BF16)
+        self.h8 = self.h8s = self.att8 = self.att8s = self.ff8 = self.ff8s = None
+        if self.fp8:
+            self.h8, self.h8s = a((n, d), FP8), a((n,), F32)
+            self.att8, self.att8s = a((n, d), FP8), a((n,), F32)
+            self.ff8, self.ff8s = a((n, cfg.ffn_dim), FP8), a((n,), F32)
         self.patches = torch.zeros((n, self.k_patch), dtype=BF16, device=ops.device)
         self.head_out = a((2, n, cfg.out_dim * cfg.patch_elems), F32)
         self.mod = a((cfg.num_layers, 6 * d), F32)
@@ -325,32 +378,35 @@ class WanDiT:
             sh1, sc1, g1 = m[0:d], m[d:2 * d], m[2 * d:3 * d]
             sh2, sc2, g2 = m[3 * d:4 * d], m[4 * d:5 * d], m[5 * d:6 * d]
             # --- self-attention ---
-            ops.ln_modulate(self.x, self.h, shift=sh1, scale=sc1, eps=eps)                  # K3
+            h = self._norm(shift=sh1, scale=sc1, eps=eps)                                   # K3
             if plan.world > 1:
                 # K and V first, so their all-gather (K13) is already moving while Q is projected
-                ops.gemm(self.h, lw["wqkv"][d:], lw["bqkv"][d:], self.qkv[1:], EPI_BF16, nsplit=d)   # K4 (k, v)
+                self._mm(h, lw["wqkv"], lw["bqkv"], self.qkv[1:], EPI_BF16, rows=slice(d, 3 * d), nsplit=d)  # K4 (k, v)
                 ops.rmsnorm_rope(k, lw["nk"], eps=eps, rope=self.rope, tok0=plan.tok0)               # K5 (k)
                 handles, bufs = self._sp_start_gather(k, v)
-                ops.gemm(self.h, lw["wqkv"][:d], lw["bqkv"][:d], q, EPI_BF16)                        # K4 (q)
+                self._mm(h, lw["wqkv"], lw["bqkv"], q, EPI_BF16, rows=slice(0, d))                   # K4 (q)
                 ops.rmsnorm_rope(q, lw["nq"], eps=eps, rope=self.rope, tok0=plan.tok0)               # K5 (q)
                 self._sp_attention(q, handles, bufs, H, scale)                                       # K6
             else:
-                ops.gemm(self.h, lw["wqkv"], lw["bqkv"], self.qkv, EPI_BF16, nsplit=d)      # K4
+                self._mm(h, lw["wqkv"], lw["bqkv"], self.qkv, EPI_BF16, nsplit=d)           # K4
                 ops.rmsnorm_rope(q, lw["nq"], k, lw["nk"], eps=eps, rope=self.rope, tok0=plan.tok0)  # K5
                 ops.attention(q, k, v, self.att, H, scale)                                  # K6
-            ops.gemm(self.att, lw["wo"], lw["bo"], self.x, EPI_RESID_F32, resid=self.x, gate=g1)  # K7
+            a = self._operand(self.att, self.att8, self.att8s)
+            self._mm(a, lw["wo"], lw["bo"], self.x, EPI_RESID_F32, resid=self.x, gate=g1)   # K7
             # --- cross-attention to text (no gate) ---
-            ops.ln_modulate(self.x, self.h, weight=lw["n3w"], bias=lw["n3b"], eps=eps)      # K8
-            ops.gemm(self.h, lw["xq_w"], lw["xq_b"], q, EPI_BF16)                           # K9
+            h = self._norm(weight=lw["n3w"], bias=lw["n3b"], eps=eps)                       # K8
+            self._mm(h, lw["xq_w"], lw["xq_b"], q, EPI_BF16)                                # K9
             ops.rmsnorm_rope(q, lw["xnq"], eps=eps)
             ops.attention(q, ctx.k[i], ctx.v[i], self.att, H, scale)
             if ctx.k_img is not None:                                                      # i2v: + softmax over CLIP tokens
                 ops.attention_add(q, ctx.k_img[i], ctx.v_img[i], self.att, H, scale)
-            ops.gemm(self.att, lw["xo_w"], lw["xo_b"], self.x, EPI_RESID_F32, resid=self.x)
+            a = self._operand(self.att, self.att8, self.att8s)
+            self._mm(a, lw["xo_w"], lw["xo_b"], self.x, EPI_RESID_F32, resid=self.x)
             # --- FFN ---
-            ops.ln_modulate(self.x, self.h, shift=sh2, scale=sc2, eps=eps)                  # K3
-            ops.gemm(self.h, lw["f0_w"], lw["f0_b"], self.ff, EPI_GELU_BF16)                # K10
-            ops.gemm(self.ff, lw["f2_w"], lw["f2_b"], self.x, EPI_RESID_F32, resid=self.x, gate=g2)
+            h = self._norm(shift=sh2, scale=sc2, eps=eps)                                   # K3
+            self._mm(h, lw["f0_w"], lw["f0_b"], self.ff, EPI_GELU_BF16)                     # K10
+            a = self._operand(self.ff, self.ff8, self.ff8s)
+            self._mm(a, lw["f2_w"], lw["f2_b"], self.x, EPI_RESID_F32, resid=self.x, gate=g2)
         # K11: head
         ops.ln_modulate(self.x, self.h, shift=self.hmod[0], scale=self.hmod[1], eps=eps)
         ops.gemm(self.h, self.head_w, self.head_b, head_out, EPI_F32)

@@ -19,6 +19,7 @@ from .. import native
 from ..native import EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_F32  # noqa: F401 (re-export)
 
 BF16, F32 = torch.bfloat16, torch.float32
+FP8 = torch.float8_e4m3fn   # OCP e4m3 (gfx950's fp8), one f32 scale per row next to it
 
 
 @dataclass
@@ -131,6 +132,53 @@ class HipOps:
         native.check(self.lib.icv_ln_modulate(
             x.data_ptr(), x.stride(0), native.ptr(weight), native.ptr(bias), native.ptr(shift),
             native.ptr(scale), out.data_ptr(), out.stride(0), rows, d, eps, self._stream()), "icv_ln_modulate")
+
+    # ---- fp8 path (BASELINE.json config #5): e4m3 rows + one f32 scale per row ----------------------
+    def quantize_rows(self, src, out_q, out_scale):
+        """src bf16|f32 [rows, K] -> out_q e4m3 [rows, K], out_scale f32 [rows] (row abs-max / 448)."""
+        if src.dtype not in (BF16, F32):
+            raise TypeError(f"quantize_rows.src: expected bf16 or f32, got {src.dtype}")
+        _chk(src, src.dtype, "quantize_rows.src"); _chk(out_q, FP8, "quantize_rows.out"); _chk(out_scale, F32, "quantize_rows.scale")
+        rows, K = src.shape
+        assert tuple(out_q.shape) == (rows, K) and out_scale.numel() == rows and out_scale.is_contiguous()
+        native.check(self.lib.icv_quantize_rows_fp8(
+            src.data_ptr(), int(src.dtype == F32), src.stride(0), rows, K, out_q.data_ptr(), out_q.stride(0),
+            out_scale.data_ptr(), self._stream()), "icv_quantize_rows_fp8")
+
+    def ln_modulate_fp8(self, x, out_q, out_scale, weight=None, bias=None, shift=None, scale=None, eps=1e-6):
+        _chk(x, F32, "ln8.x"); _chk(out_q, FP8, "ln8.out"); _chk(out_scale, F32, "ln8.scale")
+        rows, d = x.shape
+        assert tuple(out_q.shape) == (rows, d) and out_scale.numel() == rows and out_scale.is_contiguous()
+        native.check(self.lib.icv_ln_modulate_fp8(
+            x.data_ptr(), x.stride(0), native.ptr(weight), native.ptr(bias), native.ptr(shift),
+            native.ptr(scale), out_q.data_ptr(), out_q.stride(0), out_scale.data_ptr(), rows, d, eps,
+            self._stream()), "icv_ln_modulate_fp8")
+
+    def gemm_fp8(self, a_q, a_scale, w_q, w_scale, bias, out, epilogue, resid=None, gate=None, nsplit=None):
+        """out = epilogue((a_q @ w_q.T) * a_scale[:, None] * w_scale[None, :] + bias); shapes as ``gemm``."""
+        _chk(a_q, FP8, "gemm8.a"); _chk(w_q, FP8, "gemm8.w"); _chk(a_scale, F32, "gemm8.a_scale"); _chk(w_scale, F32, "gemm8.w_scale")
+        M, K = a_q.shape
+        N = w_q.shape[0]
+        if w_q.shape[1] != K:
+            raise ValueError(f"gemm_fp8: K mismatch {a_q.shape} x {w_q.shape}")
+        assert a_scale.numel() == M and w_scale.numel() == N and a_scale.is_contiguous() and w_scale.is_contiguous()
+        want = BF16 if epilogue in (EPI_BF16, EPI_GELU_BF16) else F32
+        _chk(out, want, "gemm8.out")
+        if nsplit is None:
+            if tuple(out.shape) != (M, N):
+                raise ValueError(f"gemm_fp8: out shape {tuple(out.shape)} != {(M, N)}")
+            ldo, ns, sstride = out.stride(0), N, 0
+        else:
+            if tuple(out.shape) != (N // nsplit, M, nsplit):
+                raise ValueError(f"gemm_fp8: split out shape {tuple(out.shape)} != {(N // nsplit, M, nsplit)}")
+            ldo, ns, sstride = out.stride(1), nsplit, out.stride(0)
+        for t, nm in ((bias, "bias"), (resid, "resid"), (gate, "gate")):
+            if t is not None:
+                _chk(t, F32, f"gemm8.{nm}")
+        native.check(self.lib.icv_gemm_fp8(
+            a_q.data_ptr(), a_q.stride(0), a_scale.data_ptr(), w_q.data_ptr(), w_q.stride(0), w_scale.data_ptr(),
+            native.ptr(bias), M, N, K, epilogue, out.data_ptr(), ldo, ns, sstride, native.ptr(resid),
+            resid.stride(0) if resid is not None else 0, native.ptr(gate), self._stream()), "icv_gemm_fp8")
 
     def rmsnorm_rope(self, x0, w0, x1=None, w1=None, eps=1e-6, rope: Optional[RopeTable] = None, tok0=0):
         _chk(x0, BF16, "rms.x0"); _chk(w0, F32, "rms.w0")

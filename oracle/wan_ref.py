@@ -131,34 +131,64 @@ def _lin(sd, name, x, dtype):
     return F.linear(x, sd[f"{name}.weight"].to(dtype), sd[f"{name}.bias"].to(dtype))
 
 
+# ---- fp8 GEMM mode of the build (BASELINE.json config #5 "fp8 MFMA weights"; not a behaviour of the reference) ----
+FP8_MAX = 448.0   # largest finite OCP e4m3 value
+
+
+def quantize_rows_fp8(x: Tensor) -> Tuple[Tensor, Tensor]:
+    """x [rows, K] -> (q: the e4m3 values as f32, scale f32 [rows]); scale = row abs-max / 448 (1 for a zero
+    row), q = RNE_e4m3(x * (1 / scale)).  The exact f32 operation order of csrc/fp8.hip."""
+    x = x.to(torch.float32)
+    amax = x.abs().amax(dim=-1)
+    scale = torch.where(amax > 0, amax / FP8_MAX, torch.ones_like(amax))
+    inv = 1.0 / scale
+    q = (x * inv[:, None]).to(torch.float8_e4m3fn).to(torch.float32)
+    return q, scale
+
+
+def fake_quant_rows(x: Tensor) -> Tensor:
+    q, s = quantize_rows_fp8(x)
+    return q * s[:, None]
+
+
+def _lin8(sd, name, x, dtype):
+    """Linear with both operands row-quantised to e4m3 (per token / per output channel), f32 accumulate."""
+    w = fake_quant_rows(sd[f"{name}.weight"]).to(dtype)
+    return F.linear(fake_quant_rows(x).to(dtype), w, sd[f"{name}.bias"].to(dtype))
+
+
 def dit_block(sd: Dict[str, Tensor], cfg, i: int, x: Tensor, ctx: Tensor, t_mod: Tensor,
-              freqs: Tensor, dtype=torch.float32, kv_override=None, ctx_img: Optional[Tensor] = None) -> Tensor:
+              freqs: Tensor, dtype=torch.float32, kv_override=None, ctx_img: Optional[Tensor] = None,
+              fp8: bool = False) -> Tensor:
+    """``fp8``: the six projections applied to token rows (q/k/v, o, cross q, cross o, ffn.0, ffn.2) take
+    e4m3 row-quantised operands; the cross-attention K/V projections of the context stay unquantised."""
     p = f"blocks.{i}"
+    lin = _lin8 if fp8 else _lin
     mod = sd[f"{p}.modulation"].to(dtype).reshape(6, cfg.dim) + t_mod
     sh1, sc1, g1, sh2, sc2, g2 = mod.unbind(0)
     H, eps = cfg.num_heads, cfg.eps
     # self-attention
     h = modulate(layer_norm(x, None, None, eps), sh1, sc1)
-    q = rope_apply(rms_norm(_lin(sd, f"{p}.self_attn.q", h, dtype), sd[f"{p}.self_attn.norm_q.weight"].to(dtype), eps), freqs, H)
-    k = rope_apply(rms_norm(_lin(sd, f"{p}.self_attn.k", h, dtype), sd[f"{p}.self_attn.norm_k.weight"].to(dtype), eps), freqs, H)
-    v = _lin(sd, f"{p}.self_attn.v", h, dtype)
+    q = rope_apply(rms_norm(lin(sd, f"{p}.self_attn.q", h, dtype), sd[f"{p}.self_attn.norm_q.weight"].to(dtype), eps), freqs, H)
+    k = rope_apply(rms_norm(lin(sd, f"{p}.self_attn.k", h, dtype), sd[f"{p}.self_attn.norm_k.weight"].to(dtype), eps), freqs, H)
+    v = lin(sd, f"{p}.self_attn.v", h, dtype)
     if kv_override is not None:  # sequence-parallel tests: attend over gathered K/V
         k, v = kv_override(k, v)
-    x = x + g1 * _lin(sd, f"{p}.self_attn.o", attention(q, k, v, H), dtype)
+    x = x + g1 * lin(sd, f"{p}.self_attn.o", attention(q, k, v, H), dtype)
     # cross-attention to text (no gate)
     h = layer_norm(x, sd[f"{p}.norm3.weight"].to(dtype), sd[f"{p}.norm3.bias"].to(dtype), eps)
-    q = rms_norm(_lin(sd, f"{p}.cross_attn.q", h, dtype), sd[f"{p}.cross_attn.norm_q.weight"].to(dtype), eps)
+    q = rms_norm(lin(sd, f"{p}.cross_attn.q", h, dtype), sd[f"{p}.cross_attn.norm_q.weight"].to(dtype), eps)
     k = rms_norm(_lin(sd, f"{p}.cross_attn.k", ctx, dtype), sd[f"{p}.cross_attn.norm_k.weight"].to(dtype), eps)
     v = _lin(sd, f"{p}.cross_attn.v", ctx, dtype)
     a = attention(q, k, v, H)
     if ctx_img is not None:   # i2v: a second softmax over the CLIP tokens, outputs summed before o
         k_img = rms_norm(_lin(sd, f"{p}.cross_attn.k_img", ctx_img, dtype), sd[f"{p}.cross_attn.norm_k_img.weight"].to(dtype), eps)
         a = a + attention(q, k_img, _lin(sd, f"{p}.cross_attn.v_img", ctx_img, dtype), H)
-    x = x + _lin(sd, f"{p}.cross_attn.o", a, dtype)
+    x = x + lin(sd, f"{p}.cross_attn.o", a, dtype)
     # FFN
     h = modulate(layer_norm(x, None, None, eps), sh2, sc2)
-    h = F.gelu(_lin(sd, f"{p}.ffn.0", h, dtype), approximate="tanh")
-    return x + g2 * _lin(sd, f"{p}.ffn.2", h, dtype)
+    h = F.gelu(lin(sd, f"{p}.ffn.0", h, dtype), approximate="tanh")
+    return x + g2 * lin(sd, f"{p}.ffn.2", h, dtype)
 
 
 # --------------------------------------------------------------------------------------------
@@ -197,7 +227,7 @@ def head(sd: Dict[str, Tensor], cfg, x: Tensor, t: Tensor, dtype=torch.float32) 
 def dit_forward(sd: Dict[str, Tensor], cfg, latent: Tensor, context: Tensor, timestep: float,
                 buf_tokens: Optional[Tensor] = None, dtype=torch.float32,
                 num_layers: Optional[int] = None, return_tokens: bool = False,
-                clip_fea: Optional[Tensor] = None, y: Optional[Tensor] = None) -> Tensor:
+                clip_fea: Optional[Tensor] = None, y: Optional[Tensor] = None, fp8: bool = False) -> Tensor:
     """One DiT forward: latent [C,T,H8,W8], raw text context [text_len, text_dim] -> velocity
     [out_dim, T, H8, W8].  i2v: ``y`` [in_dim-C,T,H8,W8] is concatenated under the noise channels and
     ``clip_fea`` [img_len, img_dim] feeds the image cross-attention."""
@@ -213,7 +243,7 @@ def dit_forward(sd: Dict[str, Tensor], cfg, latent: Tensor, context: Tensor, tim
         x = x + buf_tokens.to(dtype)
     freqs = rope_freqs_3d(cfg.head_dim, *grid)
     for i in range(cfg.num_layers if num_layers is None else num_layers):
-        x = dit_block(sd, cfg, i, x, ctx, t_mod, freqs, dtype, ctx_img=ctx_img)
+        x = dit_block(sd, cfg, i, x, ctx, t_mod, freqs, dtype, ctx_img=ctx_img, fp8=fp8)
     if return_tokens:
         return x
     return unpatchify(head(sd, cfg, x, t, dtype), grid, cfg.out_dim, cfg.patch)
@@ -230,16 +260,16 @@ def flow_match_sigmas(num_steps: int, shift: float = 5.0) -> Tensor:
 def denoise_loop(sd, bsd, cfg, noise: Tensor, ctx_cond: Tensor, ctx_uncond: Tensor,
                  buffer_latents: Optional[Tensor], num_steps: int = 50, cfg_scale: float = 5.0,
                  shift: float = 5.0, dtype=torch.float32, trace: Optional[list] = None,
-                 clip_fea: Optional[Tensor] = None, y: Optional[Tensor] = None) -> Tensor:
+                 clip_fea: Optional[Tensor] = None, y: Optional[Tensor] = None, fp8: bool = False) -> Tensor:
     """for sigma in sigmas: v = v_u + s (v_c - v_u); x += v (sigma_next - sigma)."""
     sig = flow_match_sigmas(num_steps, shift)
     buf = buffer_embed(bsd, buffer_latents, dtype) if buffer_latents is not None else None
     x = noise.to(dtype).clone()
     for i in range(num_steps):
         ts = float(sig[i]) * 1000.0
-        v_c = dit_forward(sd, cfg, x, ctx_cond, ts, buf, dtype, clip_fea=clip_fea, y=y)
+        v_c = dit_forward(sd, cfg, x, ctx_cond, ts, buf, dtype, clip_fea=clip_fea, y=y, fp8=fp8)
         if cfg_scale != 1.0:
-            v_u = dit_forward(sd, cfg, x, ctx_uncond, ts, buf, dtype, clip_fea=clip_fea, y=y)
+            v_u = dit_forward(sd, cfg, x, ctx_uncond, ts, buf, dtype, clip_fea=clip_fea, y=y, fp8=fp8)
             v = v_u + cfg_scale * (v_c - v_u)
         else:
             v = v_c

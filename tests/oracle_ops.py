@@ -18,7 +18,7 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import wan_ref as R  # noqa: E402
 
-BF16, F32 = torch.bfloat16, torch.float32
+BF16, F32, FP8 = torch.bfloat16, torch.float32, torch.float8_e4m3fn
 EPI_BF16, EPI_GELU_BF16, EPI_RESID_F32, EPI_F32 = 0, 1, 2, 3
 
 
@@ -37,6 +37,33 @@ class OracleOps:
     def gemm(self, a, w, bias, out, epilogue, resid=None, gate=None, nsplit=None):
         assert a.dtype == BF16 and w.dtype == BF16
         acc = a.float() @ w.float().t()
+        if bias is not None:
+            acc = acc + bias
+        if epilogue == EPI_GELU_BF16:
+            acc = F.gelu(acc, approximate="tanh")
+        if epilogue == EPI_RESID_F32:
+            acc = resid + (gate * acc if gate is not None else acc)
+        if nsplit is None:
+            out.copy_(acc.to(out.dtype))
+        else:
+            M, N = acc.shape
+            out.copy_(acc.reshape(M, N // nsplit, nsplit).permute(1, 0, 2).to(out.dtype))
+
+    def quantize_rows(self, src, out_q, out_scale):
+        q, sc = R.quantize_rows_fp8(src.float())
+        out_q.copy_(q.to(FP8)); out_scale.copy_(sc)
+
+    def ln_modulate_fp8(self, x, out_q, out_scale, weight=None, bias=None, shift=None, scale=None, eps=1e-6):
+        y = R.layer_norm(x, weight, bias, eps)
+        if scale is not None:
+            y = y * (1.0 + scale)
+        if shift is not None:
+            y = y + shift
+        self.quantize_rows(y, out_q, out_scale)
+
+    def gemm_fp8(self, a_q, a_scale, w_q, w_scale, bias, out, epilogue, resid=None, gate=None, nsplit=None):
+        assert a_q.dtype == FP8 and w_q.dtype == FP8
+        acc = (a_q.float() @ w_q.float().t()) * a_scale[:, None] * w_scale[None, :]
         if bias is not None:
             acc = acc + bias
         if epilogue == EPI_GELU_BF16:

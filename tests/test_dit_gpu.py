@@ -100,6 +100,42 @@ def test_i2v_forward_and_loop_parity(hip_ops):
     assert p >= 40.0, f"i2v final-latent PSNR {p:.1f} dB < 40 dB"
 
 
+def test_fp8_gemm_mode_forward_and_loop(hip_ops):
+    """BASELINE.json config #5 at test size: i2v DiT with the six per-layer projections on the fp8 MFMA.
+    Parity bar for the fp8 mode: against the oracle run with the SAME e4m3 row quantisation (kernel
+    arithmetic), cosine >= 0.999 / rel-L2 <= 2e-2 per forward and PSNR >= 40 dB for the loop; the gap to
+    the unquantised oracle is the quantisation itself and is only reported / bounded loosely."""
+    cfg, grid = preset("tiny-i2v"), TokenGrid(9, 64, 96)
+    sd, bsd = syn.make_dit_state_dict(cfg), syn.make_buffer_embedder_state_dict(cfg)
+    sdr, bsdr = R.round_state_dict_to_bf16(sd), R.round_state_dict_to_bf16(bsd)
+    noise, c1, c2 = syn.make_latent_noise(grid), syn.make_text_context(cfg, 1), syn.make_text_context(cfg, 2)
+    bl, clip, y = syn.make_buffer_latents(cfg, grid), syn.make_clip_features(cfg), syn.make_cond_latents(cfg, grid)
+    m = WanDiT(cfg, sd, hip_ops, bsd, gemm_dtype="fp8").prepare(grid)
+    ck, cu = m.encode_context(c1, clip), m.encode_context(c2, clip)
+    add = m.embed_cond_latents(y, add_to=m.embed_buffers(bl))
+    lat = noise.to("cuda:0")
+    m.forward_tokens(lat, ck, 731.0, add, m.head_out[0])
+    torch.cuda.synchronize()
+    v = R.unpatchify(m.head_out[0].cpu(), (grid.T, grid.Hp, grid.Wp), cfg.out_dim)
+    kw = dict(clip_fea=clip, y=y)
+    ref8 = R.dit_forward(sdr, cfg, noise, c1, 731.0, R.buffer_embed(bsdr, bl), fp8=True, **kw)
+    ref = R.dit_forward(sdr, cfg, noise, c1, 731.0, R.buffer_embed(bsdr, bl), **kw)
+    rel8 = float((v - ref8).norm() / ref8.norm())
+    cos8 = float(torch.nn.functional.cosine_similarity(v.flatten(), ref8.flatten(), dim=0))
+    rel = float((v - ref).norm() / ref.norm())
+    print(f"fp8 forward: vs fake-quant oracle rel-L2 {rel8:.2e} cos {cos8:.6f}; vs unquantised oracle rel-L2 {rel:.2e}")
+    assert cos8 >= 0.999 and rel8 <= 2e-2, f"fp8 forward vs fake-quant oracle: cos={cos8} rel-L2={rel8}"
+    assert rel <= 0.15, f"fp8 forward vs unquantised oracle rel-L2 {rel}"
+    steps = 6
+    m.denoise(lat, ck, cu, add, FlowMatchScheduler(steps), 5.0)
+    torch.cuda.synchronize()
+    refl8 = R.denoise_loop(sdr, bsdr, cfg, noise, c1, c2, bl, num_steps=steps, fp8=True, **kw)
+    refl = R.denoise_loop(sdr, bsdr, cfg, noise, c1, c2, bl, num_steps=steps, **kw)
+    p8, p = R.psnr(lat.cpu(), refl8), R.psnr(lat.cpu(), refl)
+    print(f"fp8 loop: PSNR vs fake-quant oracle {p8:.1f} dB, vs unquantised oracle {p:.1f} dB")
+    assert p8 >= 40.0, f"fp8 loop PSNR vs fake-quant oracle {p8:.1f} dB < 40 dB"
+
+
 @pytest.mark.parametrize("chunks", [1, 3])
 def test_sequence_parallel_path_on_one_gpu(hip_ops, chunks):
     """The world>1 code path (token shards, RoPE offsets, chunked K/V gather feeding the carried-state

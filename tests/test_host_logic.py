@@ -85,6 +85,29 @@ def test_i2v_branch_matches_oracle():
         t2v.embed_cond_latents(y)
 
 
+def test_fp8_gemm_mode_matches_fake_quant_oracle():
+    """gemm_dtype='fp8' (BASELINE.json config #5): the host path with row-quantised e4m3 operands equals the
+    oracle run with the same fake quantisation, and differs from the unquantised oracle by fp8-sized noise."""
+    cfg = preset("tiny-i2v")
+    sd, bsd = syn.make_dit_state_dict(cfg), syn.make_buffer_embedder_state_dict(cfg)
+    noise, c1, bl = syn.make_latent_noise(GRID), syn.make_text_context(cfg, 1), syn.make_buffer_latents(cfg, GRID)
+    clip, y = syn.make_clip_features(cfg), syn.make_cond_latents(cfg, GRID)
+    m = WanDiT(cfg, sd, OracleOps(), bsd, gemm_dtype="fp8").prepare(GRID)
+    assert m.layers[0]["wqkv"][0].dtype == torch.float8_e4m3fn and m.layers[0]["wqkv"][1].shape == (3 * cfg.dim,)
+    assert m.layers[0]["xkv_w"].dtype == torch.bfloat16            # context K/V projection stays bf16
+    add = m.embed_cond_latents(y, add_to=m.embed_buffers(bl))
+    m.forward_tokens(noise.clone(), m.encode_context(c1, clip), 500.0, add, m.head_out[0])
+    v = R.unpatchify(m.head_out[0], (GRID.T, GRID.Hp, GRID.Wp), cfg.out_dim)
+    sdr, bsdr = R.round_state_dict_to_bf16(sd), R.round_state_dict_to_bf16(bsd)
+    ref8 = R.dit_forward(sdr, cfg, noise, c1, 500.0, R.buffer_embed(bsdr, bl), clip_fea=clip, y=y, fp8=True)
+    ref = R.dit_forward(sdr, cfg, noise, c1, 500.0, R.buffer_embed(bsdr, bl), clip_fea=clip, y=y)
+    rel8, rel = float((v - ref8).norm() / ref8.norm()), float((v - ref).norm() / ref.norm())
+    assert rel8 < 2e-2, f"fp8 host path vs fake-quant oracle rel-L2 {rel8}"
+    assert 1e-3 < rel < 0.2, f"fp8 vs unquantised oracle rel-L2 {rel} (expected fp8-sized, non-zero)"
+    with pytest.raises(ValueError, match="gemm_dtype"):
+        WanDiT(cfg, sd, OracleOps(), bsd, gemm_dtype="int4")
+
+
 def test_loop_matches_oracle_and_time_cache():
     sd, bsd, noise, c1, c2, bl = _inputs()
     m = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID)

@@ -486,6 +486,104 @@ def test_attention_minimum_sizes(hip_ops, kernel):
         hip_ops.lib.icv_set_option(b"attn_kernel", 2)
 
 
+# ---------------------------------------------------------------------------------------------------
+# fp8 path (BASELINE.json config #5): row-scaled e4m3 quantisation and the K=128 fp8 MFMA GEMM
+# ---------------------------------------------------------------------------------------------------
+FP8 = torch.float8_e4m3fn
+
+
+@pytest.mark.parametrize("rows,K,src", [(5, 128, "bf16"), (257, 1536, "bf16"), (64, 13824, "bf16"), (33, 5120, "f32"), (1, 8, "f32")])
+def test_quantize_rows_fp8_bit_exact(hip_ops, rows, K, src):
+    x = rnd((rows, K), 401, 3.0)
+    x[:, ::7] *= 40.0                      # outlier channels
+    x[rows // 2] = 0.0                     # an all-zero row -> scale 1, zeros
+    if rows > 2:
+        x[1] *= 1e-6                       # tiny row: the scale keeps it in range
+    xs = x.to(torch.bfloat16) if src == "bf16" else x
+    q = torch.zeros((rows + 1, K), dtype=torch.uint8, device=DEV).view(FP8)
+    sc = torch.full((rows + 1,), 7.0, device=DEV)
+    hip_ops.quantize_rows(xs.to(DEV), q[:rows], sc[:rows])
+    qr, sr = R.quantize_rows_fp8(xs.float())
+    assert torch.equal(sc[:rows].cpu(), sr), "row scales differ"
+    got = q[:rows].cpu().float()
+    nbad = int((got != qr).sum())
+    assert nbad == 0, f"{nbad} / {got.numel()} e4m3 codes differ from the oracle (max |d| {float((got - qr).abs().max())})"
+    assert float(sc[rows]) == 7.0 and bool((q[rows].view(torch.uint8) == 0).all()), "wrote past the last row"
+
+
+@pytest.mark.parametrize("rows,d,mode", [(37, 1536, "mod"), (300, 5120, "mod"), (9, 256, "affine"), (130, 2048, "plain")])
+def test_ln_modulate_fp8(hip_ops, rows, d, mode):
+    x = rnd((rows, d), 411, 2.0) + 0.3
+    x[:, 5] += 30.0
+    kw = {}
+    if mode == "mod":
+        kw = dict(shift=rnd((d,), 412, 0.2), scale=rnd((d,), 413, 0.2))
+    elif mode == "affine":
+        kw = dict(weight=1.0 + rnd((d,), 414, 0.1), bias=rnd((d,), 415, 0.1))
+    y = R.layer_norm(x, kw.get("weight"), kw.get("bias"), 1e-6)
+    if "scale" in kw:
+        y = y * (1.0 + kw["scale"]) + kw["shift"]
+    q = torch.zeros((rows, d), dtype=torch.uint8, device=DEV).view(FP8)
+    sc = torch.zeros((rows,), device=DEV)
+    hip_ops.ln_modulate_fp8(x.to(DEV), q, sc, eps=1e-6, **{k: v.to(DEV) for k, v in kw.items()})
+    qr, sr = R.quantize_rows_fp8(y)
+    assert torch.allclose(sc.cpu(), sr, rtol=1e-5, atol=0), "row scales differ beyond f32 LN rounding"
+    deq, ref = q.cpu().float() * sc.cpu()[:, None], qr * sr[:, None]
+    # f32 LayerNorm rounding can flip an e4m3 rounding decision for values on a tie: allow one code step on <0.5 %
+    step = (deq - ref).abs() / ref.abs().clamp_min(1e-20)
+    assert float((step > 1e-6).float().mean()) < 5e-3 and float(step.max()) <= 0.126
+    # and the quantisation itself: e4m3 keeps 2^-4 relative precision down to 2^-9 of the row maximum's scale
+    tol = (2.0 ** -4) * y.abs() + (2.0 ** -10) * sr[:, None] * 448.0 / 256.0
+    assert bool(((deq - y).abs() <= tol).all()), f"ln_modulate_fp8 {mode}: dequantised row off by more than e4m3 rounding"
+
+
+@pytest.mark.parametrize("M,N,K,epi", [
+    (256, 256, 128, "f32"), (300, 260, 256, "f32"), (1, 4, 128, "f32"), (513, 1536, 1536, "bf16"),
+    (777, 1024, 512, "gelu"), (640, 512, 8960, "resid"), (515, 768, 384, "split")])
+def test_gemm_fp8(hip_ops, M, N, K, epi):
+    a = rnd((M, K), 421, 1.5)
+    a[:, 3] *= 25.0
+    w = rnd((N, K), 422, 1.0 / math.sqrt(K))
+    bias = rnd((N,), 423, 0.1)
+    aq, asc = R.quantize_rows_fp8(a)
+    wq, wsc = R.quantize_rows_fp8(w)
+    acc = (aq.double() @ wq.double().t()).float() * asc[:, None] * wsc[None, :] + bias
+    A8, W8 = aq.to(FP8).to(DEV), wq.to(FP8).to(DEV)
+    args = (A8, asc.to(DEV), W8, wsc.to(DEV), bias.to(DEV))
+    if epi == "f32":
+        out = torch.full((M + 1, N), 5.0, device=DEV)
+        hip_ops.gemm_fp8(*args, out[:M], EPI_F32)
+        assert_f32_close(out[:M], acc, rtol=1e-4, what=f"gemm_fp8 {M}x{N}x{K}")
+        assert bool((out[M:] == 5.0).all()), "wrote past the last row"
+    elif epi == "bf16":
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+        hip_ops.gemm_fp8(*args, out, EPI_BF16)
+        assert_bf16_close(out, acc, "gemm_fp8 bf16")
+    elif epi == "gelu":
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+        hip_ops.gemm_fp8(*args, out, EPI_GELU_BF16)
+        assert_bf16_close(out, torch.nn.functional.gelu(acc, approximate="tanh"), "gemm_fp8 gelu", abs_floor=2.0 ** -8)
+    elif epi == "resid":
+        resid, gate = rnd((M, N), 424), rnd((N,), 425)
+        out = resid.clone().to(DEV)
+        hip_ops.gemm_fp8(*args, out, EPI_RESID_F32, resid=out, gate=gate.to(DEV))
+        assert_f32_close(out, resid + gate * acc, rtol=1e-4, what="gemm_fp8 resid")
+    else:
+        ns = N // 3
+        out = torch.empty((3, M, ns), dtype=torch.bfloat16, device=DEV)
+        hip_ops.gemm_fp8(*args, out, EPI_BF16, nsplit=ns)
+        assert_bf16_close(out, acc.reshape(M, 3, ns).permute(1, 0, 2), "gemm_fp8 split planes")
+
+
+def test_gemm_fp8_rejects_bad_shapes(hip_ops):
+    from infinicube_amd.native import NativeError
+    a = torch.zeros((8, 192), dtype=torch.uint8, device=DEV).view(FP8)
+    w = torch.zeros((8, 192), dtype=torch.uint8, device=DEV).view(FP8)
+    s = torch.ones((8,), device=DEV)
+    with pytest.raises(NativeError, match="multiple of 128"):
+        hip_ops.gemm_fp8(a, s, w, s, None, torch.empty((8, 8), device=DEV), EPI_F32)
+
+
 @pytest.mark.parametrize("Sq,Skv,H", [(300, 257, 2), (1, 1, 1), (513, 64, 3)])
 def test_attention_add_into_output(hip_ops, Sq, Skv, H):
     """icv_attention_fwd_add: o += softmax(q k^T) v (the i2v image cross-attention; 257 = CLIP tokens)."""
