@@ -95,7 +95,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     # default = Wan2.1-14B: BASELINE.json quotes its metric/target (>= 1.0 step/s on 8 GPUs, >= 6x scaling) and
     # its multi-GPU config on the 14B model, and 14B (28 GB bf16) fits one 288 GB MI355X
-    ap.add_argument("--model", default=os.environ.get("ICV_BENCH_MODEL", "14b"), choices=["1.3b", "14b", "small", "tiny"])
+    ap.add_argument("--model", default=os.environ.get("ICV_BENCH_MODEL", "14b"),
+                    choices=["1.3b", "14b", "14b-i2v", "small", "tiny", "tiny-i2v"])
+    # bf16 is the metric's dtype; fp8 = BASELINE.json config #5's "fp8 MFMA weights" mode (e4m3 projections,
+    # bf16 attention) and is reported as such, never as the headline number
+    ap.add_argument("--gemm-dtype", default=os.environ.get("ICV_BENCH_GEMM_DTYPE", "bf16"), choices=["bf16", "fp8"])
     ap.add_argument("--frames", type=int, default=GRID_480P.num_frames)
     ap.add_argument("--height", type=int, default=GRID_480P.height)
     ap.add_argument("--width", type=int, default=GRID_480P.width)
@@ -127,12 +131,15 @@ def main():
     # ---- synthetic weights / inputs, resident in HBM before timing (SURVEY.md §8d recipe) ----
     sd = syn.make_dit_state_dict(cfg, seed=0, device=device, dtype=torch.bfloat16)
     bsd = syn.make_buffer_embedder_state_dict(cfg, device=device, dtype=torch.bfloat16)
-    model = WanDiT(cfg, sd, ops, bsd)
+    model = WanDiT(cfg, sd, ops, bsd, gemm_dtype=args.gemm_dtype)
     del sd, bsd
     model.prepare(grid, plan, sp_chunks=args.sp_chunks)
-    ctx_c = model.encode_context(syn.make_text_context(cfg, 1))
-    ctx_u = model.encode_context(syn.make_text_context(cfg, 2))
+    clip = syn.make_clip_features(cfg) if cfg.has_image_input else None
+    ctx_c = model.encode_context(syn.make_text_context(cfg, 1), clip)
+    ctx_u = model.encode_context(syn.make_text_context(cfg, 2), clip)
     buf = model.embed_buffers(syn.make_buffer_latents(cfg, grid))
+    if cfg.has_image_input:   # i2v: first-frame conditioning latent folded into the cached additive tokens
+        buf = model.embed_cond_latents(syn.make_cond_latents(cfg, grid), add_to=buf)
     latent = syn.make_latent_noise(grid, seed=0).to(device)
     total_steps = 50
     sched = FlowMatchScheduler(total_steps)
@@ -219,13 +226,13 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "bf16",
+            "dtype": "bf16" if args.gemm_dtype == "bf16" else "fp8 e4m3 projections (f32 accumulate) + bf16 attention",
             "data": "synthetic (seeded latents/text context/guidance-buffer latents, random-init weights of the named architecture)",
             "config": {
-                "workload": f"Wan2.1-{args.model.upper()} t2v DiT, {args.frames} frames {args.height}x{args.width}, "
+                "workload": f"Wan2.1-{args.model.upper()} {'i2v' if cfg.has_image_input else 't2v'} DiT, {args.frames} frames {args.height}x{args.width}, "
                             f"S={grid.S} tokens, 1 step = 2 DiT forwards (cond+uncond, cfg {CFG_SCALE}) + Euler; "
                             f"50-step flow-match schedule (shift 5)",
-                "model": f"wan2.1-t2v-{args.model}", "tokens": grid.S, "layers": cfg.num_layers, "dim": cfg.dim,
+                "model": cfg.name, "gemm_dtype": args.gemm_dtype, "tokens": grid.S, "layers": cfg.num_layers, "dim": cfg.dim,
                 "parallelism": f"sp{world} (token-sequence shards, K/V all-gather in {args.sp_chunks} chunks overlapped with attention)" if world > 1 else "single-gpu",
                 "wallclock_50_steps_s": 50.0 * elapsed / args.steps,
                 "algorithmic_pflop_per_step": f_step / 1e15,

@@ -158,6 +158,10 @@ class WanVideoPipeline:
                  text_encoder=None, vae=None, ops=None, image_encoder=None):
         self.device = device
         self.image_encoder = image_encoder   # i2v only (CLIP ViT-H/14 tokens of the conditioning image)
+        # diffsynth takes torch_dtype=float8_e4m3fn to mean "fp8 DiT weights"; here it selects the fp8 MFMA
+        # projections (BASELINE.json config #5).  Anything else = bf16, the reference's setting
+        # [R infinicube/inference/guidance_buffer_generation.py:762].
+        self.gemm_dtype = "fp8" if torch_dtype == torch.float8_e4m3fn else "bf16"
         self.torch_dtype = torch_dtype
         self.dit = dit
         self.text_encoder = text_encoder
@@ -218,14 +222,15 @@ class WanVideoPipeline:
 
     def _get_engine(self):
         from .dit import WanDiT
-        key = (self.dit.version, self.buffer_embedder.version if self.buffer_embedder else -1)
+        key = (self.dit.version, self.buffer_embedder.version if self.buffer_embedder else -1, self.gemm_dtype)
         if self._engine is None or self._engine_key != key:
             cfg = self.dit.cfg
             if self.buffer_embedder is not None and cfg.buffer_channels != self.buffer_embedder.buffer_channels:
                 import dataclasses
                 cfg = dataclasses.replace(cfg, buffer_channels=self.buffer_embedder.buffer_channels)
             self._engine = WanDiT(cfg, self.dit.state_dict(), self._get_ops(),
-                                  self.buffer_embedder.state_dict() if self.buffer_embedder else None)
+                                  self.buffer_embedder.state_dict() if self.buffer_embedder else None,
+                                  gemm_dtype=self.gemm_dtype)
             self._engine_key = key
         return self._engine
 

@@ -16,11 +16,23 @@ padding is exactly the same function, so with 288 GB of HBM the whole clip is pr
 first-frame special cases of the temporal resamplers are kept: the first frame is never time-convolved).
 Spatial tiling (``tiled=True``: tile 30x52 latent, stride 15x26, linear-ramp blend) is kept because it
 changes the numbers (each tile sees only its own receptive field) and the reference asks for it.
+
+MIOpen note (measured on MI355X, 93x480x832 decode, bf16, tools/aux_bench.py): with its default solver set
+MIOpen answers the first call of every new 3-D conv shape with `naive_conv_ab_nonpacked_fwd_ncdhw` — 435 s for
+the first decode, 17.7 s for every later one.  With the naive solver masked out it picks the CK implicit-GEMM
+kernels straight away: 2.6 s first call, 2.1 s after.  The mask is an environment switch read when MIOpen
+first runs a convolution, so it is set at import time here (``setdefault``: a user's own value wins).
+The 2 s need MIOpen's search ("find") results; they are obtained once per process (tens of seconds with the
+naive solver masked) by running the network under ``torch.backends.cudnn.flags(benchmark=True)`` — without
+them MIOpen's heuristic pick stays at 10.8 s per encode / 17.6 s per decode.
 """
 
 from __future__ import annotations
 
 import glob
+import os
+
+os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "0")
 from typing import List, Sequence, Tuple
 
 import torch
@@ -225,8 +237,20 @@ class WanVAE:
     def __init__(self, net: WanVAENet, device, dtype=torch.bfloat16):
         self.net, self.device, self.dtype = net.to(device=device, dtype=dtype).eval(), device, dtype
 
-    @torch.no_grad()
-    def encode(self, video, tiled=True, tile_size=(30, 52), tile_stride=(15, 26), **unused):
+    @staticmethod
+    def _searched_kernels():
+        """MIOpen find mode for the conv kernels (see the module docstring); a no-op on CPU."""
+        return torch.backends.cudnn.flags(enabled=True, benchmark=True)
+
+    def encode(self, video, *args, **kwargs):
+        with torch.no_grad(), self._searched_kernels():
+            return self._encode(video, *args, **kwargs)
+
+    def decode(self, latent, *args, **kwargs):
+        with torch.no_grad(), self._searched_kernels():
+            return self._decode(latent, *args, **kwargs)
+
+    def _encode(self, video, tiled=True, tile_size=(30, 52), tile_stride=(15, 26), **unused):
         x = video[None].to(device=self.device, dtype=self.dtype)
         _, _, F_, H, W = x.shape
         if not tiled:
@@ -243,8 +267,7 @@ class WanVAE:
             wts[:, :, :, h0 // 8: h0 // 8 + z.shape[3], w0 // 8: w0 // 8 + z.shape[4]] += m
         return (vals / wts)[0]
 
-    @torch.no_grad()
-    def decode(self, latent, tiled=True, tile_size=(30, 52), tile_stride=(15, 26), **unused):
+    def _decode(self, latent, tiled=True, tile_size=(30, 52), tile_stride=(15, 26), **unused):
         z = latent[None].to(device=self.device, dtype=self.dtype)
         _, _, T, H, W = z.shape
         if not tiled:

@@ -1,7 +1,7 @@
 # full GPU check: smoke + all -m gpu tests + both bench configs; results under gpurun_out/
 mkdir -p gpurun_out; export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -3
+timeout 1200 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|^FAILED|^ERROR" | tail -8
 python bench.py --model 1.3b --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_1p3b.json 2> gpurun_out/bench_1p3b.err || tail -5 gpurun_out/bench_1p3b.err
 python bench.py > gpurun_out/bench_14b.json 2> gpurun_out/bench_14b.err || tail -5 gpurun_out/bench_14b.err
 python - <<'PY'
