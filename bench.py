@@ -32,7 +32,7 @@ from infinicube_amd.videogen.config import GRID_480P, TokenGrid, dit_forward_flo
 from infinicube_amd.videogen.dit import WanDiT  # noqa: E402
 from infinicube_amd.videogen.ops import HipOps  # noqa: E402
 from infinicube_amd.videogen.scheduler import FlowMatchScheduler  # noqa: E402
-from infinicube_amd.videogen.seqpar import ShardPlan  # noqa: E402
+from infinicube_amd.videogen.seqpar import BranchExchange, ParallelLayout  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 CFG_SCALE = 5.0
@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--width", type=int, default=GRID_480P.width)
     ap.add_argument("--sp-chunks", type=int, default=int(os.environ.get("ICV_SP_CHUNKS", "4")),
                     help="N>1: the per-layer K/V all-gather is pipelined with attention in this many chunks")
+    ap.add_argument("--parallelism", default=os.environ.get("ICV_PARALLELISM", "auto"), choices=["auto", "sp", "cfg+sp"],
+                    help="N>1: 'sp' = token shards over all N ranks, both CFG forwards on every rank; 'cfg+sp' = cond / "
+                         "uncond forwards on two groups of N/2 ranks, token shards inside a group (auto when N is even)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -125,7 +128,8 @@ def main():
 
     cfg = preset(args.model)
     grid = TokenGrid(args.frames, args.height, args.width)
-    plan = ShardPlan.make(grid.S, world, rank)
+    layout = ParallelLayout.make(world, rank, args.parallelism, use_cfg=True)
+    plan = layout.shard_plan(grid.S)
     ops = HipOps(device)
 
     # ---- synthetic weights / inputs, resident in HBM before timing (SURVEY.md §8d recipe) ----
@@ -133,7 +137,7 @@ def main():
     bsd = syn.make_buffer_embedder_state_dict(cfg, device=device, dtype=torch.bfloat16)
     model = WanDiT(cfg, sd, ops, bsd, gemm_dtype=args.gemm_dtype)
     del sd, bsd
-    model.prepare(grid, plan, sp_chunks=args.sp_chunks)
+    model.prepare(grid, plan, sp_chunks=args.sp_chunks, group=layout.sp_group)
     clip = syn.make_clip_features(cfg) if cfg.has_image_input else None
     ctx_c = model.encode_context(syn.make_text_context(cfg, 1), clip)
     ctx_u = model.encode_context(syn.make_text_context(cfg, 2), clip)
@@ -181,9 +185,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    xchg = BranchExchange(layout) if layout.mode == "cfg+sp" else None
+
     def run_steps(first, count):
-        model.denoise(latent, ctx_c, ctx_u, buf, sched, CFG_SCALE,
-                      steps=[(first + i) % total_steps for i in range(count)])
+        model.denoise(latent, ctx_c if layout.branch in (None, 0) else None, ctx_u if layout.branch in (None, 1) else None,
+                      buf, sched, CFG_SCALE, steps=[(first + i) % total_steps for i in range(count)], branch_exchange=xchg)
 
     run_steps(0, args.warmup)
     sync()
@@ -233,7 +239,11 @@ def main():
                             f"S={grid.S} tokens, 1 step = 2 DiT forwards (cond+uncond, cfg {CFG_SCALE}) + Euler; "
                             f"50-step flow-match schedule (shift 5)",
                 "model": cfg.name, "gemm_dtype": args.gemm_dtype, "tokens": grid.S, "layers": cfg.num_layers, "dim": cfg.dim,
-                "parallelism": f"sp{world} (token-sequence shards, K/V all-gather in {args.sp_chunks} chunks overlapped with attention)" if world > 1 else "single-gpu",
+                "parallelism": "single-gpu" if world == 1 else (
+                    f"sp{world} (token-sequence shards over all ranks, K/V all-gather in {args.sp_chunks} chunks overlapped with attention)"
+                    if layout.mode == "sp" else
+                    f"cfg2 x sp{layout.sp_world} (cond / uncond forwards on two groups of {layout.sp_world} ranks; token-sequence shards and "
+                    f"K/V all-gather in {args.sp_chunks} chunks inside a group; one velocity swap per step between the groups)"),
                 "wallclock_50_steps_s": 50.0 * elapsed / args.steps,
                 "algorithmic_pflop_per_step": f_step / 1e15,
                 "model_tflops_all_gpus": f_step * args.steps / elapsed / 1e12,

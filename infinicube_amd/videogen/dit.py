@@ -40,7 +40,7 @@ import torch
 from .config import TokenGrid, WanDiTConfig
 from .ops import BF16, EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_F32, F32, FP8, RopeTable
 from .scheduler import FlowMatchScheduler
-from .seqpar import KVGather, ShardPlan, chunk_bounds
+from .seqpar import BranchExchange, KVGather, ShardPlan, chunk_bounds  # noqa: F401
 
 ACT_SILU = 1
 
@@ -192,8 +192,10 @@ class WanDiT:
         self.buffer_embedder = convs
 
     # ------------------------------------------------------------------------------------
-    def prepare(self, grid: TokenGrid, plan: Optional[ShardPlan] = None, kv_gather=None, sp_chunks: int = 4):
-        """Allocate the per-generation workspace for this token grid / shard."""
+    def prepare(self, grid: TokenGrid, plan: Optional[ShardPlan] = None, kv_gather=None, sp_chunks: int = 4,
+                group=None):
+        """Allocate the per-generation workspace for this token grid / shard.  ``group`` = the process group the
+        K/V all-gather runs in (seqpar.ParallelLayout.sp_group; None = the default group)."""
         cfg, ops = self.cfg, self.ops
         self.grid = grid
         self.plan = plan or ShardPlan.make(grid.S)
@@ -214,6 +216,7 @@ class WanDiT:
             self.ff8, self.ff8s = a((n, cfg.ffn_dim), FP8), a((n,), F32)
         self.patches = torch.zeros((n, self.k_patch), dtype=BF16, device=ops.device)
         self.head_out = a((2, n, cfg.out_dim * cfg.patch_elems), F32)
+        self.head_own = a((n, cfg.out_dim * cfg.patch_elems), F32)   # cfg+sp: this rank's branch before the swap
         self.mod = a((cfg.num_layers, 6 * d), F32)
         self.hmod = a((2, d), F32)
         self.t_sin = a((1, cfg.freq_dim), F32)
@@ -226,7 +229,7 @@ class WanDiT:
             self.sp_acc = a((n, d), F32)                           # carried O accumulator between key chunks
             self.sp_ml = a((n, cfg.num_heads, 2), F32)             # carried (running max, row sum)
             self.sp_bounds = chunk_bounds(n, sp_chunks)
-            self.kv_gather = kv_gather or KVGather(self.plan)
+            self.kv_gather = kv_gather or KVGather(self.plan, group)
         else:
             self.kv_full, self.kv_gather = None, None
         return self
@@ -412,12 +415,28 @@ class WanDiT:
         ops.gemm(self.h, self.head_w, self.head_b, head_out, EPI_F32)
 
     # ------------------------------------------------------------------------------------
-    def denoise(self, latent: torch.Tensor, ctx_cond: ContextKV, ctx_uncond: Optional[ContextKV],
+    def denoise(self, latent: torch.Tensor, ctx_cond: Optional[ContextKV], ctx_uncond: Optional[ContextKV],
                 buf_tokens: Optional[torch.Tensor], scheduler: FlowMatchScheduler,
-                cfg_scale: float = 5.0, steps: Optional[range] = None, on_step=None) -> torch.Tensor:
+                cfg_scale: float = 5.0, steps: Optional[range] = None, on_step=None,
+                branch_exchange=None) -> torch.Tensor:
         """The hot loop: per step 2 DiT forwards (cond, uncond) + fused unpatchify/CFG/Euler.
-        ``latent`` f32 [C,T,H8,W8] is updated IN PLACE for this rank's tokens."""
+        ``latent`` f32 [C,T,H8,W8] is updated IN PLACE for this rank's tokens.
+        ``branch_exchange`` (seqpar.BranchExchange, cfg+sp layout): this rank runs ONE forward per step — the
+        cond one if it was given ``ctx_cond`` only, the uncond one if ``ctx_uncond`` only — and swaps velocity
+        tokens with the rank that runs the other branch on the same token shard."""
         ops, plan = self.ops, self.plan
+        if branch_exchange is not None:
+            if (ctx_cond is None) == (ctx_uncond is None) or cfg_scale == 1.0:
+                raise ValueError("cfg+sp: pass exactly one of ctx_cond / ctx_uncond and a cfg_scale != 1")
+            own_ctx = ctx_cond if ctx_cond is not None else ctx_uncond
+            for i in (steps if steps is not None else range(len(scheduler.sigmas))):
+                self.forward_tokens(latent, own_ctx, scheduler.timesteps[i], buf_tokens, self.head_own)
+                branch_exchange(self.head_own, self.head_out)           # slot 0 = cond, slot 1 = uncond
+                ops.unpatchify_cfg_euler(latent, self.head_out[0], self.head_out[1], cfg_scale,
+                                         scheduler.dsigma(i), plan.tok0, plan.n_tok)
+                if on_step is not None:
+                    on_step(i, latent)
+            return latent
         use_cfg = ctx_uncond is not None and cfg_scale != 1.0
         for i in (steps if steps is not None else range(len(scheduler.sigmas))):
             ts = scheduler.timesteps[i]

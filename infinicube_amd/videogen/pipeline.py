@@ -30,7 +30,7 @@ from PIL import Image
 from .config import TokenGrid, WanDiTConfig, infer_config_from_state_dict
 from .io import load_sharded_state_dict
 from .scheduler import FlowMatchScheduler
-from .seqpar import ShardPlan, gather_latent
+from .seqpar import BranchExchange, ParallelLayout, gather_latent
 
 _IncompatibleKeys = namedtuple("_IncompatibleKeys", ["missing_keys", "unexpected_keys"])
 
@@ -162,6 +162,9 @@ class WanVideoPipeline:
         # projections (BASELINE.json config #5).  Anything else = bf16, the reference's setting
         # [R infinicube/inference/guidance_buffer_generation.py:762].
         self.gemm_dtype = "fp8" if torch_dtype == torch.float8_e4m3fn else "bf16"
+        # multi-GPU layout when torch.distributed is initialised (seqpar.ParallelLayout): "auto" | "sp" | "cfg+sp"
+        self.parallelism = "auto"
+        self._layouts = {}
         self.torch_dtype = torch_dtype
         self.dit = dit
         self.text_encoder = text_encoder
@@ -270,8 +273,12 @@ class WanVideoPipeline:
                 world, rank = dist.get_world_size(), dist.get_rank()
         except Exception:  # pragma: no cover
             pass
-        plan = ShardPlan.make(grid.S, world, rank)
-        engine.prepare(grid, plan)
+        lkey = (world, rank, self.parallelism, cfg_scale != 1.0)
+        if lkey not in self._layouts:   # process groups are created once per (world, mode)
+            self._layouts[lkey] = ParallelLayout.make(world, rank, self.parallelism, use_cfg=cfg_scale != 1.0)
+        layout = self._layouts[lkey]
+        plan = layout.shard_plan(grid.S)
+        engine.prepare(grid, plan, group=layout.sp_group)
         self.scheduler = FlowMatchScheduler(num_inference_steps, sigma_shift)
         # i2v (BASELINE.json config #5): CLIP tokens + conditioning latent of the first frame, once per call
         i2v = engine.cfg.has_image_input
@@ -283,8 +290,11 @@ class WanVideoPipeline:
         elif input_image is not None:
             raise ValueError("input_image given but the loaded DiT is text-to-video")
         # text (cond / uncond), once per prompt
-        ctx_c = engine.encode_context(self.text_encoder.encode(prompt), clip_fea)
-        ctx_u = engine.encode_context(self.text_encoder.encode(negative_prompt), clip_fea) if cfg_scale != 1.0 else None
+        ctx_c = ctx_u = None
+        if layout.branch in (None, 0):
+            ctx_c = engine.encode_context(self.text_encoder.encode(prompt), clip_fea)
+        if cfg_scale != 1.0 and layout.branch in (None, 1):
+            ctx_u = engine.encode_context(self.text_encoder.encode(negative_prompt), clip_fea)
         # noise: CPU generator, fp32 (rand_device='cpu' upstream) -> identical across devices/ranks
         g = torch.Generator(device="cpu")
         if seed is not None:
@@ -308,8 +318,9 @@ class WanVideoPipeline:
         it = range(num_inference_steps)
         if progress_bar_cmd is not None:
             it = progress_bar_cmd(it)
-        engine.denoise(latent, ctx_c, ctx_u, buf_tokens, self.scheduler, cfg_scale, steps=it)
-        latent = gather_latent(latent, plan, grid)
+        engine.denoise(latent, ctx_c, ctx_u, buf_tokens, self.scheduler, cfg_scale, steps=it,
+                       branch_exchange=BranchExchange(layout) if layout.mode == "cfg+sp" else None)
+        latent = gather_latent(latent, plan, grid, group=layout.sp_group)
         if return_latents:
             return latent
         video = self.vae.decode(latent, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride)

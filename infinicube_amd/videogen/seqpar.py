@@ -35,6 +35,70 @@ class ShardPlan:
         return ShardPlan(world, rank, S, rank * n, n)
 
 
+@dataclass
+class ParallelLayout:
+    """How ``world`` ranks split one generation.
+
+    ``sp``     : every rank owns S/world tokens and runs BOTH CFG forwards (cond, uncond); K/V all-gather over
+                 all ranks, 2 x L gathers per step.
+    ``cfg+sp`` : the ranks form two branch groups of world/2 — group 0 runs the cond forward, group 1 the uncond
+                 forward — and the token sequence is sharded over the world/2 ranks of a group.  Same FLOPs per
+                 rank, but only L gathers per step, over half as many peers, each hidden under an attention that
+                 is twice as long; at world == 2 there is no K/V exchange at all.  The two ranks that own the same
+                 token shard (rank r and r + world/2) swap their [n_tok, 64] velocity tokens once per step (a few
+                 MB) and both apply the same CFG + Euler update, so their latents stay bit-identical.
+    xGMI is point-to-point (7 links per GPU): fewer, larger exchanges among fewer peers is the layout that
+    suits it, so ``auto`` picks ``cfg+sp`` whenever CFG is on and ``world`` is even.
+    """
+    world: int
+    rank: int
+    mode: str                 # "sp" | "cfg+sp"
+    sp_world: int
+    sp_rank: int
+    branch: Optional[int]     # cfg+sp: 0 = cond, 1 = uncond; sp: None (both)
+    sp_group: object = None   # process group of the ranks sharing this rank's branch (None = default group)
+    pair_group: object = None  # cfg+sp: (cond rank, uncond rank) owning the same token shard
+
+    @staticmethod
+    def make(world: int = 1, rank: int = 0, mode: str = "auto", use_cfg: bool = True, init_groups: bool = True) -> "ParallelLayout":
+        if mode not in ("auto", "sp", "cfg+sp"):
+            raise ValueError(f"parallelism must be 'auto', 'sp' or 'cfg+sp', got {mode!r}")
+        if mode == "auto":
+            mode = "cfg+sp" if (use_cfg and world % 2 == 0) else "sp"
+        if mode == "cfg+sp" and (world % 2 or not use_cfg):
+            raise ValueError("cfg+sp needs an even number of ranks and classifier-free guidance switched on")
+        if mode == "sp" or world == 1:
+            return ParallelLayout(world, rank, "sp", world, rank, None)
+        half = world // 2
+        lay = ParallelLayout(world, rank, "cfg+sp", half, rank % half, rank // half)
+        if init_groups:
+            import torch.distributed as dist
+            # every rank must create every group, in the same order
+            sp_groups = [dist.new_group(list(range(b * half, (b + 1) * half))) for b in range(2)]
+            pair_groups = [dist.new_group([i, i + half]) for i in range(half)]
+            lay.sp_group, lay.pair_group = sp_groups[lay.branch], pair_groups[lay.sp_rank]
+        return lay
+
+    def shard_plan(self, S: int) -> "ShardPlan":
+        return ShardPlan.make(S, self.sp_world, self.sp_rank)
+
+
+class BranchExchange:
+    """cfg+sp: once per step the cond rank and the uncond rank of a token shard swap velocity tokens.
+    ``own`` f32 [n, c] (this rank's branch) -> ``both`` f32 [2, n, c] with slot 0 = cond, slot 1 = uncond
+    (the pair group lists the cond rank first, so an all-gather lands them in that order)."""
+
+    def __init__(self, layout: ParallelLayout):
+        if layout.mode != "cfg+sp":
+            raise ValueError("BranchExchange is only meaningful for the cfg+sp layout")
+        import torch.distributed as dist
+        self.dist, self.group, self.branch = dist, layout.pair_group, layout.branch
+
+    def __call__(self, own: torch.Tensor, both: torch.Tensor) -> None:
+        assert own.is_contiguous() and both.is_contiguous() and both.shape[0] == 2 and both.shape[1:] == own.shape
+        self.dist.all_gather_into_tensor(both.view(2 * own.shape[0], *own.shape[1:]), own, group=self.group)
+
+
 class KVGather:
     """Chunked, asynchronous all-gather of the local K and V shards.
 

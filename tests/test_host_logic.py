@@ -13,7 +13,7 @@ from infinicube_amd.videogen import synthetic as syn
 from infinicube_amd.videogen.config import TokenGrid, preset
 from infinicube_amd.videogen.dit import WanDiT
 from infinicube_amd.videogen.scheduler import FlowMatchScheduler
-from infinicube_amd.videogen.seqpar import KVGather, ShardPlan, gather_latent
+from infinicube_amd.videogen.seqpar import BranchExchange, KVGather, ParallelLayout, ShardPlan, gather_latent
 from oracle import wan_ref as R
 from oracle_ops import OracleOps
 
@@ -217,3 +217,67 @@ def test_gloo_world2_sequence_parallel_equals_single():
     # vs the single-process run: same math per token, but CPU GEMM blocking differs with the row count,
     # and a 1e-7 difference can flip a bf16 storage rounding -> compare to rounding, not bitwise
     assert float((got[0] - ref).norm() / ref.norm()) < 2e-3 and R.psnr(got[0], ref) > 55.0
+
+
+def test_parallel_layout_arithmetic():
+    lay = ParallelLayout.make(8, 5, "auto", use_cfg=True, init_groups=False)
+    assert (lay.mode, lay.sp_world, lay.sp_rank, lay.branch) == ("cfg+sp", 4, 1, 1)
+    assert lay.shard_plan(37440).n_tok == 9360 and lay.shard_plan(37440).tok0 == 9360
+    assert ParallelLayout.make(8, 5, "sp").sp_world == 8 and ParallelLayout.make(8, 5, "sp").branch is None
+    assert ParallelLayout.make(3, 1, "auto").mode == "sp"                       # odd world: plain token shards
+    assert ParallelLayout.make(4, 1, "auto", use_cfg=False).mode == "sp"        # no CFG: nothing to split
+    assert ParallelLayout.make(1, 0, "auto").mode == "sp"
+    with pytest.raises(ValueError, match="even"):
+        ParallelLayout.make(3, 0, "cfg+sp")
+    with pytest.raises(ValueError, match="parallelism"):
+        ParallelLayout.make(2, 0, "tp")
+
+
+def _layout_worker(rank, world, port, q, mode):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        sd, bsd, noise, c1, c2, bl = _inputs()
+        lay = ParallelLayout.make(world, rank, mode)
+        plan = lay.shard_plan(GRID.S)
+        m = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID, plan, group=lay.sp_group)
+        lat = noise.clone()
+        if lay.mode == "cfg+sp":
+            m.denoise(lat, m.encode_context(c1) if lay.branch == 0 else None, m.encode_context(c2) if lay.branch == 1 else None,
+                      m.embed_buffers(bl), FlowMatchScheduler(3), 5.0, branch_exchange=BranchExchange(lay))
+        else:
+            m.denoise(lat, m.encode_context(c1), m.encode_context(c2), m.embed_buffers(bl), FlowMatchScheduler(3), 5.0)
+        lat = gather_latent(lat, plan, GRID, group=lay.sp_group)
+        q.put((rank, lat))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode", [(2, "cfg+sp"), (4, "cfg+sp")])
+def test_gloo_cfg_branch_parallel_equals_single(world, mode):
+    """cfg+sp layout over real processes (gloo): world 2 = one rank per CFG branch and no K/V exchange; world 4 =
+    two branch groups x two token shards (group-local K/V all-gather + the per-step velocity swap)."""
+    sd, bsd, noise, c1, c2, bl = _inputs()
+    single = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID)
+    ref = noise.clone()
+    single.denoise(ref, single.encode_context(c1), single.encode_context(c2), single.embed_buffers(bl), FlowMatchScheduler(3), 5.0)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() + 7 * world) % 2000
+    procs = [ctx.Process(target=_layout_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(1, world):
+        assert torch.equal(got[0], got[r]), f"rank {r} ended with a different latent than rank 0"
+    if world == 2:      # no sharding at all: per-token math identical to the single-process run
+        assert float((got[0] - ref).norm() / ref.norm()) < 1e-5
+    assert float((got[0] - ref).norm() / ref.norm()) < 2e-3 and R.psnr(got[0], ref) > 55.0
+    with pytest.raises(ValueError, match="exactly one"):
+        single.denoise(ref, single.encode_context(c1), single.encode_context(c2), single.embed_buffers(bl), FlowMatchScheduler(1), 5.0,
+                       branch_exchange=lambda a, b: None)
