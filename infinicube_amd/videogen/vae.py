@@ -29,6 +29,7 @@ them MIOpen's heuristic pick stays at 10.8 s per encode / 17.6 s per decode.
 
 from __future__ import annotations
 
+import contextlib
 import glob
 import os
 
@@ -238,9 +239,15 @@ class WanVAE:
         self.net, self.device, self.dtype = net.to(device=device, dtype=dtype).eval(), device, dtype
 
     @staticmethod
+    @contextlib.contextmanager
     def _searched_kernels():
         """MIOpen find mode for the conv kernels (see the module docstring); a no-op on CPU."""
-        return torch.backends.cudnn.flags(enabled=True, benchmark=True)
+        prev = torch.backends.cudnn.benchmark
+        torch.backends.cudnn.benchmark = True
+        try:
+            yield
+        finally:
+            torch.backends.cudnn.benchmark = prev
 
     def encode(self, video, *args, **kwargs):
         with torch.no_grad(), self._searched_kernels():

@@ -1,0 +1,73 @@
+"""End-to-end wall-clock of WanVideoGenerator.generate() on ONE MI355X — the quantity the reference publishes
+("about 20 minutes" for one 93-frame 480p video with Wan2.1-14B on one A100, weight loading excluded
+[R README.md:65]).  Random-init weights of the real architectures everywhere (no checkpoints exist offline):
+14B DiT + non-zero buffer embedder on the HIP path, UMT5-XXL encoder and Wan-VAE on stock PyTorch-ROCm, a
+hash tokenizer in place of the sentencepiece model.  env: MODEL=14b|1.3b  STEPS=50  GEMM=bf16|fp8"""
+import hashlib, json, os, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from safetensors.torch import save_file
+
+from infinicube_amd.videogen import synthetic as syn
+from infinicube_amd.videogen.config import GRID_480P, preset
+from infinicube_amd.videogen.inference import WanVideoGenerator
+from infinicube_amd.videogen.pipeline import DiTHolder, WanVideoPipeline
+from infinicube_amd.videogen.text_encoder import UMT5Encoder, UMT5TextEncoder
+from infinicube_amd.videogen.vae import WanVAE, WanVAENet
+
+model, steps = os.environ.get("MODEL", "14b"), int(os.environ.get("STEPS", 50))
+dtype = torch.float8_e4m3fn if os.environ.get("GEMM", "bf16") == "fp8" else torch.bfloat16
+cfg, grid, dev = preset(model), GRID_480P, "cuda:0"
+
+
+class HashTokenizer:
+    def __call__(self, texts, max_length=512, **kw):
+        ids = torch.zeros((1, max_length), dtype=torch.long)
+        words = texts[0].split()[: max_length - 1]
+        for i, w in enumerate(words):
+            ids[0, i] = 3 + int.from_bytes(hashlib.sha256(w.encode()).digest()[:4], "little") % 250000
+        ids[0, len(words)] = 1
+        mask = torch.zeros((1, max_length), dtype=torch.long)
+        mask[0, : len(words) + 1] = 1
+        return {"input_ids": ids, "attention_mask": mask}
+
+
+t0 = time.perf_counter()
+sd = syn.make_dit_state_dict(cfg, seed=0, device=dev, dtype=torch.bfloat16)
+bsd = syn.make_buffer_embedder_state_dict(cfg)
+ck = os.path.join(tempfile.mkdtemp(), "step-1.safetensors")
+save_file({"buffer_embedder." + k: v for k, v in bsd.items()}, ck)
+with torch.device(dev):
+    t5 = UMT5Encoder().to(torch.bfloat16).eval()
+vae = WanVAE(WanVAENet(), dev, torch.bfloat16)
+
+
+def factory(torch_dtype, device, model_configs):
+    return WanVideoPipeline(device, torch_dtype, DiTHolder(sd, cfg), UMT5TextEncoder(t5, HashTokenizer(), dev), vae)
+
+
+gen = WanVideoGenerator(ck, device=dev, torch_dtype=dtype, use_wan_1pt3b=(model == "1.3b"), pipeline_factory=factory)
+torch.cuda.synchronize()
+print(f"setup (random weights, not part of the metric): {time.perf_counter() - t0:.1f} s", flush=True)
+sem, co = syn.make_dummy_buffers(grid)
+marks = {}
+
+
+def timed(label, n_steps):
+    gen.pipe.num_inference_steps = n_steps
+    torch.cuda.synchronize(); t = time.perf_counter()
+    frames = gen.generate(semantic_buffer=sem, coordinate_buffer=co, seed=0, tiled=True)
+    torch.cuda.synchronize(); marks[label] = time.perf_counter() - t
+    assert len(frames) == grid.num_frames and frames[0].size == (grid.width, grid.height)
+    print(f"{label}: {marks[label]:.1f} s", flush=True)
+
+
+timed("first call, 2 steps (MIOpen search + first-use costs)", 2)
+timed(f"generate() {steps} steps", steps)
+out = {"model": cfg.name, "gemm_dtype": os.environ.get("GEMM", "bf16"), "frames": grid.num_frames, "height": grid.height, "width": grid.width,
+       "steps": steps, "generate_wallclock_s": marks[f"generate() {steps} steps"],
+       "first_call_2_steps_s": marks["first call, 2 steps (MIOpen search + first-use costs)"],
+       "reference_published": "about 20 minutes on 1x A100, Wan2.1-14B, weight loading excluded [R README.md:65]",
+       "peak_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30}
+print(json.dumps(out))
