@@ -53,16 +53,19 @@ def describe_checkpoint(path: str) -> Dict[str, Dict[str, tuple]]:
 
 
 def save_video(frames: List, save_path: str, fps: int = 10, quality: int = 8) -> None:
-    """mp4 (libx264 through imageio-ffmpeg, like diffsynth's save_video).  imageio is part of the
-    reference's environment; if it is absent here this raises instead of silently writing nothing,
-    because stage 3 reads the file [R infinicube/inference/scene_gaussian_generation.py:290-293]."""
+    """mp4 at ``save_path`` (stage 3 reads it back [R infinicube/inference/scene_gaussian_generation.py:290-293]).
+    With imageio installed — it is part of the reference's environment — this is libx264 through imageio-ffmpeg,
+    like diffsynth's save_video.  Without it the file is written by the built-in Motion-JPEG muxer
+    (``mp4mux.write_mjpeg_mp4``: same container, fps and frame count, intra-only codec) and a line says so."""
+    os.makedirs(os.path.dirname(os.path.abspath(save_path)), exist_ok=True)
     try:
         import imageio
-    except ImportError as e:
-        raise RuntimeError(
-            f"save_video({save_path!r}): the 'imageio' (+ imageio-ffmpeg) package is required to write mp4") from e
+    except ImportError:
+        from .mp4mux import write_mjpeg_mp4
+        print(f"  (imageio not installed: writing {save_path} as Motion-JPEG mp4 instead of libx264)")
+        write_mjpeg_mp4(frames, save_path, fps=fps, quality=quality)
+        return
     import numpy as np
-    os.makedirs(os.path.dirname(os.path.abspath(save_path)), exist_ok=True)
     writer = imageio.get_writer(save_path, fps=fps, quality=quality)
     try:
         for fr in frames:

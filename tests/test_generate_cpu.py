@@ -157,3 +157,23 @@ def test_fp8_torch_dtype_selects_fp8_projections():
     assert not pipe._engine.fp8
     rel = float((l8 - l16).norm() / l16.norm())
     assert 0 < rel < 0.1, f"fp8 vs bf16 latents rel-L2 {rel}"
+
+
+def test_checkpoint_inventory(tmp_path, capsys):
+    """Counterpart of the reference's download script: the same six (model_id, pattern) entries, present / missing,
+    and the architecture implied by a DiT shard's tensor shapes."""
+    from infinicube_amd.videogen import download_checkpoint as dc
+    assert [(m, p) for m, p, _ in dc.REQUIRED][4:] == [
+        ("Wan-AI/Wan2.1-I2V-14B-480P", "diffusion_pytorch_model*.safetensors"),
+        ("Wan-AI/Wan2.1-I2V-14B-480P", "models_clip_open-clip-xlm-roberta-large-vit-huge-14.pth")]
+    root = tmp_path / "models"
+    d = root / "Wan-AI" / "Wan2.1-I2V-14B-480P"
+    d.mkdir(parents=True)
+    sd = syn.make_dit_state_dict(preset("tiny-i2v"))
+    keys = sorted(sd)
+    save_file({k: sd[k].contiguous() for k in keys[: len(keys) // 2]}, str(d / "diffusion_pytorch_model-00001-of-00002.safetensors"))
+    save_file({k: sd[k].contiguous() for k in keys[len(keys) // 2:]}, str(d / "diffusion_pytorch_model-00002-of-00002.safetensors"))
+    rc = dc.main(["--models-root", str(root), "--inspect"])
+    out = capsys.readouterr().out
+    assert rc == 1 and out.count("MISSING") == 5 and "2 file(s)" in out
+    assert "in_dim 36, image branch (64)" in out
