@@ -122,12 +122,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one process per GPU.  ICV_BENCH_SHARE_GPU=1 (+ ICV_DIST_BACKEND=gloo) lets several ranks share the only GPU of a
+    # development box so the N>1 code path can be exercised there; it is never a measurement mode.
+    share = os.environ.get("ICV_BENCH_SHARE_GPU", "0") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        backend = os.environ.get("ICV_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm
+        dist.init_process_group(backend=backend, **({"device_id": device} if backend == "nccl" else {}))
 
     cfg = preset(args.model)
     grid = TokenGrid(args.frames, args.height, args.width)
