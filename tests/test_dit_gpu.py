@@ -136,15 +136,22 @@ def test_fp8_gemm_mode_forward_and_loop(hip_ops):
     assert p8 >= 40.0, f"fp8 loop PSNR vs fake-quant oracle {p8:.1f} dB < 40 dB"
 
 
-@pytest.mark.parametrize("chunks", [1, 3])
-def test_sequence_parallel_path_on_one_gpu(hip_ops, chunks):
+@pytest.mark.parametrize("chunks,model,gemm_dtype", [(1, "tiny", "bf16"), (3, "tiny", "bf16"), (3, "tiny-i2v", "fp8")])
+def test_sequence_parallel_path_on_one_gpu(hip_ops, chunks, model, gemm_dtype):
     """The world>1 code path (token shards, RoPE offsets, chunked K/V gather feeding the carried-state
     attention kernel, per-shard Euler update) driven on ONE GPU: two shard engines run with a stand-in
     for the RCCL all-gather that serves the other shard's K/V rows from the unsharded run."""
     from infinicube_amd.videogen.seqpar import ShardPlan
     grid = TokenGrid(9, 64, 96)
-    cfg, sd, bsd, _, _ = _setup("tiny", grid)
+    cfg, sd, bsd, _, _ = _setup(model, grid)
     noise, ctx, bl = syn.make_latent_noise(grid), syn.make_text_context(cfg, 1), syn.make_buffer_latents(cfg, grid)
+    clip = syn.make_clip_features(cfg) if cfg.has_image_input else None
+    ycond = syn.make_cond_latents(cfg, grid) if cfg.has_image_input else None
+
+    def additive(mm):
+        bt = mm.embed_buffers(bl)
+        return mm.embed_cond_latents(ycond, add_to=bt) if ycond is not None else bt
+
     rec = []
     raw = hip_ops.attention
 
@@ -155,9 +162,9 @@ def test_sequence_parallel_path_on_one_gpu(hip_ops, chunks):
 
     hip_ops.attention = recording_attention
     try:
-        full = WanDiT(cfg, sd, hip_ops, bsd).prepare(grid)
+        full = WanDiT(cfg, sd, hip_ops, bsd, gemm_dtype=gemm_dtype).prepare(grid)
         lat = noise.to("cuda:0")
-        full.forward_tokens(lat, full.encode_context(ctx), 300.0, full.embed_buffers(bl), full.head_out[0])
+        full.forward_tokens(lat, full.encode_context(ctx, clip), 300.0, additive(full), full.head_out[0])
         torch.cuda.synchronize()
     finally:
         hip_ops.attention = raw
@@ -191,8 +198,8 @@ def test_sequence_parallel_path_on_one_gpu(hip_ops, chunks):
             def wait(self, handle):
                 pass
 
-        m = WanDiT(cfg, sd, hip_ops, bsd).prepare(grid, plan, kv_gather=FakeGather(), sp_chunks=chunks)
-        m.forward_tokens(lat, m.encode_context(ctx), 300.0, m.embed_buffers(bl), m.head_out[0])
+        m = WanDiT(cfg, sd, hip_ops, bsd, gemm_dtype=gemm_dtype).prepare(grid, plan, kv_gather=FakeGather(), sp_chunks=chunks)
+        m.forward_tokens(lat, m.encode_context(ctx, clip), 300.0, additive(m), m.head_out[0])
         torch.cuda.synchronize()
         outs.append(m.head_out[0].clone())
     got, want = torch.cat(outs, 0), full.head_out[0]

@@ -122,12 +122,22 @@ def test_loop_matches_oracle_and_time_cache():
     assert R.psnr(lat1, ref1) > 50.0
 
 
-@pytest.mark.parametrize("chunks", [1, 3])
-def test_inprocess_two_shards_equal_unsharded(chunks):
-    """Simulate world=2 in one process: run both shards with a gather that concatenates their K/V."""
-    sd, bsd, noise, c1, _, bl = _inputs()
-    full = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID)
-    full.forward_tokens(noise.clone(), full.encode_context(c1), 300.0, full.embed_buffers(bl), full.head_out[0])
+@pytest.mark.parametrize("chunks,model,gemm_dtype", [(1, "tiny", "bf16"), (3, "tiny", "bf16"), (3, "tiny-i2v", "fp8")])
+def test_inprocess_two_shards_equal_unsharded(chunks, model, gemm_dtype):
+    """Simulate world=2 in one process: run both shards with a gather that concatenates their K/V.  The third case
+    shards the i2v DiT in fp8 mode (row-sliced quantised QKV weights, per-shard conditioning-latent tokens)."""
+    CFG = preset(model)
+    sd, bsd = syn.make_dit_state_dict(CFG), syn.make_buffer_embedder_state_dict(CFG)
+    noise, c1, bl = syn.make_latent_noise(GRID), syn.make_text_context(CFG, 1), syn.make_buffer_latents(CFG, GRID)
+    clip = syn.make_clip_features(CFG) if CFG.has_image_input else None
+    ycond = syn.make_cond_latents(CFG, GRID) if CFG.has_image_input else None
+
+    def additive(m):
+        bt = m.embed_buffers(bl)
+        return m.embed_cond_latents(ycond, add_to=bt) if ycond is not None else bt
+
+    full = WanDiT(CFG, sd, OracleOps(), bsd, gemm_dtype=gemm_dtype).prepare(GRID)
+    full.forward_tokens(noise.clone(), full.encode_context(c1, clip), 300.0, additive(full), full.head_out[0])
     # lock-step emulation: layer-by-layer is awkward, so exploit determinism — shard r's K/V for layer i
     # equal rows [tok0, tok0+n) of the unsharded K/V; capture them from the full run via a recording ops.
     rec = {}
@@ -138,8 +148,8 @@ def test_inprocess_two_shards_equal_unsharded(chunks):
                 rec.setdefault("kv", []).append((k.clone(), v.clone()))
             super().attention(q, k, v, o, heads, scale)
 
-    f2 = WanDiT(CFG, sd, RecOps(), bsd).prepare(GRID)
-    f2.forward_tokens(noise.clone(), f2.encode_context(c1), 300.0, f2.embed_buffers(bl), f2.head_out[0])
+    f2 = WanDiT(CFG, sd, RecOps(), bsd, gemm_dtype=gemm_dtype).prepare(GRID)
+    f2.forward_tokens(noise.clone(), f2.encode_context(c1, clip), 300.0, additive(f2), f2.head_out[0])
     outs = []
     for r in range(2):
         plan = ShardPlan.make(GRID.S, 2, r)
@@ -170,9 +180,9 @@ def test_inprocess_two_shards_equal_unsharded(chunks):
             def wait(self, handle):
                 pass
 
-        m = WanDiT(CFG, sd, OracleOps(), bsd)
+        m = WanDiT(CFG, sd, OracleOps(), bsd, gemm_dtype=gemm_dtype)
         m.prepare(GRID, plan, kv_gather=FakeGather(), sp_chunks=chunks)   # world>1 without torch.distributed
-        m.forward_tokens(noise.clone(), m.encode_context(c1), 300.0, m.embed_buffers(bl), m.head_out[0])
+        m.forward_tokens(noise.clone(), m.encode_context(c1, clip), 300.0, additive(m), m.head_out[0])
         outs.append(m.head_out[0].clone())
     got, want = torch.cat(outs, 0), full.head_out[0]
     # chunked online softmax reorders fp32 sums (and a flipped bf16 rounding can propagate): rounding-level
