@@ -304,6 +304,10 @@ int icv_attn3_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, c
                        int state_out, int64_t Sq, int64_t Skv, int64_t heads, float scale, int var,
                        hipStream_t st);
 
+int icv_attn6_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                       void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml, int state_in,
+                       int state_out, int64_t Sq, int64_t Skv, int64_t heads, float scale, int var,
+                       hipStream_t st);
 int icv_attn5_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                        void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml, int state_in,
                        int state_out, int64_t Sq, int64_t Skv, int64_t heads, float scale, int var,
@@ -322,6 +326,9 @@ extern "C" int icv_attention_fwd_chunk(const void* q, int64_t ldq, const void* k
   ICV_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0, "icv_attention_fwd_chunk: leading dims must keep 16-byte row alignment");
   ICV_REQUIRE((first && last) || (acc && ml && ldacc % 4 == 0), "icv_attention_fwd_chunk: carried state buffers required unless first && last");
   ICV_REQUIRE(!last || (o && ldo % 4 == 0), "icv_attention_fwd_chunk: output required for the last chunk");
+  if (icv_get_option_int("attn_kernel", 2) == 6)
+    return icv_attn6_dispatch(q, ldq, k, ldk, v, ldv, o, ldo, acc, ldacc, ml, first ? 0 : 1, last ? 0 : 1,
+                              Sq, Skv, heads, scale, icv_get_option_int("attn6_variant", 5), (hipStream_t)stream);
   if (icv_get_option_int("attn_kernel", 2) == 5)
     return icv_attn5_dispatch(q, ldq, k, ldk, v, ldv, o, ldo, acc, ldacc, ml, first ? 0 : 1, last ? 0 : 1,
                               Sq, Skv, heads, scale, 0, (hipStream_t)stream);
@@ -342,6 +349,9 @@ extern "C" int icv_attention_fwd(const void* q, int64_t ldq, const void* k, int6
   ICV_REQUIRE(q && k && v && o, "icv_attention_fwd: null pointer");
   ICV_REQUIRE(Sq > 0 && Skv > 0 && heads > 0, "icv_attention_fwd: empty problem (Sq=%lld Skv=%lld heads=%lld)", (long long)Sq, (long long)Skv, (long long)heads);
   ICV_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "icv_attention_fwd: leading dims must keep 16-byte row alignment");
+  if (icv_get_option_int("attn_kernel", 2) == 6)
+    return icv_attn6_dispatch(q, ldq, k, ldk, v, ldv, o, ldo, nullptr, 0, nullptr, 0, 0, Sq, Skv, heads, scale,
+                              icv_get_option_int("attn6_variant", 5), (hipStream_t)stream);
   if (icv_get_option_int("attn_kernel", 2) == 5)
     return icv_attn5_dispatch(q, ldq, k, ldk, v, ldv, o, ldo, nullptr, 0, nullptr, 0, 0, Sq, Skv, heads, scale, 0,
                               (hipStream_t)stream);

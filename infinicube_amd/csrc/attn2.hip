@@ -55,6 +55,12 @@ __global__ __launch_bounds__(512) void attn2_kernel(Params p) {
   // ---- staging: thread owns chunk sc0 of keys sk0 + 32u (u = 0..3) of the 128-key tile ----
   const int sk0 = tid >> 4, sc0 = tid & 15;
   uint4 kreg0, kreg1, kreg2, kreg3, vreg0, vreg1, vreg2, vreg3;
+  // Steady state: the tile base is wave-uniform (SGPR pair) and each thread adds a fixed 32-bit byte offset, so a
+  // tile costs 8 loads and no address VALU; only a partial last tile takes the clamped 64-bit path.  (The kernel
+  // is bound by the VALU issue port the MFMAs share — measured with s_memtime in attn6.hip — so every VALU
+  // instruction removed from the loop is MFMA issue time.)
+  const unsigned koff0 = (unsigned)(((int64_t)sk0 * p.ldk + sc0 * 8) * 2), kstep = (unsigned)(32 * p.ldk * 2);
+  const unsigned voff0 = (unsigned)(((int64_t)sk0 * p.ldv + sc0 * 8) * 2), vstep = (unsigned)(32 * p.ldv * 2);
 #define A2_LOAD_ROW(KR_, VR_, U_, T_)                                        \
   {                                                                          \
     int64_t kr_ = (int64_t)(T_) * KVB + sk0 + 32 * (U_);                     \
@@ -62,12 +68,25 @@ __global__ __launch_bounds__(512) void attn2_kernel(Params p) {
     KR_ = *reinterpret_cast<const uint4*>(kh + kr_ * p.ldk + sc0 * 8);       \
     VR_ = *reinterpret_cast<const uint4*>(vh + kr_ * p.ldv + sc0 * 8);       \
   }
-#define A2_LOAD_TILE(T_)                  \
-  {                                       \
-    A2_LOAD_ROW(kreg0, vreg0, 0, T_)      \
-    A2_LOAD_ROW(kreg1, vreg1, 1, T_)      \
-    A2_LOAD_ROW(kreg2, vreg2, 2, T_)      \
-    A2_LOAD_ROW(kreg3, vreg3, 3, T_)      \
+#define A2_LOAD_TILE(T_)                                                                       \
+  {                                                                                            \
+    if ((int64_t)((T_) + 1) * KVB <= p.Skv) {                                                  \
+      const char* kt_ = reinterpret_cast<const char*>(kh + (int64_t)(T_) * KVB * p.ldk);       \
+      const char* vt_ = reinterpret_cast<const char*>(vh + (int64_t)(T_) * KVB * p.ldv);       \
+      kreg0 = *reinterpret_cast<const uint4*>(kt_ + koff0);                                    \
+      vreg0 = *reinterpret_cast<const uint4*>(vt_ + voff0);                                    \
+      kreg1 = *reinterpret_cast<const uint4*>(kt_ + (koff0 + kstep));                          \
+      vreg1 = *reinterpret_cast<const uint4*>(vt_ + (voff0 + vstep));                          \
+      kreg2 = *reinterpret_cast<const uint4*>(kt_ + (koff0 + 2 * kstep));                      \
+      vreg2 = *reinterpret_cast<const uint4*>(vt_ + (voff0 + 2 * vstep));                      \
+      kreg3 = *reinterpret_cast<const uint4*>(kt_ + (koff0 + 3 * kstep));                      \
+      vreg3 = *reinterpret_cast<const uint4*>(vt_ + (voff0 + 3 * vstep));                      \
+    } else {                                                                                   \
+      A2_LOAD_ROW(kreg0, vreg0, 0, T_)                                                         \
+      A2_LOAD_ROW(kreg1, vreg1, 1, T_)                                                         \
+      A2_LOAD_ROW(kreg2, vreg2, 2, T_)                                                         \
+      A2_LOAD_ROW(kreg3, vreg3, 3, T_)                                                         \
+    }                                                                                          \
   }
   const int k_wr_off = sk0 * 256 + ((sc0 ^ (sk0 & 15)) << 4);
   const int v_wr_off = KT_BYTES + sk0 * 256 + ((sc0 << 4) ^ ((sk0 & 3) << 6));

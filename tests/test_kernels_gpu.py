@@ -369,7 +369,7 @@ def test_attention5(hip_ops):
         hip_ops.lib.icv_set_option(b"attn_kernel", 2)
 
 
-@pytest.mark.parametrize("kernel", [2, 3, 4, 5])
+@pytest.mark.parametrize("kernel", [2, 3, 4, 5, 6])
 @pytest.mark.parametrize("chunks", [[700], [128, 572], [300, 100, 300], [64, 64, 64, 508]])
 def test_attention_chunked_state(hip_ops, chunks, kernel):
     """Splitting the KEY axis over several launches with carried (O, m, l) state must reproduce the
@@ -470,7 +470,26 @@ def test_error_reporting(hip_ops):
 # ---------------------------------------------------------------------------------------------------
 # edge cases: minimum / ragged sizes through every kernel family (tails, clamps, masks)
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("kernel", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 4, 5])
+def test_attention6_pingpong(hip_ops, variant):
+    """attn6.hip (PV pipelined one tile behind QK^T, wave groups one phase apart): parity incl. ragged tails."""
+    hip_ops.lib.icv_set_option(b"attn_kernel", 6); hip_ops.lib.icv_set_option(b"attn6_variant", variant)
+    try:
+        for Sq, Skv, H in ((300, 1000, 2), (257, 64, 1), (64, 65, 1), (512, 129, 3), (1, 1, 1), (2240, 2240, 2)):
+            d = H * 128
+            q, k, v = (rnd((Sq, d), 501).to(torch.bfloat16), rnd((Skv, d), 502).to(torch.bfloat16), rnd((Skv, d), 503).to(torch.bfloat16))
+            ref = R.attention(q.float(), k.float(), v.float(), H)
+            o = torch.empty((Sq, d), dtype=torch.bfloat16, device=DEV)
+            o2 = torch.empty_like(o)
+            hip_ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), o, H, 1.0 / math.sqrt(128))
+            hip_ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), o2, H, 1.0 / math.sqrt(128))
+            assert_bf16_close(o, ref, f"attn6 v{variant} Sq={Sq} Skv={Skv}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
+            assert torch.equal(o, o2), "attn6 is not deterministic"
+    finally:
+        hip_ops.lib.icv_set_option(b"attn_kernel", 2); hip_ops.lib.icv_set_option(b"attn6_variant", 5)
+
+
+@pytest.mark.parametrize("kernel", [1, 2, 3, 4, 5, 6])
 def test_attention_minimum_sizes(hip_ops, kernel):
     hip_ops.lib.icv_set_option(b"attn_kernel", kernel)
     try:

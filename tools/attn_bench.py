@@ -39,7 +39,9 @@ for name, Sq, Skv, H in cases:
     for rd in range(rounds):           # interleaved rounds: within-process A/B
         for vv in variants:
             # variant codes: <100 -> attn.hip variant; 1000+x -> attn2.hip variant x
-            if vv >= 5000:
+            if vv >= 6000:
+                ops.lib.icv_set_option(b"attn_kernel", 6); ops.lib.icv_set_option(b"attn6_variant", vv - 6000)
+            elif vv >= 5000:
                 ops.lib.icv_set_option(b"attn_kernel", 5)
             elif vv >= 4000:
                 ops.lib.icv_set_option(b"attn_kernel", 4); ops.lib.icv_set_option(b"attn4_variant", vv - 4000)
