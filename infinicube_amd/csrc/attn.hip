@@ -338,7 +338,7 @@ extern "C" int icv_attention_fwd_chunk(const void* q, int64_t ldq, const void* k
   if (icv_get_option_int("attn_kernel", 2) == 3)
     return icv_attn3_dispatch(q, ldq, k, ldk, v, ldv, o, ldo, acc, ldacc, ml, first ? 0 : 1, last ? 0 : 1,
                               Sq, Skv, heads, scale, icv_get_option_int("attn3_variant", 0), (hipStream_t)stream);
-  const int var = icv_get_option_int("attn2_variant", 4);
+  const int var = icv_get_option_int("attn2_variant", 12);
   return icv_attn2_dispatch(q, ldq, k, ldk, v, ldv, o, ldo, acc, ldacc, ml, first ? 0 : 1, last ? 0 : 1,
                             Sq, Skv, heads, scale, var, (hipStream_t)stream);
 }
@@ -363,7 +363,7 @@ extern "C" int icv_attention_fwd(const void* q, int64_t ldq, const void* k, int6
                               icv_get_option_int("attn3_variant", 0), (hipStream_t)stream);
   if (icv_get_option_int("attn_kernel", 2) == 2)
     return icv_attn2_dispatch(q, ldq, k, ldk, v, ldv, o, ldo, nullptr, 0, nullptr, 0, 0, Sq, Skv, heads, scale,
-                              icv_get_option_int("attn2_variant", 4), (hipStream_t)stream);
+                              icv_get_option_int("attn2_variant", 12), (hipStream_t)stream);
   AttnParams p;
   p.q = (const bf16_t*)q; p.ldq = ldq; p.k = (const bf16_t*)k; p.ldk = ldk;
   p.v = (const bf16_t*)v; p.ldv = ldv; p.o = (bf16_t*)o; p.ldo = ldo;
@@ -392,5 +392,5 @@ extern "C" int icv_attention_fwd_add(const void* q, int64_t ldq, const void* k, 
   ICV_REQUIRE(Sq > 0 && Skv > 0 && heads > 0, "icv_attention_fwd_add: empty problem (Sq=%lld Skv=%lld heads=%lld)", (long long)Sq, (long long)Skv, (long long)heads);
   ICV_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "icv_attention_fwd_add: leading dims must keep 16-byte row alignment");
   return icv_attn2_dispatch(q, ldq, k, ldk, v, ldv, o, ldo, nullptr, 0, nullptr, 0, 2, Sq, Skv, heads, scale,
-                            icv_get_option_int("attn2_variant", 4), (hipStream_t)stream);
+                            icv_get_option_int("attn2_variant", 12), (hipStream_t)stream);
 }

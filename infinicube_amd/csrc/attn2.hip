@@ -23,10 +23,11 @@ constexpr int KT_BYTES = KVB * D * 2;    // 32 KiB (K or V part of a stage)
 constexpr int STAGE_BYTES = 2 * KT_BYTES;
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;  // 128 KiB
 constexpr int HALF_BYTES = 64 * D * 2;      // 16 KiB
-// VAR bit flags: 1 = stagger wave groups, 4 = s_setprio(1) around MFMA clusters
+// VAR bit flags: 1 = stagger wave groups, 4 = s_setprio(1) around MFMA clusters, 8 = lazy max (see A2_HALF)
 template <int VAR>
 __global__ __launch_bounds__(512) void attn2_kernel(Params p) {
-  constexpr bool STAGGER = VAR & 1, SETPRIO = VAR & 4;
+  constexpr bool STAGGER = VAR & 1, SETPRIO = VAR & 4, LAZYMAX = VAR & 8;
+  const float p_lim = __builtin_amdgcn_exp2f(p.thr);   // lazy max: largest row-partial sum of P accepted without a rescale
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -156,28 +157,55 @@ __global__ __launch_bounds__(512) void attn2_kernel(Params p) {
         if (key >= p.Skv) st[kb][r] = NEG_BIG;                                                        \
       }                                                                                               \
     }                                                                                                 \
-    float mloc = st[0][0];                                                                            \
-    _Pragma("unroll") for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[0][r]);                      \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[1][r]);                      \
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));                                                     \
-    if (__any((mloc - m_run) * p.sc > p.thr)) {                                                       \
-      const float m_new = fmaxf(m_run, mloc);                                                         \
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.sc);                             \
-      m_run = m_new;                                                                                  \
-      l_run *= alpha;                                                                                 \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;                               \
+    if (!LAZYMAX) {                                                                                   \
+      float mloc = st[0][0];                                                                          \
+      _Pragma("unroll") for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[0][r]);                    \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[1][r]);                    \
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));                                                   \
+      if (__any((mloc - m_run) * p.sc > p.thr)) {                                                     \
+        const float m_new = fmaxf(m_run, mloc);                                                       \
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.sc);                           \
+        m_run = m_new;                                                                                \
+        l_run *= alpha;                                                                               \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;                             \
+      }                                                                                               \
     }                                                                                                 \
-    const float mb = -m_run * p.sc;                                                                   \
+    float mb = -m_run * p.sc;                                                                         \
     float psum = 0.f;                                                                                 \
     if (SETPRIO) __builtin_amdgcn_s_setprio(1);                                                       \
     _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                \
       bf16x8 pf[2];                                                                                   \
+      float ps = 0.f;                                                                                 \
       _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                \
         const float pv = __builtin_amdgcn_exp2f(fmaf(st[kb][r], p.sc, mb));                           \
-        psum += pv;                                                                                   \
+        ps += pv;                                                                                     \
         pf[r >> 3][r & 7] = (__bf16)pv;                                                               \
       }                                                                                               \
+      /* lazy max: no row-max pass at all while P stays small against the current reference m_run.   \
+         P > 0, so the 16-key partial sum bounds every P of the block: ps <= 2^thr proves no element \
+         outgrew the reference by more than thr (inf / NaN fail the test too).  Only then is the     \
+         block's true max taken, O and l rescaled to it, and P recomputed (first tiles, rare later). */ \
+      if (LAZYMAX && __any(!(ps <= p_lim))) {                                                         \
+        float mloc = st[kb][0];                                                                       \
+        _Pragma("unroll") for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[kb][r]);                 \
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));                                                 \
+        const float m_new = fmaxf(m_run, mloc);                                                       \
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.sc);                           \
+        m_run = m_new;                                                                                \
+        l_run = (l_run + psum) * alpha;                                                               \
+        psum = 0.f;                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;                             \
+        mb = -m_run * p.sc;                                                                           \
+        ps = 0.f;                                                                                     \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                              \
+          const float pv = __builtin_amdgcn_exp2f(fmaf(st[kb][r], p.sc, mb));                         \
+          ps += pv;                                                                                   \
+          pf[r >> 3][r & 7] = (__bf16)pv;                                                             \
+        }                                                                                             \
+      }                                                                                               \
+      psum += ps;                                                                                     \
       _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {                                              \
         const int kk = kb * 2 + hf;                                                                   \
         _Pragma("unroll") for (int d0 = 0; d0 < 4; ++d0) {                                            \
@@ -251,6 +279,8 @@ int icv_attn2_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, c
     case 1: return att2::launch<1>(p, st);
     case 4: return att2::launch<4>(p, st);
     case 5: return att2::launch<5>(p, st);
+    case 12: return att2::launch<12>(p, st);
+    case 13: return att2::launch<13>(p, st);
   }
   icv_set_error("icv_attention_fwd: unknown attn2 variant %d", var);
   return 1;

@@ -13,6 +13,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Optional
 
+import os
+
 import torch
 
 from .. import native
@@ -65,6 +67,10 @@ class HipOps:
         if not torch.cuda.is_available():
             raise native.NativeError("HipOps: no GPU visible to PyTorch-ROCm; there is no CPU fallback")
         self.lib = native.lib()
+        # kernel A/B switches (icv_set_option) from the environment, e.g. ICV_OPTIONS="attn2_variant=4,gemm256=1"
+        for item in filter(None, os.environ.get("ICV_OPTIONS", "").split(",")):
+            name, _, val = item.partition("=")
+            native.check(self.lib.icv_set_option(name.strip().encode(), int(val)), f"icv_set_option({item})")
 
     # -- helpers ---------------------------------------------------------------------------
     def _stream(self) -> int:

@@ -275,7 +275,7 @@ def test_attention_variants(hip_ops, variant, thr):
     assert_bf16_close(o, ref, f"attention variant {variant} thr {thr}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 4, 5, 12, 13])
 def test_attention2_variants(hip_ops, variant):
     """attn2.hip (128-key staged tile, two 64-key halves per barrier pair) in every variant, including
     Skv values that leave the second half of the last tile empty / partially masked."""
@@ -294,8 +294,21 @@ def test_attention2_variants(hip_ops, variant):
             hip_ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), o2, H, 1.0 / math.sqrt(128))
             assert torch.equal(o, o2), "non-deterministic attention output (LDS staging race?)"
             assert_bf16_close(o, ref, f"attn2 variant {variant} Sq={Sq} Skv={Skv}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
+        # scores that keep growing along the key axis (every tile outgrows the running reference: the rescale path,
+        # lazy or not, fires again and again), and a row whose scores are hugely negative everywhere
+        Sq, Skv = 130, 1500
+        q = rnd((Sq, d), 174).to(torch.bfloat16)
+        k = (rnd((Skv, d), 175) * torch.linspace(0.2, 6.0, Skv)[:, None]).to(torch.bfloat16)
+        k[:, :128] += (q[5, :128].float() * torch.linspace(0.0, 3.0, Skv)[:, None]).to(torch.bfloat16)
+        v = rnd((Skv, d), 176).to(torch.bfloat16)
+        q[7] = -8.0 * k[:, :].float().mean(0).to(torch.bfloat16)
+        ref = R.attention(q.float(), k.float(), v.float(), H)
+        o = torch.zeros((Sq, d), dtype=torch.bfloat16, device=DEV)
+        hip_ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), o, H, 1.0 / math.sqrt(128))
+        assert torch.isfinite(o.float()).all()
+        assert_bf16_close(o, ref, f"attn2 variant {variant} growing scores", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
     finally:
-        hip_ops.lib.icv_set_option(b"attn2_variant", 4)
+        hip_ops.lib.icv_set_option(b"attn2_variant", 12)
 
 
 @pytest.mark.parametrize("variant", [0, 4])

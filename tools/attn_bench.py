@@ -62,7 +62,7 @@ for name, Sq, Skv, H in cases:
     fl = 4.0 * Sq * Skv * d
     print(f"{name:10s} Sq={Sq} Skv={Skv} H={H}: " + " | ".join(
         f"v{vv}: {fl / sorted(best[vv])[len(best[vv]) // 2] / 1e9:6.1f} TF (min {min(best[vv]):.3f} ms)" for vv in variants))
-ops.lib.icv_set_option(b"attn_variant", 5); ops.lib.icv_set_option(b"attn_kernel", 2); ops.lib.icv_set_option(b"attn2_variant", 4)
+ops.lib.icv_set_option(b"attn_variant", 5); ops.lib.icv_set_option(b"attn_kernel", 2); ops.lib.icv_set_option(b"attn2_variant", 12)
 
 # cost of splitting one self-attention over C key chunks with carried state (sequence-parallel path)
 if os.environ.get("ATTN_CHUNKS"):
