@@ -23,10 +23,13 @@ constexpr int KT_BYTES = KVB * D * 2;    // 32 KiB (K or V part of a stage)
 constexpr int STAGE_BYTES = 2 * KT_BYTES;
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;  // 128 KiB
 constexpr int HALF_BYTES = 64 * D * 2;      // 16 KiB
-// VAR bit flags: 1 = stagger wave groups, 4 = s_setprio(1) around MFMA clusters, 8 = lazy max (see A2_HALF)
+// VAR bit flags: 1 = stagger wave groups, 4 = s_setprio(1) around MFMA clusters, 8 = lazy max (see A2_HALF),
+// 16 = unit scale (needs 8): scale * log2(e) == 1, i.e. the caller folded the softmax scale into K (the DiT does it in the
+// K RMSNorm weight, same single bf16 rounding) -> the S accumulator starts at -m_ref and P = exp2(S) with no fma per element
 template <int VAR>
 __global__ __launch_bounds__(512) void attn2_kernel(Params p) {
-  constexpr bool STAGGER = VAR & 1, SETPRIO = VAR & 4, LAZYMAX = VAR & 8;
+  constexpr bool STAGGER = VAR & 1, SETPRIO = VAR & 4, LAZYMAX = VAR & 8, UNIT = VAR & 16;
+  static_assert(!UNIT || LAZYMAX, "unit-scale path is built on the lazy-max path");
   const float p_lim = __builtin_amdgcn_exp2f(p.thr);   // lazy max: largest row-partial sum of P accepted without a rescale
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -140,8 +143,12 @@ __global__ __launch_bounds__(512) void attn2_kernel(Params p) {
     const char* ks = (KS_);                                                                           \
     const char* vs = (VS_);                                                                           \
     f32x16 st[2];                                                                                     \
+    /* UNIT: reference baked into the accumulators of this half (0 while there is no reference yet) */ \
+    const bool no_ref = UNIT && m_run < -1.0e29f;                                                     \
+    float m_base = no_ref ? 0.f : m_run;                                                              \
+    const float st0 = UNIT ? -m_base : 0.f;                                                           \
     _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                  \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;                                   \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) st[kb][r] = st0;                                   \
     if (SETPRIO) __builtin_amdgcn_s_setprio(1);                                                       \
     _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                  \
     _Pragma("unroll") for (int ds = 0; ds < 8; ++ds) {                                                \
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(512) void attn2_kernel(Params p) {
       bf16x8 pf[2];                                                                                   \
       float ps = 0.f;                                                                                 \
       _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                \
-        const float pv = __builtin_amdgcn_exp2f(fmaf(st[kb][r], p.sc, mb));                           \
+        const float pv = UNIT ? __builtin_amdgcn_exp2f(st[kb][r]) : __builtin_amdgcn_exp2f(fmaf(st[kb][r], p.sc, mb)); \
         ps += pv;                                                                                     \
         pf[r >> 3][r & 7] = (__bf16)pv;                                                               \
       }                                                                                               \
@@ -186,10 +193,11 @@ __global__ __launch_bounds__(512) void attn2_kernel(Params p) {
          P > 0, so the 16-key partial sum bounds every P of the block: ps <= 2^thr proves no element \
          outgrew the reference by more than thr (inf / NaN fail the test too).  Only then is the     \
          block's true max taken, O and l rescaled to it, and P recomputed (first tiles, rare later). */ \
-      if (LAZYMAX && __any(!(ps <= p_lim))) {                                                         \
+      if (LAZYMAX && __any(!(ps <= p_lim) || no_ref)) {                                               \
         float mloc = st[kb][0];                                                                       \
         _Pragma("unroll") for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[kb][r]);                 \
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));                                                 \
+        if (UNIT) mloc += m_base;                      /* st = s - m_base */                           \
         const float m_new = fmaxf(m_run, mloc);                                                       \
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.sc);                           \
         m_run = m_new;                                                                                \
@@ -198,9 +206,15 @@ __global__ __launch_bounds__(512) void attn2_kernel(Params p) {
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;                             \
         mb = -m_run * p.sc;                                                                           \
+        if (UNIT) {                                    /* re-base this and the later blocks of the half */ \
+          const float dm = m_new - m_base;                                                            \
+          m_base = m_new;                                                                             \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j)                                               \
+            if (j >= kb) { _Pragma("unroll") for (int r = 0; r < 16; ++r) st[j][r] -= dm; }           \
+        }                                                                                             \
         ps = 0.f;                                                                                     \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                              \
-          const float pv = __builtin_amdgcn_exp2f(fmaf(st[kb][r], p.sc, mb));                         \
+          const float pv = UNIT ? __builtin_amdgcn_exp2f(st[kb][r]) : __builtin_amdgcn_exp2f(fmaf(st[kb][r], p.sc, mb)); \
           ps += pv;                                                                                   \
           pf[r >> 3][r & 7] = (__bf16)pv;                                                             \
         }                                                                                             \
@@ -274,6 +288,7 @@ int icv_attn2_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, c
                        hipStream_t st) {
   att2::Params p;
   attc::fill_params(p, q, ldq, k, ldk, v, ldv, o, ldo, acc, ldacc, ml, state_in, state_out, Sq, Skv, heads, scale, att2::QB);
+  if (p.sc == 1.0f && (var & 8) && icv_get_option_int("attn_unit_scale", 1)) var |= 16;   // unit scale (attn_common.h fill_params snaps |sc - 1| < 1e-6 to exactly 1)
   switch (var) {
     case 0: return att2::launch<0>(p, st);
     case 1: return att2::launch<1>(p, st);
@@ -281,6 +296,8 @@ int icv_attn2_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, c
     case 5: return att2::launch<5>(p, st);
     case 12: return att2::launch<12>(p, st);
     case 13: return att2::launch<13>(p, st);
+    case 28: return att2::launch<28>(p, st);
+    case 29: return att2::launch<29>(p, st);
   }
   icv_set_error("icv_attention_fwd: unknown attn2 variant %d", var);
   return 1;

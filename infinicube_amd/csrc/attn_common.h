@@ -35,6 +35,7 @@ inline void fill_params(Params& p, const void* q, int64_t ldq, const void* k, in
   p.Sq = Sq; p.Skv = Skv; p.heads = (int)heads;
   p.nqb = (int)((Sq + rows_per_block - 1) / rows_per_block);
   p.sc = scale * 1.4426950408889634f;
+  if (fabsf(p.sc - 1.0f) < 1e-6f) p.sc = 1.0f;   // "unit scale": the caller folded scale * log2(e) into K (scale = ln 2)
   p.thr = (float)icv_get_option_int("attn_defer_max_log2", 8);
 }
 

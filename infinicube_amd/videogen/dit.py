@@ -93,6 +93,9 @@ class WanDiT:
         self.tproj_w, self.tproj_b = W("time_projection.1.weight"), V("time_projection.1.bias")
         self.head_w, self.head_b = W("head.head.weight"), V("head.head.bias")
         self.head_mod = V("head.modulation").reshape(2, d).contiguous()
+        # softmax scale folded into the K norm weights (see the module docstring); attention then runs at unit scale
+        self.k_fold = (1.0 / math.sqrt(cfg.head_dim)) * math.log2(math.e)
+        self.attn_scale = math.log(2.0)
         self.layers = []
         mods = []
         for i in range(cfg.num_layers):
@@ -101,13 +104,13 @@ class WanDiT:
             lw = dict(
                 wqkv=torch.cat([W(f"{sa}.q.weight"), W(f"{sa}.k.weight"), W(f"{sa}.v.weight")], 0).contiguous(),
                 bqkv=torch.cat([V(f"{sa}.q.bias"), V(f"{sa}.k.bias"), V(f"{sa}.v.bias")], 0).contiguous(),
-                nq=V(f"{sa}.norm_q.weight"), nk=V(f"{sa}.norm_k.weight"),
+                nq=V(f"{sa}.norm_q.weight"), nk=V(f"{sa}.norm_k.weight") * self.k_fold,
                 wo=W(f"{sa}.o.weight"), bo=V(f"{sa}.o.bias"),
                 n3w=V(f"{p}.norm3.weight"), n3b=V(f"{p}.norm3.bias"),
                 xq_w=W(f"{ca}.q.weight"), xq_b=V(f"{ca}.q.bias"),
                 xkv_w=torch.cat([W(f"{ca}.k.weight"), W(f"{ca}.v.weight")], 0).contiguous(),
                 xkv_b=torch.cat([V(f"{ca}.k.bias"), V(f"{ca}.v.bias")], 0).contiguous(),
-                xnq=V(f"{ca}.norm_q.weight"), xnk=V(f"{ca}.norm_k.weight"),
+                xnq=V(f"{ca}.norm_q.weight"), xnk=V(f"{ca}.norm_k.weight") * self.k_fold,
                 xo_w=W(f"{ca}.o.weight"), xo_b=V(f"{ca}.o.bias"),
                 f0_w=W(f"{p}.ffn.0.weight"), f0_b=V(f"{p}.ffn.0.bias"),
                 f2_w=W(f"{p}.ffn.2.weight"), f2_b=V(f"{p}.ffn.2.bias"),
@@ -118,7 +121,7 @@ class WanDiT:
             if cfg.has_image_input:
                 lw["xkv_img_w"] = torch.cat([W(f"{ca}.k_img.weight"), W(f"{ca}.v_img.weight")], 0).contiguous()
                 lw["xkv_img_b"] = torch.cat([V(f"{ca}.k_img.bias"), V(f"{ca}.v_img.bias")], 0).contiguous()
-                lw["xnk_img"] = V(f"{ca}.norm_k_img.weight")
+                lw["xnk_img"] = V(f"{ca}.norm_k_img.weight") * self.k_fold
             self.layers.append(lw)
             mods.append(V(f"{p}.modulation").reshape(6 * d))
         self.modulation = torch.stack(mods, 0).contiguous()  # f32 [L, 6d]
@@ -361,7 +364,7 @@ class WanDiT:
         head_out f32 [n, out_dim*4] (velocity in token space)."""
         cfg, ops, plan = self.cfg, self.ops, self.plan
         d, H, n, eps = cfg.dim, cfg.num_heads, plan.n_tok, cfg.eps
-        scale = 1.0 / math.sqrt(cfg.head_dim)
+        scale = self.attn_scale          # = ln 2: K already carries (1/sqrt(hd)) * log2(e)
         if (self.cond_w is not None) and buf_tokens is None:
             raise ValueError("i2v DiT: pass the cached embed_cond_latents(y) tokens as buf_tokens")
         if cfg.has_image_input != (ctx.k_img is not None):

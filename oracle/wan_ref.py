@@ -117,13 +117,13 @@ def modulate(x: Tensor, shift: Tensor, scale: Tensor) -> Tensor:
     return x * (1.0 + scale) + shift
 
 
-def attention(q: Tensor, k: Tensor, v: Tensor, num_heads: int) -> Tensor:
-    """q [Sq, H*hd], k/v [Sk, H*hd] -> [Sq, H*hd]; non-causal softmax(q k^T / sqrt(hd)) v."""
+def attention(q: Tensor, k: Tensor, v: Tensor, num_heads: int, scale: Optional[float] = None) -> Tensor:
+    """q [Sq, H*hd], k/v [Sk, H*hd] -> [Sq, H*hd]; non-causal softmax(q k^T * scale) v, scale = 1/sqrt(hd) by default."""
     Sq, Sk = q.shape[0], k.shape[0]
     qh = q.reshape(Sq, num_heads, -1).transpose(0, 1)
     kh = k.reshape(Sk, num_heads, -1).transpose(0, 1)
     vh = v.reshape(Sk, num_heads, -1).transpose(0, 1)
-    o = F.scaled_dot_product_attention(qh[None], kh[None], vh[None])[0]
+    o = F.scaled_dot_product_attention(qh[None], kh[None], vh[None], scale=scale)[0]
     return o.transpose(0, 1).reshape(Sq, -1)
 
 

@@ -109,11 +109,10 @@ class OracleOps:
             x.copy_(y.to(BF16))
 
     def attention(self, q, k, v, o, heads, scale):
-        assert abs(scale - 1.0 / math.sqrt(q.shape[1] // heads)) < 1e-9
-        o.copy_(R.attention(q.float(), k.float(), v.float(), heads).to(BF16))
+        o.copy_(R.attention(q.float(), k.float(), v.float(), heads, scale=scale).to(BF16))
 
     def attention_add(self, q, k, v, o, heads, scale):
-        o.copy_((o.float() + R.attention(q.float(), k.float(), v.float(), heads)).to(BF16))
+        o.copy_((o.float() + R.attention(q.float(), k.float(), v.float(), heads, scale=scale)).to(BF16))
 
     def attention_chunk(self, q, k, v, o, acc, ml, heads, scale, first, last):
         """Online-softmax over one chunk of keys with carried (acc, m, l) state, fp32."""

@@ -158,23 +158,23 @@ def test_inprocess_two_shards_equal_unsharded(chunks, model, gemm_dtype):
         class FakeGather:
             """Stands in for RCCL: serves chunk (r0, r1) of every rank's shard from the recorded full K/V."""
             def __init__(self):
-                self.layer, self.calls = 0, 0
+                self.layer, self.calls, self.r0 = 0, 0, 0
 
             def start(self, k_rows, v_rows, k_out, v_out):
                 kf, vf = rec["kv"][self.layer]
-                m = k_rows.shape[0]
-                # locate this chunk inside the local shard by matching rows (RoPE offsets, shard indexing)
-                for r0 in range(0, n - m + 1):
-                    if torch.equal(kf[plan.tok0 + r0: plan.tok0 + r0 + m], k_rows):
-                        break
-                else:
-                    raise AssertionError("local K rows do not match the unsharded run")
-                assert torch.equal(vf[plan.tok0 + r0: plan.tok0 + r0 + m], v_rows)
+                m, r0 = k_rows.shape[0], self.r0
+                # this chunk = rows [r0, r0 + m) of the local shard (RoPE offsets, shard indexing).  CPU GEMM blocking
+                # depends on the row count, so a 1e-7 difference can flip a bf16 rounding: compare to rounding
+                mine = kf[plan.tok0 + r0: plan.tok0 + r0 + m].float()
+                assert float((mine - k_rows.float()).norm() / mine.norm()) < 1e-2, "local K rows do not match the unsharded run"
+                minev = vf[plan.tok0 + r0: plan.tok0 + r0 + m].float()
+                assert float((minev - v_rows.float()).norm() / minev.norm()) < 1e-2
                 k_out.copy_(torch.cat([kf[rk * n + r0: rk * n + r0 + m] for rk in range(2)], 0))
                 v_out.copy_(torch.cat([vf[rk * n + r0: rk * n + r0 + m] for rk in range(2)], 0))
                 self.calls += 1
+                self.r0 += m
                 if self.calls % chunks == 0:
-                    self.layer += 1
+                    self.layer, self.r0 = self.layer + 1, 0
                 return ()
 
             def wait(self, handle):

@@ -311,6 +311,44 @@ def test_attention2_variants(hip_ops, variant):
         hip_ops.lib.icv_set_option(b"attn2_variant", 12)
 
 
+@pytest.mark.parametrize("unit", [1, 0])
+def test_attention_unit_scale(hip_ops, unit):
+    """scale * log2(e) == 1 (the DiT folds the softmax scale into K and calls with scale = ln 2): the kernel then
+    starts the S accumulator at -m_ref and takes exp2(S) directly.  Same answers as the generic path (unit=0)."""
+    H = 2
+    d = H * 128
+    ln2, fold = math.log(2.0), (1.0 / math.sqrt(128)) * math.log2(math.e)
+    hip_ops.lib.icv_set_option(b"attn_unit_scale", unit)
+    try:
+        for Sq, Skv, grow in ((300, 1100, False), (64, 64, False), (257, 65, False), (130, 1500, True), (1, 1, False), (513, 640, False)):
+            q = rnd((Sq, d), 181).to(torch.bfloat16)
+            kf = rnd((Skv, d), 182)
+            if grow:     # scores that keep outgrowing the running reference + one row with hugely negative scores
+                kf = kf * torch.linspace(0.2, 6.0, Skv)[:, None]
+                kf[:, :128] += q[5, :128].float() * torch.linspace(0.0, 3.0, Skv)[:, None]
+                q[7] = (-8.0 * kf.mean(0)).to(torch.bfloat16)
+            else:
+                kf[Skv - 1] = q[min(3, Sq - 1)].float() * 5.0
+            k = (kf * fold).to(torch.bfloat16)          # K carries the scale, rounded once
+            v = rnd((Skv, d), 183).to(torch.bfloat16)
+            ref = R.attention(q.float(), k.float(), v.float(), H, scale=ln2)
+            o = torch.zeros((Sq, d), dtype=torch.bfloat16, device=DEV)
+            hip_ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), o, H, ln2)
+            assert torch.isfinite(o.float()).all()
+            assert_bf16_close(o, ref, f"unit-scale={unit} Sq={Sq} Skv={Skv}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
+            # key-axis chunks with carried state (sequence-parallel path) take the same route
+            if Skv >= 640:
+                acc = torch.empty((Sq, d), device=DEV); ml = torch.empty((Sq, H, 2), device=DEV)
+                o2 = torch.zeros_like(o)
+                cuts = [0, 100, 357, Skv]
+                for c in range(3):
+                    hip_ops.attention_chunk(q.to(DEV), k[cuts[c]:cuts[c + 1]].to(DEV), v[cuts[c]:cuts[c + 1]].to(DEV), o2, acc, ml, H, ln2,
+                                            first=(c == 0), last=(c == 2))
+                assert_bf16_close(o2, ref, f"unit-scale={unit} chunked Sq={Sq} Skv={Skv}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
+    finally:
+        hip_ops.lib.icv_set_option(b"attn_unit_scale", 1)
+
+
 @pytest.mark.parametrize("variant", [0, 4])
 def test_attention3_variants(hip_ops, variant):
     """attn3.hip (one wave per SIMD, 64 query rows per wave, shared K/V fragments)."""
