@@ -258,7 +258,7 @@ def main():
                 "frac_of_bf16_mfma_peak": f_step * args.steps / elapsed / 1e12 / (PEAK_BF16_TFLOPS * world),
             },
             "roofline": {
-                "kernel": "att2::attn2_kernel (self-attention, K6)",
+                "kernel": "att7::attn7_kernel (self-attention, K6)",
                 "bound": "mfma", "achieved": attn_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": attn_tflops / PEAK_BF16_TFLOPS, "traffic": traffic,
                 "avg_launch_ms": attn_ms, "launches_timed": len(attn_events),

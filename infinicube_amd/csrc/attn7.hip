@@ -1,0 +1,333 @@
+// Flash attention forward: attn4.hip's LDS-DMA ring (no staging VGPRs, counted vmcnt, one barrier per 64-key tile)
+// with the vector-side diet of attn2.hip, which the freed registers make affordable:
+//   * lazy max: P = exp2(S - m_ref) is taken against the current reference and the 16-key partial row sum (needed
+//     anyway) bounds every P; only when it exceeds 2^thr is the block's true max taken, O/l rescaled, P recomputed;
+//   * unit scale (scale * log2 e == 1: the DiT folds the softmax scale into the K RMSNorm weight): the reference
+//     lives in a persistent 16-register vector cinit = -m_ref that is the C operand of the first MFMA of each
+//     S^T chain, so there is neither a per-element fma nor a per-tile accumulator initialisation;
+//   * DMA addresses: tile base in an SGPR pair + four fixed 32-bit per-lane byte offsets (saddr form of
+//     global_load_lds_dwordx4); only a partial last tile takes the clamped 64-bit path.
+// Everything else (fragments, swizzled LDS images, ring invariants, stagger option) is attn4.hip's: see there.
+#include "attn_common.h"
+
+namespace att7 {
+
+using attc::D;
+using attc::NEG_BIG;
+using attc::Params;
+using attc::lds_read_tr16;
+constexpr int KVB = 64;
+constexpr int QB = 256;
+constexpr int TILE_BYTES = KVB * D * 2;      // 16 KiB (K or V)
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;  // 32 KiB
+constexpr int NSTAGE = 4;
+constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;  // 128 KiB
+
+// LDS-DMA through inline asm: hipcc does not count it, so it never guards the (alias-info-free)
+// ds_read_b64_tr_b16 reads with vmcnt(0); completion is tracked by our own counted s_waitcnt vmcnt.
+// M0 (the DMA's LDS base) is compiler-reserved: it is saved, set and restored inside ONE statement
+// (cdna guide §5.7).  lds_dst must be wave-uniform; the hardware adds lane*16.
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+// saddr form: 64-bit wave-uniform base in SGPRs + 32-bit per-lane byte offset
+__device__ __forceinline__ void dma16s(const void* base, unsigned off, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(off), "s"(base), "s"(lds_dst)
+      : "memory");
+}
+
+// VAR bit flags: 1 = stagger wave groups, 2 = issue all 16 K-fragment reads ahead of the QK^T MFMAs,
+//                4 = s_setprio(1) around MFMA clusters, 16 = unit scale
+template <int VAR>
+__global__ __launch_bounds__(512) void attn7_kernel(Params p) {
+  constexpr bool STAGGER = VAR & 1, KPREFETCH = VAR & 2, SETPRIO = VAR & 4, UNIT = VAR & 16;   // 16: unit scale (set by the dispatcher)
+  const float p_lim = __builtin_amdgcn_exp2f(p.thr);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int l31 = lane & 31;
+
+  int head, qb;
+  attc::work_item(p, head, qb);
+  const int64_t q0 = (int64_t)qb * QB + wave * 32;
+
+  const bf16_t* qh = p.q + (int64_t)head * D;
+  const bf16_t* kh = p.k + (int64_t)head * D;
+  const bf16_t* vh = p.v + (int64_t)head * D;
+
+  int64_t qr_c = q0 + l31;
+  qr_c = qr_c < p.Sq ? qr_c : p.Sq - 1;
+
+  // ---- softmax state ----
+  f32x16 ot[4];
+  float m_run, l_run;
+  attc::load_state(p, qr_c, head, hi, ot, m_run, l_run);
+  float m_base = m_run < -1.0e29f ? 0.f : m_run;   // UNIT: the reference currently baked into cinit
+  f32x16 cinit;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cinit[r] = UNIT ? -m_base : 0.f;
+
+  bf16x8 qf[8];
+  {
+    const bf16_t* qp = qh + qr_c * p.ldq + hi * 8;
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds) qf[ds] = *reinterpret_cast<const bf16x8*>(qp + ds * 16);
+  }
+  // Retire the ordinary (VGPR-destination) prologue loads before any LDS-DMA is in flight: beside a
+  // DMA hipcc waits vmcnt(0) for every ordinary load, which would drain the ring (guide §5 trap (b)).
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+
+  // ---- LDS-DMA lane mapping: instruction j of this wave covers keys (wave*2 + j)*4 + lane/16 ----
+  const int dkey0 = (wave * 2 + 0) * 4 + (lane >> 4);
+  const int dkey1 = (wave * 2 + 1) * 4 + (lane >> 4);
+  const int pc = lane & 15;
+  const int kcol0 = (pc ^ (dkey0 & 15)) * 8, kcol1 = (pc ^ (dkey1 & 15)) * 8;        // elements
+  const int vcol0 = (pc ^ ((dkey0 & 3) << 2)) * 8, vcol1 = (pc ^ ((dkey1 & 3) << 2)) * 8;
+  const int nt = (int)((p.Skv + KVB - 1) / KVB);
+  const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+  const unsigned ko0 = (unsigned)(((int64_t)dkey0 * p.ldk + kcol0) * 2), ko1 = (unsigned)(((int64_t)dkey1 * p.ldk + kcol1) * 2);
+  const unsigned vo0 = (unsigned)(((int64_t)dkey0 * p.ldv + vcol0) * 2), vo1 = (unsigned)(((int64_t)dkey1 * p.ldv + vcol1) * 2);
+#define A7_DMA_TILE(T_)                                                                              \
+  {                                                                                                  \
+    const int tt_ = (T_) < nt ? (T_) : nt - 1;                                                       \
+    const unsigned l0_ = lds_base + (unsigned)(((T_) & (NSTAGE - 1)) * STAGE_BYTES + (wave * 2) * 1024); \
+    if ((int64_t)(tt_ + 1) * KVB <= p.Skv) {                                                         \
+      const bf16_t* kt_ = kh + (int64_t)tt_ * KVB * p.ldk;                                           \
+      const bf16_t* vt_ = vh + (int64_t)tt_ * KVB * p.ldv;                                           \
+      dma16s(kt_, ko0, l0_);                                                                         \
+      dma16s(kt_, ko1, l0_ + 1024);                                                                  \
+      dma16s(vt_, vo0, l0_ + TILE_BYTES);                                                            \
+      dma16s(vt_, vo1, l0_ + TILE_BYTES + 1024);                                                     \
+    } else {                                                                                         \
+      int64_t r0_ = (int64_t)tt_ * KVB + dkey0, r1_ = (int64_t)tt_ * KVB + dkey1;                    \
+      r0_ = r0_ < p.Skv ? r0_ : p.Skv - 1;                                                           \
+      r1_ = r1_ < p.Skv ? r1_ : p.Skv - 1;                                                           \
+      dma16(kh + r0_ * p.ldk + kcol0, l0_);                                                          \
+      dma16(kh + r1_ * p.ldk + kcol1, l0_ + 1024);                                                   \
+      dma16(vh + r0_ * p.ldv + vcol0, l0_ + TILE_BYTES);                                             \
+      dma16(vh + r1_ * p.ldv + vcol1, l0_ + TILE_BYTES + 1024);                                      \
+    }                                                                                                \
+  }
+#define A7_VMCNT4() asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
+#define A7_BARRIER()                                          \
+  do {                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        \
+    __builtin_amdgcn_s_barrier();                             \
+    asm volatile("" ::: "memory");                            \
+    __builtin_amdgcn_sched_barrier(0);                        \
+  } while (0)
+
+  const int grp = STAGGER ? (wave >> 2) : 0;
+
+  // ---- prologue: tiles 0 and 1 in flight; tile 0 landed + published ----
+  A7_DMA_TILE(0);
+  A7_DMA_TILE(1);
+  A7_VMCNT4();
+  A7_BARRIER();
+  if (grp == 1) {   // group 1's idle interval I_0: it still owes its DMA duties (issue tile 2, retire tile 1)
+    A7_DMA_TILE(2);
+    A7_VMCNT4();
+    A7_BARRIER();
+  }
+
+  const int k_row_off = l31 * 256;
+  const int k_sw = l31 & 15;
+  const int g = lane >> 4, t16 = lane & 15;
+  const int v_key_lo = 4 * hi + (t16 >> 2);
+  const int v_byte_lo = (g & 1) * 32 + (t16 & 3) * 8;
+  const int v_sw = (t16 >> 2) << 6;
+  const int ahead = 2 + grp;   // group 1 runs one tile behind, so its DMA duties are one tile further ahead
+
+  for (int t = 0; t < nt; ++t) {
+    const char* ks = smem + (t & (NSTAGE - 1)) * STAGE_BYTES;
+    const char* vs = ks + TILE_BYTES;
+    const int64_t key0 = (int64_t)t * KVB;
+
+    // DMA of tile t+ahead first (longest possible flight), counted wait at the end of the interval
+    A7_DMA_TILE(t + ahead);
+
+    f32x16 st[2];
+    const bool no_ref = UNIT && m_run < -1.0e29f;
+    if (KPREFETCH) {
+      // hipcc otherwise recycles ONE register quad for consecutive K fragments (read -> lgkmcnt(0) ->
+      // MFMA -> read ...), exposing the LDS latency 16 times per tile: read everything first.
+      bf16x8 kf[2][8];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ds = 0; ds < 8; ++ds) {
+          const int c = ds * 2 + hi;
+          kf[kb][ds] = *reinterpret_cast<const bf16x8*>(ks + kb * 8192 + k_row_off + ((c ^ k_sw) << 4));
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      if (SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ds = 0; ds < 8; ++ds)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+          st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][ds], qf[ds], ds == 0 ? (UNIT ? cinit : zero16) : st[kb], 0, 0, 0);
+      if (SETPRIO) __builtin_amdgcn_s_setprio(0);
+    } else {
+      if (SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ds = 0; ds < 8; ++ds) {
+          const int c = ds * 2 + hi;
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + kb * 8192 + k_row_off + ((c ^ k_sw) << 4));
+          st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], ds == 0 ? (UNIT ? cinit : zero16) : st[kb], 0, 0, 0);
+        }
+      if (SETPRIO) __builtin_amdgcn_s_setprio(0);
+    }
+    if (key0 + KVB > p.Skv) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= p.Skv) st[kb][r] = NEG_BIG;
+        }
+    }
+    float mb = -m_run * p.sc;
+    float psum = 0.f;
+    if (SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      bf16x8 pf[2];
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = UNIT ? __builtin_amdgcn_exp2f(st[kb][r]) : __builtin_amdgcn_exp2f(fmaf(st[kb][r], p.sc, mb));
+        ps += pv;
+        pf[r >> 3][r & 7] = (__bf16)pv;
+      }
+      // lazy max (see attn2.hip): the partial row sum bounds every P of the block
+      if (__any(!(ps <= p_lim) || no_ref)) {
+        float mloc = st[kb][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[kb][r]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        if (UNIT) mloc += m_base;                        // st = s - m_base
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.sc);
+        m_run = m_new;
+        l_run = (l_run + psum) * alpha;
+        psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
+        mb = -m_run * p.sc;
+        if (UNIT) {                                      // re-base this and the later block of the tile, and cinit
+          const float dm = m_new - m_base;
+          m_base = m_new;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (j >= kb) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) st[j][r] -= dm;
+            }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) cinit[r] = -m_new;
+        }
+        ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = UNIT ? __builtin_amdgcn_exp2f(st[kb][r]) : __builtin_amdgcn_exp2f(fmaf(st[kb][r], p.sc, mb));
+          ps += pv;
+          pf[r >> 3][r & 7] = (__bf16)pv;
+        }
+      }
+      psum += ps;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int kk = kb * 2 + hf;
+#pragma unroll
+        for (int d0 = 0; d0 < 4; ++d0) {
+          const int key_l = kk * 16 + v_key_lo;
+          const int byte = (d0 * 64 + v_byte_lo) ^ v_sw;
+          const bf16x4 va = lds_read_tr16(vs + key_l * 256 + byte);
+          const bf16x4 vb = lds_read_tr16(vs + (key_l + 8) * 256 + byte);
+          bf16x8 vf;
+          vf[0] = va[0]; vf[1] = va[1]; vf[2] = va[2]; vf[3] = va[3];
+          vf[4] = vb[0]; vf[5] = vb[1]; vf[6] = vb[2]; vf[7] = vb[3];
+          ot[d0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[hf], ot[d0], 0, 0, 0);
+        }
+      }
+    }
+    if (SETPRIO) __builtin_amdgcn_s_setprio(0);
+    l_run += psum;
+
+    A7_VMCNT4();    // this wave's share of tile t+ahead-1 has landed (tile t+ahead may still be in flight)
+    A7_BARRIER();   // ... and is published to the block
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail DMAs before the LDS is released
+  if (grp == 0 && STAGGER) A7_BARRIER();             // re-balance the stagger
+
+  attc::store_result(p, q0 + l31, head, hi, ot, m_run, l_run);
+}
+
+template <int VAR>
+int launch(const Params& p, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn7_kernel<VAR>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) {
+      icv_set_error("attn7: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return 2;
+    }
+    attr_set = true;
+  }
+  const int64_t nwg = (int64_t)p.heads * p.nqb;
+  hipLaunchKernelGGL(attn7_kernel<VAR>, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p);
+  return icv_check_launch("icv_attention(7)");
+}
+
+}  // namespace att7
+
+int icv_attn7_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                       void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml, int state_in,
+                       int state_out, int64_t Sq, int64_t Skv, int64_t heads, float scale, int var,
+                       hipStream_t st) {
+  att7::Params p;
+  attc::fill_params(p, q, ldq, k, ldk, v, ldv, o, ldo, acc, ldacc, ml, state_in, state_out, Sq, Skv, heads, scale, att7::QB);
+  if (p.sc == 1.0f && icv_get_option_int("attn_unit_scale", 1)) var |= 16;
+  switch (var) {
+    case 0: return att7::launch<0>(p, st);
+    case 1: return att7::launch<1>(p, st);
+    case 4: return att7::launch<4>(p, st);
+    case 5: return att7::launch<5>(p, st);
+    case 6: return att7::launch<6>(p, st);
+    case 7: return att7::launch<7>(p, st);
+    case 16: return att7::launch<16>(p, st);
+    case 17: return att7::launch<17>(p, st);
+    case 20: return att7::launch<20>(p, st);
+    case 21: return att7::launch<21>(p, st);
+    case 22: return att7::launch<22>(p, st);
+    case 23: return att7::launch<23>(p, st);
+  }
+  icv_set_error("icv_attention_fwd: unknown attn7 variant %d", var);
+  return 1;
+}

@@ -21,17 +21,20 @@ if os.environ.get("ATTN_ACC"):
     for thr in (0, 2, 4, 8):
         ops.lib.icv_set_option(b"attn_defer_max_log2", thr)
         o = torch.empty_like(q)
-        ops.attention(q, k, v, o, H, 128 ** -0.5)
+        ops.attention(q, k, v, o, H, SCALE)
         e = (o.double() - ref)
         print(f"thr={thr}: max|err| {e.abs().max():.3e}  rms err {e.pow(2).mean().sqrt():.3e}  (rms ref {ref.pow(2).mean().sqrt():.3e})")
     ops.lib.icv_set_option(b"attn_defer_max_log2", int(os.environ.get("ATTN_THR", "8")))
 variants = [int(x) for x in os.environ.get("ATTN_VARIANTS", "5").split(",")]
 rounds = int(os.environ.get("ATTN_ROUNDS", "3"))
+SCALE = math.log(2.0) if os.environ.get("ATTN_UNIT") else 128 ** -0.5   # ATTN_UNIT=1: the DiT's unit-scale call (K carries the scale)
 for name, Sq, Skv, H in cases:
     d = H * 128
     q = torch.randn((Sq, d), device="cuda").to(torch.bfloat16)
     k = torch.randn((Skv, d), device="cuda").to(torch.bfloat16)
     v = torch.randn((Skv, d), device="cuda").to(torch.bfloat16)
+    if os.environ.get("ATTN_UNIT"):
+        k = (k.float() * (128 ** -0.5 * math.log2(math.e))).to(torch.bfloat16)   # K carries the softmax scale, like the DiT's
     if os.environ.get("ATTN_ZERO"):
         q.zero_(); k.zero_(); v.zero_()
     o = torch.empty_like(q)
@@ -39,7 +42,9 @@ for name, Sq, Skv, H in cases:
     for rd in range(rounds):           # interleaved rounds: within-process A/B
         for vv in variants:
             # variant codes: <100 -> attn.hip variant; 1000+x -> attn2.hip variant x
-            if vv >= 6000:
+            if vv >= 7000:
+                ops.lib.icv_set_option(b"attn_kernel", 7); ops.lib.icv_set_option(b"attn7_variant", vv - 7000)
+            elif vv >= 6000:
                 ops.lib.icv_set_option(b"attn_kernel", 6); ops.lib.icv_set_option(b"attn6_variant", vv - 6000)
             elif vv >= 5000:
                 ops.lib.icv_set_option(b"attn_kernel", 5)
@@ -48,21 +53,21 @@ for name, Sq, Skv, H in cases:
             elif vv >= 3000:
                 ops.lib.icv_set_option(b"attn_kernel", 3); ops.lib.icv_set_option(b"attn3_variant", vv - 3000)
             elif vv >= 1000:
-                ops.lib.icv_set_option(b"attn_kernel", 2); ops.lib.icv_set_option(b"attn2_variant", vv - 1000)
+                ops.lib.icv_set_option(b"attn_kernel", 7); ops.lib.icv_set_option(b"attn2_variant", vv - 1000)
             else:
                 ops.lib.icv_set_option(b"attn_kernel", 1); ops.lib.icv_set_option(b"attn_variant", vv)
-            ops.attention(q, k, v, o, H, 128 ** -0.5)
+            ops.attention(q, k, v, o, H, SCALE)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(n):
-                ops.attention(q, k, v, o, H, 128 ** -0.5)
+                ops.attention(q, k, v, o, H, SCALE)
             e1.record(); torch.cuda.synchronize()
             best[vv].append(e0.elapsed_time(e1) / n)
     fl = 4.0 * Sq * Skv * d
     print(f"{name:10s} Sq={Sq} Skv={Skv} H={H}: " + " | ".join(
         f"v{vv}: {fl / sorted(best[vv])[len(best[vv]) // 2] / 1e9:6.1f} TF (min {min(best[vv]):.3f} ms)" for vv in variants))
-ops.lib.icv_set_option(b"attn_variant", 5); ops.lib.icv_set_option(b"attn_kernel", 2); ops.lib.icv_set_option(b"attn2_variant", 12)
+ops.lib.icv_set_option(b"attn_variant", 5); ops.lib.icv_set_option(b"attn_kernel", 7); ops.lib.icv_set_option(b"attn2_variant", 12)
 
 # cost of splitting one self-attention over C key chunks with carried state (sequence-parallel path)
 if os.environ.get("ATTN_CHUNKS"):
