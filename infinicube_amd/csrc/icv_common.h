@@ -49,8 +49,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 __device__ __forceinline__ float gelu_tanh(float x) {
-  // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) == x * sigmoid(2u)
-  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  return x / (1.0f + __expf(-2.0f * u));
+  // 0.5 x (1 + tanh(u)) == x * sigmoid(2u) == x / (1 + 2^(-2u log2 e)),  u = sqrt(2/pi) (x + 0.044715 x^3).
+  // 7 VALU ops (2 transcendental): the constants are folded and the division is v_rcp_f32 (1 ulp; the result is
+  // rounded to bf16).  x -> -inf: 2^(+big) = inf, rcp = 0, result -0 like the exact function.
+  constexpr float C1 = 2.0f * 0.7978845608028654f * 1.4426950408889634f;   // 2 sqrt(2/pi) log2(e)
+  constexpr float C3 = C1 * 0.044715f;
+  const float w = x * fmaf(x * x, C3, C1);                                  // 2u log2(e)
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-w));
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
