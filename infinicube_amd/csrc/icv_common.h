@@ -32,15 +32,14 @@ __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(
 __device__ __forceinline__ float bf16lo_to_f32(unsigned v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float bf16hi_to_f32(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
 
-// round-to-nearest-even f32 -> bf16 (NaN-preserving enough for our ranges)
-__device__ __forceinline__ unsigned f32_to_bf16_bits(float f) {
-  unsigned u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return u >> 16;
-}
+// round-to-nearest-even f32 -> bf16 through the hardware converter (v_cvt_pk_bf16_f32 on gfx950: one instruction per
+// PAIR, where the integer add/shift idiom costs ~11)
+typedef __bf16 icv_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+  const icv_bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
 }
+__device__ __forceinline__ unsigned f32_to_bf16_bits(float f) { return pack_bf16x2(f, 0.f) & 0xffffu; }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
