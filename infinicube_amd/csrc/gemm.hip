@@ -142,8 +142,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
         const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
       }
-      const int64_t sub = n / p.nsplit, col = n - sub * p.nsplit;
-      const int64_t off = sub * p.split_stride + m * p.ldo + col;
+      const int64_t off = icv_out_offset(m, n, p.ldo, p.N, p.nsplit, p.split_stride);
       if (EPI == ICV_EPI_BF16 || EPI == ICV_EPI_GELU_BF16) {
         if (EPI == ICV_EPI_GELU_BF16) {
           v[0] = gelu_tanh(v[0]); v[1] = gelu_tanh(v[1]); v[2] = gelu_tanh(v[2]); v[3] = gelu_tanh(v[3]);
@@ -180,6 +179,7 @@ extern "C" int icv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t 
                              const float* resid, int64_t ldr, const float* gate, void* stream) {
   ICV_REQUIRE(A && W && out, "icv_gemm_bf16: null pointer");
   ICV_REQUIRE(M > 0 && N > 0 && K >= 64 && K % 64 == 0, "icv_gemm_bf16: K=%lld must be a positive multiple of 64", (long long)K);
+  ICV_REQUIRE(N < (1LL << 31), "icv_gemm_bf16: N=%lld too large", (long long)N);
   ICV_REQUIRE(N % 4 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldo % 4 == 0, "icv_gemm_bf16: N%%4, lda%%8, ldw%%8, ldo%%4 alignment");
   if (nsplit <= 0) nsplit = N;
   ICV_REQUIRE(nsplit % 4 == 0 && N % nsplit == 0, "icv_gemm_bf16: nsplit must divide N and be a multiple of 4");

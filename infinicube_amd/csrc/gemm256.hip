@@ -234,8 +234,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
         const float4 b = *reinterpret_cast<const float4*>(p.bias + n);                                 \
         v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;                                                    \
       }                                                                                                \
-      const int64_t sub = n / p.nsplit, col = n - sub * p.nsplit;                                      \
-      const int64_t off = sub * p.split_stride + m * p.ldo + col;                                      \
+      const int64_t off = icv_out_offset(m, n, p.ldo, p.N, p.nsplit, p.split_stride);                  \
       if (EPI == ICV_EPI_BF16 || EPI == ICV_EPI_GELU_BF16) {                                           \
         if (EPI == ICV_EPI_GELU_BF16) {                                                                \
           v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3);              \

@@ -205,8 +205,7 @@ __global__ __launch_bounds__(512) void gemm_fp8_kernel(Params p) {
           const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
           v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
         }
-        const int64_t sub = n / p.nsplit, col = n - sub * p.nsplit;
-        const int64_t off = sub * p.split_stride + m * p.ldo + col;
+        const int64_t off = icv_out_offset(m, n, p.ldo, p.N, p.nsplit, p.split_stride);
         if (EPI == ICV_EPI_BF16 || EPI == ICV_EPI_GELU_BF16) {
           if (EPI == ICV_EPI_GELU_BF16) {
             v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3);
@@ -253,7 +252,7 @@ extern "C" int icv_gemm_fp8(const void* A, int64_t lda, const float* a_scale, co
                             void* out, int64_t ldo, int64_t nsplit, int64_t split_stride, const float* resid,
                             int64_t ldr, const float* gate, void* stream) {
   ICV_REQUIRE(A && W && a_scale && w_scale && out, "icv_gemm_fp8: null pointer");
-  ICV_REQUIRE(M > 0 && N > 0 && K > 0, "icv_gemm_fp8: empty problem");
+  ICV_REQUIRE(M > 0 && N > 0 && K > 0 && N < (1LL << 31), "icv_gemm_fp8: empty problem or N too large");
   ICV_REQUIRE(K % 128 == 0, "icv_gemm_fp8: K=%lld must be a multiple of 128", (long long)K);
   ICV_REQUIRE(N % 4 == 0 && nsplit > 0 && nsplit % 4 == 0 && N % nsplit == 0, "icv_gemm_fp8: N=%lld / nsplit=%lld must be multiples of 4 with nsplit | N", (long long)N, (long long)nsplit);
   ICV_REQUIRE(lda % 16 == 0 && ldw % 16 == 0 && ldo % 4 == 0, "icv_gemm_fp8: lda/ldw must be multiples of 16 bytes, ldo of 4 elements");

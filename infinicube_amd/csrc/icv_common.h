@@ -41,6 +41,15 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 }
 __device__ __forceinline__ unsigned f32_to_bf16_bits(float f) { return pack_bf16x2(f, 0.f) & 0xffffu; }
 
+// Element offset of output (m, n) for the GEMM epilogues: plain [M, N] (nsplit == N) or split planes
+// [N / nsplit][M][nsplit].  A 64-bit n / nsplit per fragment cost more VALU than the GELU; the plain case needs no
+// division at all and the split case only a 32-bit one (N < 2^31 is checked by the dispatchers).
+__device__ __forceinline__ int64_t icv_out_offset(int64_t m, int64_t n, int64_t ldo, int64_t N, int64_t nsplit, int64_t split_stride) {
+  if (nsplit == N) return m * ldo + n;
+  const unsigned sub = (unsigned)n / (unsigned)nsplit;
+  return (int64_t)sub * split_stride + m * ldo + (int64_t)((unsigned)n - sub * (unsigned)nsplit);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
