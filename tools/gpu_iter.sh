@@ -1,3 +1,3 @@
+# scratch: one-off GPU experiment of the moment (run with: gpurun -- 'bash tools/gpu_iter.sh')
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_kernels_gpu.py -q -k "gemm" 2>&1 | grep -E "passed|failed|outside|Error" | head
-python tools/gemm_bench.py 2>&1 | cut -c1-110
+python bench.py --steps 2 --warmup 1 --no-cpu-baseline | tail -1
