@@ -67,6 +67,9 @@ class HipOps:
         if not torch.cuda.is_available():
             raise native.NativeError("HipOps: no GPU visible to PyTorch-ROCm; there is no CPU fallback")
         self.lib = native.lib()
+        # one process drives one GPU: kernels are launched on this device's current stream and the library keeps
+        # per-process (not per-device) launch attributes, so make it the process's current HIP device
+        torch.cuda.set_device(self.device)
         # kernel A/B switches (icv_set_option) from the environment, e.g. ICV_OPTIONS="attn2_variant=4,gemm256=1"
         for item in filter(None, os.environ.get("ICV_OPTIONS", "").split(",")):
             name, _, val = item.partition("=")
