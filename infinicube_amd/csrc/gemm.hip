@@ -168,6 +168,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 
 }  // namespace
 
+int icv_gemm256w_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                          int64_t M, int64_t N, int64_t K, int epilogue, void* out, int64_t ldo,
+                          int64_t nsplit, int64_t split_stride, const float* resid, int64_t ldr,
+                          const float* gate, hipStream_t st);
 int icv_gemm256_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                          int64_t M, int64_t N, int64_t K, int epilogue, void* out, int64_t ldo,
                          int64_t nsplit, int64_t split_stride, const float* resid, int64_t ldr,
@@ -190,6 +194,9 @@ extern "C" int icv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t 
   // quantisation-adjusted throughput; option gemm256 = 0 / 1 forces one kernel, 2 (default) = heuristic.
   if (N % 256 == 0 && M >= 256) {
     const int mode = icv_get_option_int("gemm256", 2);
+    if (mode == 3)   // experiment: 4 waves x (128 x 128), one wave per SIMD (gemm256w.hip)
+      return icv_gemm256w_dispatch(A, lda, W, ldw, bias, M, N, K, epilogue, out, ldo, nsplit, split_stride,
+                                   resid, ldr, gate, (hipStream_t)stream);
     bool use256 = mode == 1;
     if (mode == 2) {
       static int n_cu = 0;

@@ -691,6 +691,44 @@ def test_attention_add_into_output(hip_ops, Sq, Skv, H):
     assert bool((o[Sq:] == 9.0).all()), "wrote past the last query row"
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(256, 256, 64, "f32"), (300, 512, 192, "f32"), (1000, 768, 1536, "bf16"), (513, 1024, 512, "gelu"),
+                                       (640, 512, 1280, "resid"), (515, 768, 384, "split")])
+def test_gemm_4wave_variant(hip_ops, M, N, K, epi):
+    """gemm256w.hip (option gemm256 = 3): 4 waves x 128x128 wave tiles, accumulators pinned to AGPRs, fragments read one
+    half-phase ahead.  Same results as the default kernels for every epilogue and for ragged M."""
+    a = rnd((M, K), 431).to(torch.bfloat16)
+    w = rnd((N, K), 432, 1.0 / math.sqrt(K)).to(torch.bfloat16)
+    bias = rnd((N,), 433, 0.1)
+    acc = a.float() @ w.float().t() + bias
+    hip_ops.lib.icv_set_option(b"gemm256", 3)
+    try:
+        if epi == "f32":
+            out = torch.full((M + 1, N), 5.0, device=DEV)
+            hip_ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out[:M], EPI_F32)
+            assert_f32_close(out[:M], acc, what=f"gemm 4-wave {M}x{N}x{K}")
+            assert bool((out[M:] == 5.0).all()), "wrote past the last row"
+        elif epi == "bf16":
+            out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+            hip_ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out, EPI_BF16)
+            assert_bf16_close(out, acc, "gemm 4-wave bf16")
+        elif epi == "gelu":
+            out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+            hip_ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out, EPI_GELU_BF16)
+            assert_bf16_close(out, torch.nn.functional.gelu(acc, approximate="tanh"), "gemm 4-wave gelu", abs_floor=2.0 ** -8)
+        elif epi == "resid":
+            resid, gate = rnd((M, N), 434), rnd((N,), 435)
+            out = resid.clone().to(DEV)
+            hip_ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out, EPI_RESID_F32, resid=out, gate=gate.to(DEV))
+            assert_f32_close(out, resid + gate * acc, what="gemm 4-wave resid")
+        else:
+            ns = N // 3
+            out = torch.empty((3, M, ns), dtype=torch.bfloat16, device=DEV)
+            hip_ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out, EPI_BF16, nsplit=ns)
+            assert_bf16_close(out, acc.reshape(M, 3, ns).permute(1, 0, 2), "gemm 4-wave split planes")
+    finally:
+        hip_ops.lib.icv_set_option(b"gemm256", 2)
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 4, 64), (3, 68, 64), (255, 252, 192), (257, 260, 128), (513, 256, 64)])
 def test_gemm_ragged_shapes(hip_ops, M, N, K):
     a = rnd((M, K), 311).to(torch.bfloat16)

@@ -1,3 +1,3 @@
-# scratch: one-off GPU experiment of the moment (run with: gpurun -- 'bash tools/gpu_iter.sh')
 mkdir -p gpurun_out; export TMPDIR=/tmp
-python bench.py --steps 2 --warmup 1 --no-cpu-baseline | tail -1
+timeout 600 python -m pytest tests/test_kernels_gpu.py -q -k "4wave" 2>&1 | grep -E "passed|failed|outside|Error|max err" | head
+python tools/gemm_bench.py 2>&1 | grep -v amdgpu | awk -F'|' '{print $1 "|" $2 "|" $5}' | cut -c1-140
