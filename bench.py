@@ -145,7 +145,9 @@ def main():
     bsd = syn.make_buffer_embedder_state_dict(cfg, device=device, dtype=torch.bfloat16)
     model = WanDiT(cfg, sd, ops, bsd, gemm_dtype=args.gemm_dtype)
     del sd, bsd
-    model.prepare(grid, plan, sp_chunks=args.sp_chunks, group=layout.sp_group)
+    # graphs off: the bench times individual attention launches with events (at the metric's size the loop is GPU-bound
+    # and "auto" would not capture anyway)
+    model.prepare(grid, plan, sp_chunks=args.sp_chunks, group=layout.sp_group, graphs=False)
     clip = syn.make_clip_features(cfg) if cfg.has_image_input else None
     ctx_c = model.encode_context(syn.make_text_context(cfg, 1), clip)
     ctx_u = model.encode_context(syn.make_text_context(cfg, 2), clip)

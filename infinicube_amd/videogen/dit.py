@@ -32,6 +32,7 @@ HBM layout, the step-invariant caches and the sequence-parallel schedule:
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -195,10 +196,18 @@ class WanDiT:
         self.buffer_embedder = convs
 
     # ------------------------------------------------------------------------------------
+    GRAPH_MAX_TOKENS = 8192   # graphs="auto": only sizes whose forward is made of many short kernels (cfg #1: S = 2240)
+
     def prepare(self, grid: TokenGrid, plan: Optional[ShardPlan] = None, kv_gather=None, sp_chunks: int = 4,
-                group=None):
+                group=None, graphs=False):
         """Allocate the per-generation workspace for this token grid / shard.  ``group`` = the process group the
-        K/V all-gather runs in (seqpar.ParallelLayout.sp_group; None = the default group)."""
+        K/V all-gather runs in (seqpar.ParallelLayout.sp_group; None = the default group).
+        ``graphs``: replay each DiT forward (its ~25 launches x L layers) as ONE hipGraph instead of issuing the
+        kernels from Python: True / False / "auto" (= single-rank runs of at most GRAPH_MAX_TOKENS tokens on a GPU;
+        env ICV_GRAPHS=0|1 overrides).  The time embedding and the fused Euler step take a per-step scalar by value
+        and stay outside the graph.  Off by default: measured on MI355X the loop is not host-bound even at S = 400
+        (10.7 us per launch eagerly AND replayed - the cost is the GPU-side dispatch of many tiny kernels), so replay
+        buys nothing today; it is kept, tested bit-identical, for hosts that are slower at issuing launches."""
         cfg, ops = self.cfg, self.ops
         self.grid = grid
         self.plan = plan or ShardPlan.make(grid.S)
@@ -227,6 +236,14 @@ class WanDiT:
         self.t_e = a((1, d), F32)
         self.t_mod = a((1, 6 * d), F32)
         self._t_cached = None
+        env = os.environ.get("ICV_GRAPHS")
+        if env is not None:
+            graphs = env == "1"
+        if graphs == "auto":
+            graphs = n <= self.GRAPH_MAX_TOKENS
+        self._graphs_on = bool(graphs) and self.plan.world == 1 and getattr(ops, "device", None) is not None \
+            and torch.device(ops.device).type == "cuda"
+        self._graphs = {}
         if self.plan.world > 1:
             self.kv_full = a((2, S, d), BF16)                      # gathered K, V (chunk-major, rank-major inside)
             self.sp_acc = a((n, d), F32)                           # carried O accumulator between key chunks
@@ -370,6 +387,28 @@ class WanDiT:
         if cfg.has_image_input != (ctx.k_img is not None):
             raise ValueError("context was encoded without/with CLIP features but the DiT is/isn't i2v")
         self._time_state(timestep)
+        if self._graphs_on:
+            key = (id(ctx), latent.data_ptr(), 0 if buf_tokens is None else buf_tokens.data_ptr(), head_out.data_ptr(), num_layers)
+            entry = self._graphs.get(key)
+            if entry is None:
+                # first call with these buffers: run eagerly (that IS this call's result; it also lets every kernel do
+                # its one-time launch-attribute set-up), then record the same launch sequence for the later calls
+                self._forward_body(latent, ctx, buf_tokens, head_out, num_layers)
+                torch.cuda.synchronize(ops.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._forward_body(latent, ctx, buf_tokens, head_out, num_layers)
+                self._graphs[key] = (g, ctx, latent, buf_tokens, head_out)   # keep the captured buffers alive
+            else:
+                entry[0].replay()
+            return
+        self._forward_body(latent, ctx, buf_tokens, head_out, num_layers)
+
+    def _forward_body(self, latent, ctx, buf_tokens, head_out, num_layers):
+        """The launch sequence of one forward after the time state: patch embed, L blocks, head."""
+        cfg, ops, plan = self.cfg, self.ops, self.plan
+        d, H, n, eps = cfg.dim, cfg.num_heads, plan.n_tok, cfg.eps
+        scale = self.attn_scale
         # K1: patch embed (+ cached guidance-buffer tokens fused into the GEMM epilogue)
         ops.patchify(latent, self.patches, plan.tok0, n)
         if buf_tokens is not None:

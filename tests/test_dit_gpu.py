@@ -74,6 +74,34 @@ def test_denoise_loop_psnr(hip_ops):
     assert torch.equal(lat, lat2)
 
 
+def test_hipgraph_replay_equals_eager_launches(hip_ops):
+    """Launch-bound sizes replay each DiT forward as one hipGraph (WanDiT.prepare(graphs=...)): bit-identical to
+    issuing the kernels one by one, across steps (the per-step scalars stay outside the graph) and CFG branches."""
+    import time
+    cfg, grid = preset("small"), TokenGrid(17, 128, 160)
+    sd, bsd = syn.make_dit_state_dict(cfg), syn.make_buffer_embedder_state_dict(cfg)
+    noise, c1, c2, bl = syn.make_latent_noise(grid), syn.make_text_context(cfg, 1), syn.make_text_context(cfg, 2), syn.make_buffer_latents(cfg, grid)
+    res, times = {}, {}
+    for mode in (False, True):
+        m = WanDiT(cfg, sd, hip_ops, bsd).prepare(grid, graphs=mode)
+        assert m._graphs_on == mode
+        ck, cu, bt = m.encode_context(c1), m.encode_context(c2), m.embed_buffers(bl)
+        lat = noise.to("cuda:0")
+        m.denoise(lat, ck, cu, bt, FlowMatchScheduler(3), 5.0)          # first steps: eager + capture
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.denoise(lat, ck, cu, bt, FlowMatchScheduler(8), 5.0)          # replays (same buffers -> same graphs)
+        torch.cuda.synchronize()
+        times[mode], res[mode] = time.perf_counter() - t0, lat.clone()
+        if mode:
+            assert len(m._graphs) == 2                                  # one graph per CFG branch
+    print(f"8 steps, S={grid.S}: eager launches {times[False] * 1e3:.1f} ms, hipGraph replay {times[True] * 1e3:.1f} ms")
+    assert torch.equal(res[False], res[True])
+    # default off; "auto" = on for small token counts only
+    assert not WanDiT(cfg, sd, hip_ops, bsd).prepare(grid)._graphs_on
+    assert WanDiT(cfg, sd, hip_ops, bsd).prepare(grid, graphs="auto")._graphs_on and WanDiT.GRAPH_MAX_TOKENS < 37440
+
+
 def test_i2v_forward_and_loop_parity(hip_ops):
     """BASELINE.json config #5's image-conditioning branch at test size (in_dim 36, 257 CLIP tokens)."""
     cfg, grid = preset("tiny-i2v"), TokenGrid(9, 64, 96)
@@ -162,7 +190,7 @@ def test_sequence_parallel_path_on_one_gpu(hip_ops, chunks, model, gemm_dtype):
 
     hip_ops.attention = recording_attention
     try:
-        full = WanDiT(cfg, sd, hip_ops, bsd, gemm_dtype=gemm_dtype).prepare(grid)
+        full = WanDiT(cfg, sd, hip_ops, bsd, gemm_dtype=gemm_dtype).prepare(grid, graphs=False)   # ops are wrapped: no capture
         lat = noise.to("cuda:0")
         full.forward_tokens(lat, full.encode_context(ctx, clip), 300.0, additive(full), full.head_out[0])
         torch.cuda.synchronize()
@@ -231,7 +259,7 @@ def test_sequence_parallel_gather_on_rccl_stream(hip_ops):
 
     hip_ops.attention = recording_attention
     try:
-        full = WanDiT(cfg, sd, hip_ops, bsd).prepare(grid)
+        full = WanDiT(cfg, sd, hip_ops, bsd).prepare(grid, graphs=False)   # ops are wrapped: no capture
         lat = noise.to("cuda:0")
         full.forward_tokens(lat, full.encode_context(ctx), 300.0, full.embed_buffers(bl), full.head_out[0])
         torch.cuda.synchronize()
