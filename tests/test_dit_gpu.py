@@ -102,6 +102,23 @@ def test_hipgraph_replay_equals_eager_launches(hip_ops):
     assert WanDiT(cfg, sd, hip_ops, bsd).prepare(grid, graphs="auto")._graphs_on and WanDiT.GRAPH_MAX_TOKENS < 37440
 
 
+def test_dual_stream_cfg_equals_sequential(hip_ops, monkeypatch):
+    """ICV_DUAL_STREAM=1: cond / uncond forwards on two HIP streams in twin engines sharing the weights — same latents."""
+    cfg, grid = preset("small"), TokenGrid(17, 128, 160)
+    sd, bsd = syn.make_dit_state_dict(cfg), syn.make_buffer_embedder_state_dict(cfg)
+    noise, c1, c2, bl = syn.make_latent_noise(grid), syn.make_text_context(cfg, 1), syn.make_text_context(cfg, 2), syn.make_buffer_latents(cfg, grid)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ICV_DUAL_STREAM", mode)
+        m = WanDiT(cfg, sd, hip_ops, bsd).prepare(grid)
+        assert m.dual_stream == (mode == "1")
+        lat = noise.to("cuda:0")
+        m.denoise(lat, m.encode_context(c1), m.encode_context(c2), m.embed_buffers(bl), FlowMatchScheduler(5), 5.0)
+        torch.cuda.synchronize()
+        res[mode] = lat.clone()
+    assert torch.equal(res["0"], res["1"])
+
+
 def test_i2v_forward_and_loop_parity(hip_ops):
     """BASELINE.json config #5's image-conditioning branch at test size (in_dim 36, 257 CLIP tokens)."""
     cfg, grid = preset("tiny-i2v"), TokenGrid(9, 64, 96)
