@@ -103,6 +103,8 @@ def main():
     # bf16 is the metric's dtype; fp8 = BASELINE.json config #5's "fp8 MFMA weights" mode (e4m3 projections,
     # bf16 attention) and is reported as such, never as the headline number
     ap.add_argument("--gemm-dtype", default=os.environ.get("ICV_BENCH_GEMM_DTYPE", "bf16"), choices=["bf16", "fp8"])
+    ap.add_argument("--attn-dtype", default=os.environ.get("ICV_BENCH_ATTN_DTYPE", "bf16"), choices=["bf16", "fp8"],
+                    help="fp8: e4m3 self-attention (single-GPU runs of the fp8 mode only; reported as such)")
     ap.add_argument("--frames", type=int, default=GRID_480P.num_frames)
     ap.add_argument("--height", type=int, default=GRID_480P.height)
     ap.add_argument("--width", type=int, default=GRID_480P.width)
@@ -143,7 +145,7 @@ def main():
     # ---- synthetic weights / inputs, resident in HBM before timing (SURVEY.md §8d recipe) ----
     sd = syn.make_dit_state_dict(cfg, seed=0, device=device, dtype=torch.bfloat16)
     bsd = syn.make_buffer_embedder_state_dict(cfg, device=device, dtype=torch.bfloat16)
-    model = WanDiT(cfg, sd, ops, bsd, gemm_dtype=args.gemm_dtype)
+    model = WanDiT(cfg, sd, ops, bsd, gemm_dtype=args.gemm_dtype, attn_dtype=args.attn_dtype)
     del sd, bsd
     # graphs off: the bench times individual attention launches with events (at the metric's size the loop is GPU-bound
     # and "auto" would not capture anyway)
@@ -174,6 +176,19 @@ def main():
             raw_attention(q, k, v, o, heads, scale)
 
     ops.attention = timed_attention
+    raw_attention8 = ops.attention_fp8
+
+    def timed_attention8(q, k, v, o, heads, ws):     # fp8 mode: prepare + forward timed together
+        if record["on"]:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            raw_attention8(q, k, v, o, heads, ws)
+            e1.record()
+            attn_events.append((e0, e1))
+        else:
+            raw_attention8(q, k, v, o, heads, ws)
+
+    ops.attention_fp8 = timed_attention8
     raw_chunk = ops.attention_chunk
     chunk_events = []
 
@@ -242,7 +257,8 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "bf16" if args.gemm_dtype == "bf16" else "fp8 e4m3 projections (f32 accumulate) + bf16 attention",
+            "dtype": "bf16" if (args.gemm_dtype, args.attn_dtype) == ("bf16", "bf16") else
+                     f"projections {args.gemm_dtype}, self-attention {args.attn_dtype} (e4m3 operands, f32 accumulate), rest bf16/f32",
             "data": "synthetic (seeded latents/text context/guidance-buffer latents, random-init weights of the named architecture)",
             "config": {
                 "workload": f"Wan2.1-{args.model.upper()} {'i2v' if cfg.has_image_input else 't2v'} DiT, {args.frames} frames {args.height}x{args.width}, "
@@ -260,7 +276,8 @@ def main():
                 "frac_of_bf16_mfma_peak": f_step * args.steps / elapsed / 1e12 / (PEAK_BF16_TFLOPS * world),
             },
             "roofline": {
-                "kernel": "att7::attn7_kernel (self-attention, K6)",
+                "kernel": "att7::attn7_kernel (self-attention, K6)" if args.attn_dtype == "bf16" else
+                          "att8::attn8_kernel + its quantise pre-pass (e4m3 self-attention, K6)",
                 "bound": "mfma", "achieved": attn_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": attn_tflops / PEAK_BF16_TFLOPS, "traffic": traffic,
                 "avg_launch_ms": attn_ms, "launches_timed": len(attn_events),

@@ -127,6 +127,23 @@ int icv_attention_fwd_add(const void* q, int64_t ldq, const void* k, int64_t ldk
                           int64_t ldv, void* o, int64_t ldo, int64_t Sq, int64_t Skv, int64_t heads,
                           float scale, void* stream);
 
+/* ---- K6 / K9 in the fp8 mode (BASELINE.json config #5, "CDNA4 fp8 path"): e4m3 attention ------------------
+ * Both GEMMs of attention on v_mfma_scale_f32_32x32x64_f8f6f4.  Not a behaviour of the reference (it runs bf16
+ * flash attention through diffsynth); selected by this build's WanDiT(attn_dtype="fp8").
+ * icv_attention_fp8_prepare: q (may be NULL: keys / values only), k, v bf16 [S, H*128] -> per-head abs-max
+ *   amax f32 [3, H] (q, k, v rows; power-of-two scales 2^ceil(log2(amax/448)) are derived from it), qq / kq e4m3
+ *   [S, H*128] (ld in bytes), vt e4m3 transposed key-permuted tiles [H][ceil(Skv/64)][128][64]
+ *   (icv_attention_fp8_vt_bytes gives its size).  K must already carry the softmax scale * log2(e) ("unit scale").
+ * icv_attention_fp8_fwd: o bf16 [Sq, H*128] = softmax2(qq kq^T) v  (exp2, i.e. natural softmax of the unscaled
+ *   product when K carries (1/sqrt d) log2 e). */
+int64_t icv_attention_fp8_vt_bytes(int64_t Skv, int64_t heads);
+int icv_attention_fp8_prepare(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                              int64_t Sq, int64_t Skv, int64_t heads, void* qq, int64_t ldqq, void* kq,
+                              int64_t ldkq, void* vt, float* amax, void* stream);
+int icv_attention_fp8_fwd(const void* qq, int64_t ldqq, const void* kq, int64_t ldkq, const void* vt,
+                          const float* amax, void* o, int64_t ldo, int64_t Sq, int64_t Skv, int64_t heads,
+                          void* stream);
+
 /* ---- K6 split along the KEY axis (K13 overlap): attention over one chunk of keys with a carried
  * online-softmax state, so the sequence-parallel path can consume K/V chunks as the RCCL all-gather
  * delivers them.  State = acc f32 [Sq, H*128] (ldacc; un-normalised O) + ml f32 [Sq, H, 2] (running

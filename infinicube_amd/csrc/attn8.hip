@@ -1,0 +1,412 @@
+// fp8 (OCP e4m3) flash attention forward for the fp8 mode (BASELINE.json config #5 "CDNA4 fp8 path"): both GEMMs of
+// attention on v_mfma_scale_f32_32x32x64_f8f6f4 (twice the bf16 MFMA rate, half the LDS / DMA bytes per key).
+//
+//   icv_attention_fp8_prepare : per-head abs-max of Q, K, V -> power-of-two scales 2^e (e = ceil(log2(amax / 448)));
+//                               Qq, Kq = e4m3(x * 2^-e) row-major [S, H*128] bytes;  V is written TRANSPOSED and
+//                               key-permuted per 64-key tile: Vt[head][tile][d = 0..127][64 bytes], byte g*32 + j of a
+//                               row = V[key(g, j)][d] with key(g, j) = (j>>4)*32 + (j&3) + 8*((j&15)>>2) + 4*g — exactly
+//                               the k-slot order in which a lane of the S^T accumulator holds its 32 keys of the tile.
+//   icv_attention_fp8_fwd     : attn7.hip's structure (LDS-DMA ring, lazy max, unit scale with the reference in the
+//                               first MFMA's C operand) with
+//       S^T = Kq Qq^T : 2 MFMAs (K = 64 each) per 32-key block instead of 8; the power-of-two scales of Q and K ride
+//                       in the MFMA's E8M0 block-scale operands, so S arrives in log2 units with no VALU at all
+//                       (K already carries (1/sqrt d) log2 e: the DiT folds it into the K RMSNorm weight);
+//       O^T += Vt P^T : ONE MFMA (K = 64 keys) per 32-row d block; P is packed to e4m3 lane-locally in accumulator
+//                       order (16 v_cvt_pk_fp8_f32), Vt fragments are two plain ds_read_b128 (no transposing read).
+// Operand layout of the f8f6f4 MFMAs (lane (r = lane & 31, g = lane >> 5) holds K-bytes [32 g, 32 g + 32) of row r)
+// and the scale semantics (E8M0 127 = 1.0) were probed on hardware: tools/probe_f8.hip.
+#include "attn_common.h"
+
+namespace att8 {
+
+using attc::D;
+using attc::NEG_BIG;
+constexpr int KVB = 64;
+constexpr int QB = 256;
+constexpr int KT_BYTES = KVB * D;          // 8 KiB: K tile [64 keys][128 B]
+constexpr int VT_BYTES = D * KVB;          // 8 KiB: V^T tile [128 d][64 B]
+constexpr int STAGE_BYTES = KT_BYTES + VT_BYTES;
+constexpr int NSTAGE = 4;
+constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;   // 64 KiB
+constexpr float FP8_MAX = 448.0f;
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int scale_exp(float amax) {   // e with 2^e >= amax / 448
+  return amax > 0.f ? (int)ceilf(log2f(amax / FP8_MAX)) : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// prepare, pass 1: per-head abs-max (bits of a non-negative float order like ints -> atomicMax on the int view)
+// block = 256 threads = 16 rows x 16 lanes (a lane owns 8 consecutive elements of a head's 128), grid (heads, row blocks)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void amax_kernel(const bf16_t* __restrict__ x, int64_t ld, int64_t rows, int* __restrict__ amax_bits) {
+  const int head = blockIdx.x;
+  const int lane16 = threadIdx.x & 15, rsub = threadIdx.x >> 4;
+  float m = 0.f;
+  for (int64_t r = (int64_t)blockIdx.y * 256 + rsub; r < min(rows, (int64_t)(blockIdx.y + 1) * 256); r += 16) {
+    const uint4 u = *reinterpret_cast<const uint4*>(x + r * ld + head * D + lane16 * 8);
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m = fmaxf(m, fmaxf(fabsf(__uint_as_float(w[i] << 16)), fabsf(__uint_as_float(w[i] & 0xFFFF0000u))));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(amax_bits + head, __float_as_int(m));
+}
+
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (unsigned)w;
+}
+
+// pass 2a: Q / K rows -> e4m3 [rows, H*128] with the head's power-of-two scale
+__global__ __launch_bounds__(256) void quant_rows_kernel(const bf16_t* __restrict__ x, int64_t ld, int64_t rows,
+                                                         const float* __restrict__ amax, unsigned char* __restrict__ out, int64_t ldo) {
+  const int head = blockIdx.x;
+  const int lane16 = threadIdx.x & 15, rsub = threadIdx.x >> 4;
+  const float inv = exp2f((float)-scale_exp(amax[head]));
+  for (int64_t r = (int64_t)blockIdx.y * 256 + rsub; r < min(rows, (int64_t)(blockIdx.y + 1) * 256); r += 16) {
+    const uint4 u = *reinterpret_cast<const uint4*>(x + r * ld + head * D + lane16 * 8);
+    const float f0 = __uint_as_float(u.x << 16), f1 = __uint_as_float(u.x & 0xFFFF0000u);
+    const float f2 = __uint_as_float(u.y << 16), f3 = __uint_as_float(u.y & 0xFFFF0000u);
+    const float f4 = __uint_as_float(u.z << 16), f5 = __uint_as_float(u.z & 0xFFFF0000u);
+    const float f6 = __uint_as_float(u.w << 16), f7 = __uint_as_float(u.w & 0xFFFF0000u);
+    *reinterpret_cast<uint2*>(out + r * ldo + head * D + lane16 * 8) =
+        make_uint2(pack_fp8x4(f0 * inv, f1 * inv, f2 * inv, f3 * inv), pack_fp8x4(f4 * inv, f5 * inv, f6 * inv, f7 * inv));
+  }
+}
+
+// key of k-slot j (0..31) of lane group g (0..1) inside a 64-key tile: the S^T accumulator order (see the header)
+__device__ __host__ __forceinline__ int tile_key(int g, int j) { return (j >> 4) * 32 + (j & 3) + 8 * ((j & 15) >> 2) + 4 * g; }
+
+// pass 2b: V -> transposed, key-permuted e4m3 tiles.  One block per (tile, head): 256 threads, thread t -> d = t >> 1, g = t & 1.
+__global__ __launch_bounds__(256) void quant_vt_kernel(const bf16_t* __restrict__ v, int64_t ld, int64_t Skv,
+                                                       const float* __restrict__ amax, unsigned char* __restrict__ vt, int ntiles) {
+  __shared__ bf16_t tile[KVB][D + 8];   // +8: column reads hit different banks
+  const int t = blockIdx.x, head = blockIdx.y;
+  const float inv = exp2f((float)-scale_exp(amax[head]));
+  for (int i = threadIdx.x; i < KVB * 16; i += 256) {   // 64 rows x 16 chunks of 8 elements
+    const int key = i >> 4, c = i & 15;
+    const int64_t r = (int64_t)t * KVB + key;
+    uint4 u = make_uint4(0, 0, 0, 0);                      // keys past Skv: zeros (their P is masked to 0 anyway)
+    if (r < Skv) u = *reinterpret_cast<const uint4*>(v + r * ld + head * D + c * 8);
+    *reinterpret_cast<uint4*>(&tile[key][c * 8]) = u;
+  }
+  __syncthreads();
+  const int d = threadIdx.x >> 1, g = threadIdx.x & 1;
+  unsigned w[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    float f[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = __uint_as_float(((unsigned)tile[tile_key(g, q * 4 + e)][d]) << 16) * inv;
+    w[q] = pack_fp8x4(f[0], f[1], f[2], f[3]);
+  }
+  uint4* dst = reinterpret_cast<uint4*>(vt + (((int64_t)head * ntiles + t) * D + d) * KVB + g * 32);
+  dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------------
+struct Params {
+  const unsigned char* q; int64_t ldq;     // e4m3 [Sq, H*128]
+  const unsigned char* k; int64_t ldk;     // e4m3 [Skv, H*128]
+  const unsigned char* vt;                 // e4m3 [H][ntiles][128][64]
+  const float* amax;                       // f32 [3][H]: q, k, v
+  bf16_t* o; int64_t ldo;
+  int64_t Sq, Skv;
+  int heads, nqb, ntiles;
+  float thr;
+};
+
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+__device__ __forceinline__ i32x8 read32(const char* p0, const char* p1) {
+  const i32x4 lo = *reinterpret_cast<const i32x4*>(p0);
+  const i32x4 hi = *reinterpret_cast<const i32x4*>(p1);
+  return (i32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+// VAR bit flags: 1 = wave groups one tile apart, 4 = s_setprio(1) around MFMA clusters
+template <int VAR>
+__global__ __launch_bounds__(512) void attn8_kernel(Params p) {
+  constexpr bool STAGGER = VAR & 1, SETPRIO = VAR & 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int l31 = lane & 31;
+  const float p_lim = __builtin_amdgcn_exp2f(p.thr);
+
+  // (head, query block) with the XCD-aware remap of attn_common.h
+  int head, qb;
+  {
+    const int nwg = p.heads * p.nqb;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int qn = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (qn + 1) : r * (qn + 1) + (xcd - r) * qn) + local;
+    head = wg / p.nqb;
+    qb = wg - head * p.nqb;
+  }
+  const int64_t q0 = (int64_t)qb * QB + wave * 32;
+  int64_t qr_c = q0 + l31;
+  qr_c = qr_c < p.Sq ? qr_c : p.Sq - 1;
+
+  // E8M0 block scales of the three operands (one power of two per head)
+  const int sQ = 127 + scale_exp(p.amax[head]), sK = 127 + scale_exp(p.amax[p.heads + head]);
+  const int sV = 127 + scale_exp(p.amax[2 * p.heads + head]);
+
+  // Q fragments: lane (q = lane & 31, g = hi) holds bytes [64 s + 32 g, +32) of its row, s = 0, 1
+  i32x8 qf[2];
+  {
+    const unsigned char* qp = p.q + qr_c * p.ldq + (int64_t)head * D + hi * 32;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) qf[s] = read32(reinterpret_cast<const char*>(qp + s * 64), reinterpret_cast<const char*>(qp + s * 64 + 16));
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // retire ordinary loads before any LDS-DMA is in flight (see attn4.hip)
+
+  f32x16 ot[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[i][r] = 0.f;
+  float m_run = NEG_BIG, l_run = 0.f;
+  float m_base = 0.f;                    // reference baked into cinit (0 while there is no reference yet)
+  f32x16 cinit;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
+
+  // ---- LDS-DMA lane mapping ----
+  // K tile: wave w covers key rows 8w..8w+7 (8 lanes x 16 B per row); physical chunk pc holds logical pc ^ ((row >> 1) & 7)
+  const int krow = wave * 8 + (lane >> 3);
+  const int kcol = ((lane & 7) ^ ((krow >> 1) & 7)) * 16;
+  // V^T tile: wave w covers bytes [1024 w, +1024) = d rows 16w..16w+15 (4 lanes x 16 B per row); pc holds pc ^ ((d >> 2) & 3)
+  const int vrow = wave * 16 + (lane >> 2);
+  const int vcol = ((lane & 3) ^ ((vrow >> 2) & 3)) * 16;
+  const int nt = p.ntiles;
+  const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+  const unsigned char* kh = p.k + (int64_t)head * D;
+  const unsigned char* vth = p.vt + (int64_t)head * nt * (D * KVB);
+#define A8_DMA_TILE(T_)                                                                              \
+  {                                                                                                  \
+    const int tt_ = (T_) < nt ? (T_) : nt - 1;                                                       \
+    int64_t kr_ = (int64_t)tt_ * KVB + krow;                                                         \
+    kr_ = kr_ < p.Skv ? kr_ : p.Skv - 1;                                                             \
+    const unsigned l0_ = lds_base + (unsigned)(((T_) & (NSTAGE - 1)) * STAGE_BYTES + wave * 1024);   \
+    dma16(kh + kr_ * p.ldk + kcol, l0_);                                                             \
+    dma16(vth + ((int64_t)tt_ * D + vrow) * KVB + vcol, l0_ + KT_BYTES);                             \
+  }
+#define A8_VMCNT2() asm volatile("s_waitcnt vmcnt(2)" ::: "memory")
+#define A8_BARRIER()                                          \
+  do {                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        \
+    __builtin_amdgcn_s_barrier();                             \
+    asm volatile("" ::: "memory");                            \
+    __builtin_amdgcn_sched_barrier(0);                        \
+  } while (0)
+
+  const int grp = STAGGER ? (wave >> 2) : 0;
+  A8_DMA_TILE(0);
+  A8_DMA_TILE(1);
+  A8_VMCNT2();
+  A8_BARRIER();
+  if (grp == 1) {
+    A8_DMA_TILE(2);
+    A8_VMCNT2();
+    A8_BARRIER();
+  }
+  const int ahead = 2 + grp;
+
+  // fragment read offsets: K row l31 (+32 per key block), chunks 4s + 2hi, +1;  V^T row d0*32 + l31, chunks 2hi, 2hi+1
+  const int k_sw = (l31 >> 1) & 7;          // (key >> 1) & 7 is the same for key and key + 32
+  const int k_row = l31 * 128;
+  const int v_sw0 = (l31 >> 2) & 3;          // ((d0*32 + l31) >> 2) & 3 == (l31 >> 2) & 3
+
+  for (int t = 0; t < nt; ++t) {
+    const char* ks = smem + (t & (NSTAGE - 1)) * STAGE_BYTES;
+    const char* vs = ks + KT_BYTES;
+    const int64_t key0 = (int64_t)t * KVB;
+    A8_DMA_TILE(t + ahead);
+
+    // ---- S^T = Kq Qq^T (4 MFMAs), scales in the MFMA, reference in the C operand of the first step ----
+    f32x16 st[2];
+    const bool no_ref = m_run < -1.0e29f;
+    if (SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const int c0 = 4 * s + 2 * hi;
+        const char* rowp = ks + kb * 4096 + k_row;
+        const i32x8 kf = read32(rowp + ((c0 ^ k_sw) << 4), rowp + (((c0 + 1) ^ k_sw) << 4));
+        st[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf[s], s == 0 ? cinit : st[kb], 0, 0, 0, sK, 0, sQ);
+      }
+    if (SETPRIO) __builtin_amdgcn_s_setprio(0);
+    if (key0 + KVB > p.Skv) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= p.Skv) st[kb][r] = NEG_BIG;
+        }
+    }
+    // ---- lazy-max softmax at unit scale (attn2.hip / attn7.hip) over the whole 64-key tile: P = exp2(S) against
+    // the reference in the accumulators; its partial row sum bounds every P, so only when it exceeds 2^thr (or there is
+    // no reference yet) the tile's true max is taken, O / l rescaled, the scores re-based and P recomputed ----
+    float pv[2][16];
+    float ps = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pv[kb][r] = __builtin_amdgcn_exp2f(st[kb][r]);
+        ps += pv[kb][r];
+      }
+    if (__any(!(ps <= p_lim) || no_ref)) {
+      float mloc = st[0][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[0][r]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[1][r]);
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) + m_base;       // st = s - m_base
+      const float m_new = fmaxf(m_run, mloc);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
+      const float dm = m_new - m_base;
+      m_base = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cinit[r] = -m_new;
+      ps = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          pv[kb][r] = __builtin_amdgcn_exp2f(st[kb][r] - dm);
+          ps += pv[kb][r];
+        }
+    }
+    l_run += ps;
+    i32x8 pf;   // P^T operand: the lane's 32 keys in k-slot order j = kb*16 + r (tile_key), 4 e4m3 per dword
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; r += 4) pf[kb * 4 + (r >> 2)] = (int)pack_fp8x4(pv[kb][r], pv[kb][r + 1], pv[kb][r + 2], pv[kb][r + 3]);
+    // ---- O^T += Vt P^T : one MFMA per 32-row d block ----
+    if (SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int d0 = 0; d0 < 4; ++d0) {
+      const char* rowp = vs + (d0 * 32 + l31) * 64;
+      const i32x8 vf = read32(rowp + (((2 * hi) ^ v_sw0) << 4), rowp + (((2 * hi + 1) ^ v_sw0) << 4));
+      ot[d0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, pf, ot[d0], 0, 0, 0, sV, 0, 127);
+    }
+    if (SETPRIO) __builtin_amdgcn_s_setprio(0);
+
+    A8_VMCNT2();
+    A8_BARRIER();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (grp == 0 && STAGGER) A8_BARRIER();
+
+  // ---- epilogue: normalise and store bf16 (layout of attn_common.h store_result) ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const int64_t qr = q0 + l31;
+  if (qr < p.Sq) {
+    const float inv = 1.0f / l_tot;
+    bf16_t* op = p.o + qr * p.ldo + (int64_t)head * D + 4 * hi;
+#pragma unroll
+    for (int d0 = 0; d0 < 4; ++d0)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        *reinterpret_cast<uint2*>(op + d0 * 32 + rr * 8) =
+            make_uint2(pack_bf16x2(ot[d0][rr * 4 + 0] * inv, ot[d0][rr * 4 + 1] * inv), pack_bf16x2(ot[d0][rr * 4 + 2] * inv, ot[d0][rr * 4 + 3] * inv));
+  }
+}
+
+template <int VAR>
+int launch(const Params& p, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn8_kernel<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) {
+      icv_set_error("attn8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return 2;
+    }
+    attr_set = true;
+  }
+  const int64_t nwg = (int64_t)p.heads * p.nqb;
+  hipLaunchKernelGGL(attn8_kernel<VAR>, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p);
+  return icv_check_launch("icv_attention_fp8_fwd");
+}
+
+}  // namespace att8
+
+extern "C" int64_t icv_attention_fp8_vt_bytes(int64_t Skv, int64_t heads) {
+  return heads * ((Skv + att8::KVB - 1) / att8::KVB) * (int64_t)(att8::D * att8::KVB);
+}
+
+extern "C" int icv_attention_fp8_prepare(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                                         int64_t Sq, int64_t Skv, int64_t heads, void* qq, int64_t ldqq, void* kq,
+                                         int64_t ldkq, void* vt, float* amax, void* stream) {
+  ICV_REQUIRE(k && v && kq && vt && amax, "icv_attention_fp8_prepare: null pointer");
+  ICV_REQUIRE((q == nullptr) == (qq == nullptr), "icv_attention_fp8_prepare: q and qq go together");
+  ICV_REQUIRE(Skv > 0 && heads > 0 && (q == nullptr || Sq > 0), "icv_attention_fp8_prepare: empty problem");
+  ICV_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldqq % 16 == 0 && ldkq % 16 == 0, "icv_attention_fp8_prepare: leading dims must keep 16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  ICV_REQUIRE(hipMemsetAsync(amax, 0, sizeof(float) * 3 * heads, st) == hipSuccess, "icv_attention_fp8_prepare: memset failed");
+  int* ab = reinterpret_cast<int*>(amax);
+  const int nt = (int)((Skv + att8::KVB - 1) / att8::KVB);
+  if (q) hipLaunchKernelGGL(att8::amax_kernel, dim3((unsigned)heads, (unsigned)((Sq + 255) / 256)), dim3(256), 0, st, (const bf16_t*)q, ldq, Sq, ab);
+  hipLaunchKernelGGL(att8::amax_kernel, dim3((unsigned)heads, (unsigned)((Skv + 255) / 256)), dim3(256), 0, st, (const bf16_t*)k, ldk, Skv, ab + heads);
+  hipLaunchKernelGGL(att8::amax_kernel, dim3((unsigned)heads, (unsigned)((Skv + 255) / 256)), dim3(256), 0, st, (const bf16_t*)v, ldv, Skv, ab + 2 * heads);
+  if (q) hipLaunchKernelGGL(att8::quant_rows_kernel, dim3((unsigned)heads, (unsigned)((Sq + 255) / 256)), dim3(256), 0, st, (const bf16_t*)q, ldq, Sq, amax, (unsigned char*)qq, ldqq);
+  hipLaunchKernelGGL(att8::quant_rows_kernel, dim3((unsigned)heads, (unsigned)((Skv + 255) / 256)), dim3(256), 0, st, (const bf16_t*)k, ldk, Skv, amax + heads, (unsigned char*)kq, ldkq);
+  hipLaunchKernelGGL(att8::quant_vt_kernel, dim3((unsigned)nt, (unsigned)heads), dim3(256), 0, st, (const bf16_t*)v, ldv, Skv, amax + 2 * heads, (unsigned char*)vt, nt);
+  return icv_check_launch("icv_attention_fp8_prepare");
+}
+
+extern "C" int icv_attention_fp8_fwd(const void* qq, int64_t ldqq, const void* kq, int64_t ldkq, const void* vt,
+                                     const float* amax, void* o, int64_t ldo, int64_t Sq, int64_t Skv, int64_t heads,
+                                     void* stream) {
+  ICV_REQUIRE(qq && kq && vt && amax && o, "icv_attention_fp8_fwd: null pointer");
+  ICV_REQUIRE(Sq > 0 && Skv > 0 && heads > 0, "icv_attention_fp8_fwd: empty problem");
+  ICV_REQUIRE(ldqq % 16 == 0 && ldkq % 16 == 0 && ldo % 4 == 0, "icv_attention_fp8_fwd: leading dims must keep 16-byte row alignment");
+  att8::Params p;
+  p.q = (const unsigned char*)qq; p.ldq = ldqq; p.k = (const unsigned char*)kq; p.ldk = ldkq; p.vt = (const unsigned char*)vt;
+  p.amax = amax; p.o = (bf16_t*)o; p.ldo = ldo; p.Sq = Sq; p.Skv = Skv; p.heads = (int)heads;
+  p.nqb = (int)((Sq + att8::QB - 1) / att8::QB);
+  p.ntiles = (int)((Skv + att8::KVB - 1) / att8::KVB);
+  p.thr = (float)icv_get_option_int("attn_defer_max_log2", 8);
+  ICV_REQUIRE((int64_t)p.heads * p.nqb < (1LL << 31), "icv_attention_fp8_fwd: grid too large");
+  switch (icv_get_option_int("attn8_variant", 5)) {
+    case 0: return att8::launch<0>(p, (hipStream_t)stream);
+    case 1: return att8::launch<1>(p, (hipStream_t)stream);
+    case 4: return att8::launch<4>(p, (hipStream_t)stream);
+    case 5: return att8::launch<5>(p, (hipStream_t)stream);
+  }
+  icv_set_error("icv_attention_fp8_fwd: unknown attn8_variant");
+  return 1;
+}

@@ -10,7 +10,7 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$root/include" -I"$here" -W
 objs=()
 pids=()
 mkdir -p "$here/build"
-for src in api elementwise gemm gemm256 gemm256w gemm_fp8 fp8 attn attn2 attn3 attn4 attn5 attn6 attn7 buffers; do
+for src in api elementwise gemm gemm256 gemm256w gemm_fp8 fp8 attn attn2 attn3 attn4 attn5 attn6 attn7 attn8 buffers; do
   obj="$here/build/$src.o"
   if [[ ! -f "$obj" || "$here/$src.hip" -nt "$obj" || "$here/icv_common.h" -nt "$obj" || "$here/attn_common.h" -nt "$obj" || "$root/include/icvideo.h" -nt "$obj" ]]; then
     "$HIPCC" "${FLAGS[@]}" "$@" -c "$here/$src.hip" -o "$obj" &

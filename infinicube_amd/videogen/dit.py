@@ -59,12 +59,18 @@ class WanDiT:
     FP8_WEIGHTS = ("wqkv", "wo", "xq_w", "xo_w", "f0_w", "f2_w")
 
     def __init__(self, cfg: WanDiTConfig, state_dict: Dict[str, torch.Tensor], ops,
-                 buffer_embedder_sd: Optional[Dict[str, torch.Tensor]] = None, gemm_dtype: str = "bf16"):
+                 buffer_embedder_sd: Optional[Dict[str, torch.Tensor]] = None, gemm_dtype: str = "bf16",
+                 attn_dtype: str = "bf16"):
         self.cfg = cfg.validate()
         self.ops = ops
         if gemm_dtype not in ("bf16", "fp8"):
             raise ValueError(f"gemm_dtype must be 'bf16' or 'fp8', got {gemm_dtype!r}")
         self.fp8 = gemm_dtype == "fp8"
+        if attn_dtype not in ("bf16", "fp8"):
+            raise ValueError(f"attn_dtype must be 'bf16' or 'fp8', got {attn_dtype!r}")
+        # fp8 self-attention (e4m3 Q/K/V/P on the K=64 scaled MFMA, csrc/attn8.hip): single-rank runs only; cross-attention
+        # (512 + 257 keys, 1 % of the flops) and the sequence-parallel chunked path stay bf16
+        self.attn_fp8 = attn_dtype == "fp8"
         if self.fp8 and (cfg.dim % 128 or cfg.ffn_dim % 128):
             raise ValueError("fp8 GEMMs need dim and ffn_dim to be multiples of 128")
         d = cfg.dim
@@ -221,6 +227,7 @@ class WanDiT:
         self.qkv = a((3, n, d), BF16)
         self.att = a((n, d), BF16)
         self.ff = a((n, cfg.ffn_dim), BF16)
+        self.attn8_ws = ops.attention_fp8_buffers(n, n, d, cfg.num_heads) if (self.attn_fp8 and self.plan.world == 1) else None
         self.h8 = self.h8s = self.att8 = self.att8s = self.ff8 = self.ff8s = None
         if self.fp8:
             self.h8, self.h8s = a((n, d), FP8), a((n,), F32)
@@ -443,7 +450,10 @@ class WanDiT:
             else:
                 self._mm(h, lw["wqkv"], lw["bqkv"], self.qkv, EPI_BF16, nsplit=d)           # K4
                 ops.rmsnorm_rope(q, lw["nq"], k, lw["nk"], eps=eps, rope=self.rope, tok0=plan.tok0)  # K5
-                ops.attention(q, k, v, self.att, H, scale)                                  # K6
+                if self.attn8_ws is not None:
+                    ops.attention_fp8(q, k, v, self.att, H, self.attn8_ws)                  # K6 (e4m3)
+                else:
+                    ops.attention(q, k, v, self.att, H, scale)                              # K6
             a = self._operand(self.att, self.att8, self.att8s)
             self._mm(a, lw["wo"], lw["bo"], self.x, EPI_RESID_F32, resid=self.x, gate=g1)   # K7
             # --- cross-attention to text (no gate) ---

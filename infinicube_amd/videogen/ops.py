@@ -219,6 +219,27 @@ class HipOps:
             o.data_ptr(), o.stride(0), q.shape[0], k.shape[0], heads, scale, self._stream()),
             "icv_attention_fwd_add")
 
+    # ---- fp8 attention (fp8 mode only): e4m3 Q/K/V/P on the K=64 scaled MFMA ----------------------------------
+    def attention_fp8_buffers(self, Sq: int, Skv: int, d: int, heads: int):
+        """Workspace of attention_fp8: (qq [Sq,d], kq [Skv,d], vt bytes, amax f32 [3, heads])."""
+        nbytes = int(self.lib.icv_attention_fp8_vt_bytes(Skv, heads))
+        return (self.alloc((Sq, d), FP8), self.alloc((Skv, d), FP8), self.alloc((nbytes,), torch.uint8), self.alloc((3, heads), F32))
+
+    def attention_fp8(self, q, k, v, o, heads: int, ws):
+        """o = softmax2(q k^T) v with e4m3 operands; K must carry scale * log2(e) (the DiT's unit-scale convention).
+        ``ws`` = attention_fp8_buffers(...) sized for these shapes."""
+        for t, nm in ((q, "q"), (k, "k"), (v, "v"), (o, "o")):
+            _chk(t, BF16, f"attention_fp8.{nm}")
+        qq, kq, vt, amax = ws
+        assert tuple(qq.shape) == tuple(q.shape) and tuple(kq.shape) == tuple(k.shape)
+        native.check(self.lib.icv_attention_fp8_prepare(
+            q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), q.shape[0], k.shape[0], heads,
+            qq.data_ptr(), qq.stride(0), kq.data_ptr(), kq.stride(0), vt.data_ptr(), amax.data_ptr(), self._stream()),
+            "icv_attention_fp8_prepare")
+        native.check(self.lib.icv_attention_fp8_fwd(
+            qq.data_ptr(), qq.stride(0), kq.data_ptr(), kq.stride(0), vt.data_ptr(), amax.data_ptr(), o.data_ptr(), o.stride(0),
+            q.shape[0], k.shape[0], heads, self._stream()), "icv_attention_fp8_fwd")
+
     def attention_chunk(self, q, k, v, o, acc, ml, heads: int, scale: float, first: bool, last: bool):
         """Attention over one chunk of keys with carried softmax state (acc f32 [Sq, H*128], ml f32
         [Sq, H, 2]); ``first`` starts from the empty state, ``last`` normalises into ``o``."""

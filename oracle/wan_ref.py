@@ -127,6 +127,31 @@ def attention(q: Tensor, k: Tensor, v: Tensor, num_heads: int, scale: Optional[f
     return o.transpose(0, 1).reshape(Sq, -1)
 
 
+def attention_fp8(q: Tensor, k: Tensor, v: Tensor, num_heads: int) -> Tensor:
+    """The build's fp8 attention mode (not the reference's): per head, Q / K / V are scaled by a power of two
+    2^-ceil(log2(amax/448)) and rounded to e4m3; S = Qq Kq^T in log2 units (K already carries scale * log2 e), P = 2^(S - max)
+    rounded to e4m3, O = P Vq / sum(P) with the row sum taken before P is rounded.  The kernel rounds P against a LAZY
+    reference (P up to 2^8 larger than here), so the two agree statistically, not bit for bit: e4m3 keeps the same
+    relative precision at either scale."""
+    Sq, Sk = q.shape[0], k.shape[0]
+    hd = q.shape[1] // num_heads
+    out = torch.empty((Sq, q.shape[1]), dtype=torch.float32)
+
+    def qd(x):   # [S, hd] -> dequantised e4m3 values
+        amax = float(x.abs().max())
+        e = math.ceil(math.log2(amax / FP8_MAX)) if amax > 0 else 0
+        return (x * 2.0 ** -e).to(torch.float8_e4m3fn).to(torch.float32) * 2.0 ** e
+
+    for h in range(num_heads):
+        sl = slice(h * hd, (h + 1) * hd)
+        qh, kh, vh = qd(q[:, sl].float()), qd(k[:, sl].float()), qd(v[:, sl].float())
+        s = qh @ kh.t()
+        p = torch.exp2(s - s.max(dim=-1, keepdim=True).values)
+        l = p.sum(-1, keepdim=True)
+        out[:, sl] = (p.to(torch.float8_e4m3fn).to(torch.float32) @ vh) / l
+    return out
+
+
 def _lin(sd, name, x, dtype):
     return F.linear(x, sd[f"{name}.weight"].to(dtype), sd[f"{name}.bias"].to(dtype))
 

@@ -111,6 +111,12 @@ class OracleOps:
     def attention(self, q, k, v, o, heads, scale):
         o.copy_(R.attention(q.float(), k.float(), v.float(), heads, scale=scale).to(BF16))
 
+    def attention_fp8_buffers(self, Sq, Skv, d, heads):
+        return ()
+
+    def attention_fp8(self, q, k, v, o, heads, ws):
+        o.copy_(R.attention_fp8(q.float(), k.float(), v.float(), heads).to(BF16))
+
     def attention_add(self, q, k, v, o, heads, scale):
         o.copy_((o.float() + R.attention(q.float(), k.float(), v.float(), heads, scale=scale)).to(BF16))
 

@@ -358,6 +358,16 @@ def test_config1_wan_1p3b_17f_256p_10_steps(hip_ops):
     cos8 = float(torch.nn.functional.cosine_similarity((lat8.cpu() - noise).flatten(), (ref - noise).flatten(), dim=0))
     print(f"config #1, fp8 projections: PSNR vs unquantised fp32 oracle {p8:.1f} dB, update cosine {cos8:.5f}")
     assert p8 >= 25.0 and cos8 >= 0.99, f"fp8 mode drifted further than e4m3 rounding explains: PSNR {p8:.1f} dB, cosine {cos8}"
+    # ... and with the self-attention in e4m3 as well (attn8.hip)
+    del m8
+    m9 = WanDiT(cfg, sd, hip_ops, bsd, gemm_dtype="fp8", attn_dtype="fp8").prepare(grid)
+    lat9 = noise.clone().to("cuda:0")
+    m9.denoise(lat9, m9.encode_context(c1), m9.encode_context(c2), m9.embed_buffers(bl), FlowMatchScheduler(steps), 5.0)
+    torch.cuda.synchronize()
+    p9 = R.psnr(lat9.cpu(), ref)
+    cos9 = float(torch.nn.functional.cosine_similarity((lat9.cpu() - noise).flatten(), (ref - noise).flatten(), dim=0))
+    print(f"config #1, fp8 projections + fp8 self-attention: PSNR vs unquantised fp32 oracle {p9:.1f} dB, update cosine {cos9:.5f}")
+    assert p9 >= 22.0 and cos9 >= 0.98, f"fp8 attention mode: PSNR {p9:.1f} dB, cosine {cos9}"
 
 
 def test_generator_end_to_end_on_gpu(tmp_path, monkeypatch):

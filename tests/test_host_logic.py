@@ -106,6 +106,14 @@ def test_fp8_gemm_mode_matches_fake_quant_oracle():
     assert 1e-3 < rel < 0.2, f"fp8 vs unquantised oracle rel-L2 {rel} (expected fp8-sized, non-zero)"
     with pytest.raises(ValueError, match="gemm_dtype"):
         WanDiT(cfg, sd, OracleOps(), bsd, gemm_dtype="int4")
+    with pytest.raises(ValueError, match="attn_dtype"):
+        WanDiT(cfg, sd, OracleOps(), bsd, attn_dtype="fp4")
+    # fp8 self-attention on top (host routing; the e4m3 attention oracle stands in for the kernel)
+    m2 = WanDiT(cfg, sd, OracleOps(), bsd, gemm_dtype="fp8", attn_dtype="fp8").prepare(GRID)
+    m2.forward_tokens(noise.clone(), m2.encode_context(c1, clip), 500.0, m2.embed_cond_latents(y, add_to=m2.embed_buffers(bl)), m2.head_out[0])
+    v2 = R.unpatchify(m2.head_out[0], (GRID.T, GRID.Hp, GRID.Wp), cfg.out_dim)
+    rel2 = float((v2 - ref).norm() / ref.norm())
+    assert 1e-3 < rel2 < 0.25, f"fp8 GEMMs + fp8 attention vs unquantised oracle rel-L2 {rel2}"
 
 
 def test_loop_matches_oracle_and_time_cache():

@@ -677,6 +677,41 @@ def test_gemm_fp8_rejects_bad_shapes(hip_ops):
         hip_ops.gemm_fp8(a, s, w, s, None, torch.empty((8, 8), device=DEV), EPI_F32)
 
 
+@pytest.mark.parametrize("Sq,Skv,H", [(300, 1100, 2), (64, 64, 1), (257, 65, 1), (130, 1500, 2), (1, 1, 1), (513, 640, 3)])
+def test_attention_fp8(hip_ops, Sq, Skv, H):
+    """fp8 attention (prepare: per-head power-of-two scales, transposed key-permuted V tiles; forward on the K=64 scaled
+    MFMA).  Bar: against the oracle that applies the same e4m3 quantisation, rms error <= 3 % of the output rms (P is
+    rounded against a lazy reference in the kernel and against the true max in the oracle); against the unquantised
+    attention the fp8 noise itself stays below 8 % (short key sequences average it least)."""
+    d = H * 128
+    fold = (1.0 / math.sqrt(128)) * math.log2(math.e)
+    q = rnd((Sq, d), 441).to(torch.bfloat16)
+    kf = rnd((Skv, d), 442)
+    kf[Skv - 1] = q[min(3, Sq - 1)].float() * 3.0                     # one strongly matching key late in the sequence
+    k = (kf * fold).to(torch.bfloat16)
+    v = (rnd((Skv, d), 443) * torch.linspace(0.5, 2.0, d)[None, :]).to(torch.bfloat16)
+    ref8 = R.attention_fp8(q.float(), k.float(), v.float(), H)
+    ref = R.attention(q.float(), k.float(), v.float(), H, scale=math.log(2.0))
+    o = torch.full((Sq + 2, d), 9.0, dtype=torch.bfloat16, device=DEV)
+    ws = hip_ops.attention_fp8_buffers(Sq, Skv, d, H)
+    hip_ops.attention_fp8(q.to(DEV), k.to(DEV), v.to(DEV), o[:Sq], H, ws)
+    o2 = torch.empty((Sq, d), dtype=torch.bfloat16, device=DEV)
+    hip_ops.attention_fp8(q.to(DEV), k.to(DEV), v.to(DEV), o2, H, ws)
+    got = o[:Sq].float().cpu()
+    assert torch.isfinite(got).all() and torch.equal(o[:Sq], o2), "fp8 attention not finite / not deterministic"
+    assert bool((o[Sq:] == 9.0).all()), "wrote past the last query row"
+    # prepare: scales and e4m3 codes of K are exactly the oracle's
+    amax = ws[3].cpu()
+    assert torch.equal(amax[1], k.float().abs().reshape(Skv, H, 128).amax(dim=(0, 2)))
+    e = torch.ceil(torch.log2(amax[1] / 448.0))
+    kq_ref = (k.float().reshape(Skv, H, 128) * torch.exp2(-e)[None, :, None]).to(torch.float8_e4m3fn).reshape(Skv, d)
+    assert torch.equal(ws[1].cpu().view(torch.uint8), kq_ref.view(torch.uint8)), "K e4m3 codes differ from the oracle"
+    rms = float(ref.pow(2).mean().sqrt())
+    e8 = float((got - ref8).pow(2).mean().sqrt()) / rms
+    e0 = float((got - ref).pow(2).mean().sqrt()) / rms
+    assert e8 <= 0.03 and e0 <= 0.08, f"fp8 attention Sq={Sq} Skv={Skv}: rms err vs fp8 oracle {e8:.4f}, vs unquantised {e0:.4f}"
+
+
 @pytest.mark.parametrize("Sq,Skv,H", [(300, 257, 2), (1, 1, 1), (513, 64, 3)])
 def test_attention_add_into_output(hip_ops, Sq, Skv, H):
     """icv_attention_fwd_add: o += softmax(q k^T) v (the i2v image cross-attention; 257 = CLIP tokens)."""
