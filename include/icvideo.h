@@ -134,8 +134,11 @@ int icv_attention_fwd_add(const void* q, int64_t ldq, const void* k, int64_t ldk
  *   amax f32 [3, H] (q, k, v rows; power-of-two scales 2^ceil(log2(amax/448)) are derived from it), qq / kq e4m3
  *   [S, H*128] (ld in bytes), vt e4m3 transposed key-permuted tiles [H][ceil(Skv/64)][128][64]
  *   (icv_attention_fp8_vt_bytes gives its size).  K must already carry the softmax scale * log2(e) ("unit scale").
+ *   q == NULL: keys / values only; k == NULL: queries only (the other rows of amax are left untouched).
  * icv_attention_fp8_fwd: o bf16 [Sq, H*128] = softmax2(qq kq^T) v  (exp2, i.e. natural softmax of the unscaled
- *   product when K carries (1/sqrt d) log2 e). */
+ *   product when K carries (1/sqrt d) log2 e).
+ * icv_attention_fp8_fwd_chunk: the same over one chunk of keys with the carried state of icv_attention_fwd_chunk
+ *   (each chunk is prepared on its own: its own K / V scales; the state is in real units). */
 int64_t icv_attention_fp8_vt_bytes(int64_t Skv, int64_t heads);
 int icv_attention_fp8_prepare(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                               int64_t Sq, int64_t Skv, int64_t heads, void* qq, int64_t ldqq, void* kq,
@@ -143,6 +146,9 @@ int icv_attention_fp8_prepare(const void* q, int64_t ldq, const void* k, int64_t
 int icv_attention_fp8_fwd(const void* qq, int64_t ldqq, const void* kq, int64_t ldkq, const void* vt,
                           const float* amax, void* o, int64_t ldo, int64_t Sq, int64_t Skv, int64_t heads,
                           void* stream);
+int icv_attention_fp8_fwd_chunk(const void* qq, int64_t ldqq, const void* kq, int64_t ldkq, const void* vt,
+                                const float* amax, void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml,
+                                int64_t Sq, int64_t Skv, int64_t heads, int first, int last, void* stream);
 
 /* ---- K6 split along the KEY axis (K13 overlap): attention over one chunk of keys with a carried
  * online-softmax state, so the sequence-parallel path can consume K/V chunks as the RCCL all-gather

@@ -118,10 +118,10 @@ struct Params {
   const unsigned char* k; int64_t ldk;     // e4m3 [Skv, H*128]
   const unsigned char* vt;                 // e4m3 [H][ntiles][128][64]
   const float* amax;                       // f32 [3][H]: q, k, v
-  bf16_t* o; int64_t ldo;
   int64_t Sq, Skv;
   int heads, nqb, ntiles;
   float thr;
+  attc::Params c;   // o / ldo, carried state (acc, ldacc, ml, state_in, state_out), Sq, heads: what load_state / store_result read
 };
 
 __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
@@ -184,15 +184,12 @@ __global__ __launch_bounds__(512) void attn8_kernel(Params p) {
   __builtin_amdgcn_s_waitcnt(0x0F70);   // retire ordinary loads before any LDS-DMA is in flight (see attn4.hip)
 
   f32x16 ot[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ot[i][r] = 0.f;
-  float m_run = NEG_BIG, l_run = 0.f;
-  float m_base = 0.f;                    // reference baked into cinit (0 while there is no reference yet)
+  float m_run, l_run;
+  attc::load_state(p.c, qr_c, head, hi, ot, m_run, l_run);      // empty, or the state carried from the previous key chunk
+  float m_base = m_run < -1.0e29f ? 0.f : m_run;               // reference baked into cinit (0 while there is none yet)
   f32x16 cinit;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
+  for (int r = 0; r < 16; ++r) cinit[r] = -m_base;
 
   // ---- LDS-DMA lane mapping ----
   // K tile: wave w covers key rows 8w..8w+7 (8 lanes x 16 B per row); physical chunk pc holds logical pc ^ ((row >> 1) & 7)
@@ -331,19 +328,7 @@ __global__ __launch_bounds__(512) void attn8_kernel(Params p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (grp == 0 && STAGGER) A8_BARRIER();
 
-  // ---- epilogue: normalise and store bf16 (layout of attn_common.h store_result) ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const int64_t qr = q0 + l31;
-  if (qr < p.Sq) {
-    const float inv = 1.0f / l_tot;
-    bf16_t* op = p.o + qr * p.ldo + (int64_t)head * D + 4 * hi;
-#pragma unroll
-    for (int d0 = 0; d0 < 4; ++d0)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr)
-        *reinterpret_cast<uint2*>(op + d0 * 32 + rr * 8) =
-            make_uint2(pack_bf16x2(ot[d0][rr * 4 + 0] * inv, ot[d0][rr * 4 + 1] * inv), pack_bf16x2(ot[d0][rr * 4 + 2] * inv, ot[d0][rr * 4 + 3] * inv));
-  }
+  attc::store_result(p.c, q0 + l31, head, hi, ot, m_run, l_run);
 }
 
 template <int VAR>
@@ -371,21 +356,53 @@ extern "C" int64_t icv_attention_fp8_vt_bytes(int64_t Skv, int64_t heads) {
 extern "C" int icv_attention_fp8_prepare(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                                          int64_t Sq, int64_t Skv, int64_t heads, void* qq, int64_t ldqq, void* kq,
                                          int64_t ldkq, void* vt, float* amax, void* stream) {
-  ICV_REQUIRE(k && v && kq && vt && amax, "icv_attention_fp8_prepare: null pointer");
+  ICV_REQUIRE(amax && (q || k), "icv_attention_fp8_prepare: null pointer");
   ICV_REQUIRE((q == nullptr) == (qq == nullptr), "icv_attention_fp8_prepare: q and qq go together");
-  ICV_REQUIRE(Skv > 0 && heads > 0 && (q == nullptr || Sq > 0), "icv_attention_fp8_prepare: empty problem");
+  ICV_REQUIRE((k == nullptr) == (kq == nullptr) && (k == nullptr) == (v == nullptr) && (k == nullptr) == (vt == nullptr),
+              "icv_attention_fp8_prepare: k, v, kq and vt go together");
+  ICV_REQUIRE(heads > 0 && (q == nullptr || Sq > 0) && (k == nullptr || Skv > 0), "icv_attention_fp8_prepare: empty problem");
   ICV_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldqq % 16 == 0 && ldkq % 16 == 0, "icv_attention_fp8_prepare: leading dims must keep 16-byte alignment");
   hipStream_t st = (hipStream_t)stream;
-  ICV_REQUIRE(hipMemsetAsync(amax, 0, sizeof(float) * 3 * heads, st) == hipSuccess, "icv_attention_fp8_prepare: memset failed");
   int* ab = reinterpret_cast<int*>(amax);
-  const int nt = (int)((Skv + att8::KVB - 1) / att8::KVB);
-  if (q) hipLaunchKernelGGL(att8::amax_kernel, dim3((unsigned)heads, (unsigned)((Sq + 255) / 256)), dim3(256), 0, st, (const bf16_t*)q, ldq, Sq, ab);
-  hipLaunchKernelGGL(att8::amax_kernel, dim3((unsigned)heads, (unsigned)((Skv + 255) / 256)), dim3(256), 0, st, (const bf16_t*)k, ldk, Skv, ab + heads);
-  hipLaunchKernelGGL(att8::amax_kernel, dim3((unsigned)heads, (unsigned)((Skv + 255) / 256)), dim3(256), 0, st, (const bf16_t*)v, ldv, Skv, ab + 2 * heads);
-  if (q) hipLaunchKernelGGL(att8::quant_rows_kernel, dim3((unsigned)heads, (unsigned)((Sq + 255) / 256)), dim3(256), 0, st, (const bf16_t*)q, ldq, Sq, amax, (unsigned char*)qq, ldqq);
-  hipLaunchKernelGGL(att8::quant_rows_kernel, dim3((unsigned)heads, (unsigned)((Skv + 255) / 256)), dim3(256), 0, st, (const bf16_t*)k, ldk, Skv, amax + heads, (unsigned char*)kq, ldkq);
-  hipLaunchKernelGGL(att8::quant_vt_kernel, dim3((unsigned)nt, (unsigned)heads), dim3(256), 0, st, (const bf16_t*)v, ldv, Skv, amax + 2 * heads, (unsigned char*)vt, nt);
+  if (q) {
+    ICV_REQUIRE(hipMemsetAsync(amax, 0, sizeof(float) * heads, st) == hipSuccess, "icv_attention_fp8_prepare: memset failed");
+    const dim3 grid((unsigned)heads, (unsigned)((Sq + 255) / 256));
+    hipLaunchKernelGGL(att8::amax_kernel, grid, dim3(256), 0, st, (const bf16_t*)q, ldq, Sq, ab);
+    hipLaunchKernelGGL(att8::quant_rows_kernel, grid, dim3(256), 0, st, (const bf16_t*)q, ldq, Sq, amax, (unsigned char*)qq, ldqq);
+  }
+  if (k) {
+    ICV_REQUIRE(hipMemsetAsync(amax + heads, 0, sizeof(float) * 2 * heads, st) == hipSuccess, "icv_attention_fp8_prepare: memset failed");
+    const dim3 grid((unsigned)heads, (unsigned)((Skv + 255) / 256));
+    const int nt = (int)((Skv + att8::KVB - 1) / att8::KVB);
+    hipLaunchKernelGGL(att8::amax_kernel, grid, dim3(256), 0, st, (const bf16_t*)k, ldk, Skv, ab + heads);
+    hipLaunchKernelGGL(att8::amax_kernel, grid, dim3(256), 0, st, (const bf16_t*)v, ldv, Skv, ab + 2 * heads);
+    hipLaunchKernelGGL(att8::quant_rows_kernel, grid, dim3(256), 0, st, (const bf16_t*)k, ldk, Skv, amax + heads, (unsigned char*)kq, ldkq);
+    hipLaunchKernelGGL(att8::quant_vt_kernel, dim3((unsigned)nt, (unsigned)heads), dim3(256), 0, st, (const bf16_t*)v, ldv, Skv, amax + 2 * heads, (unsigned char*)vt, nt);
+  }
   return icv_check_launch("icv_attention_fp8_prepare");
+}
+
+static int attn8_run(const void* qq, int64_t ldqq, const void* kq, int64_t ldkq, const void* vt, const float* amax, void* o,
+                     int64_t ldo, float* acc, int64_t ldacc, float* ml, int state_in, int state_out, int64_t Sq, int64_t Skv,
+                     int64_t heads, hipStream_t st) {
+  att8::Params p;
+  p.q = (const unsigned char*)qq; p.ldq = ldqq; p.k = (const unsigned char*)kq; p.ldk = ldkq; p.vt = (const unsigned char*)vt;
+  p.amax = amax; p.Sq = Sq; p.Skv = Skv; p.heads = (int)heads;
+  p.nqb = (int)((Sq + att8::QB - 1) / att8::QB);
+  p.ntiles = (int)((Skv + att8::KVB - 1) / att8::KVB);
+  p.thr = (float)icv_get_option_int("attn_defer_max_log2", 8);
+  p.c = attc::Params{};
+  p.c.o = (bf16_t*)o; p.c.ldo = ldo; p.c.acc = acc; p.c.ldacc = ldacc; p.c.ml = ml; p.c.state_in = state_in; p.c.state_out = state_out;
+  p.c.Sq = Sq; p.c.Skv = Skv; p.c.heads = (int)heads; p.c.nqb = p.nqb; p.c.sc = 1.0f; p.c.thr = p.thr;
+  ICV_REQUIRE((int64_t)p.heads * p.nqb < (1LL << 31), "icv_attention_fp8_fwd: grid too large");
+  switch (icv_get_option_int("attn8_variant", 5)) {
+    case 0: return att8::launch<0>(p, st);
+    case 1: return att8::launch<1>(p, st);
+    case 4: return att8::launch<4>(p, st);
+    case 5: return att8::launch<5>(p, st);
+  }
+  icv_set_error("icv_attention_fp8_fwd: unknown attn8_variant");
+  return 1;
 }
 
 extern "C" int icv_attention_fp8_fwd(const void* qq, int64_t ldqq, const void* kq, int64_t ldkq, const void* vt,
@@ -394,19 +411,16 @@ extern "C" int icv_attention_fp8_fwd(const void* qq, int64_t ldqq, const void* k
   ICV_REQUIRE(qq && kq && vt && amax && o, "icv_attention_fp8_fwd: null pointer");
   ICV_REQUIRE(Sq > 0 && Skv > 0 && heads > 0, "icv_attention_fp8_fwd: empty problem");
   ICV_REQUIRE(ldqq % 16 == 0 && ldkq % 16 == 0 && ldo % 4 == 0, "icv_attention_fp8_fwd: leading dims must keep 16-byte row alignment");
-  att8::Params p;
-  p.q = (const unsigned char*)qq; p.ldq = ldqq; p.k = (const unsigned char*)kq; p.ldk = ldkq; p.vt = (const unsigned char*)vt;
-  p.amax = amax; p.o = (bf16_t*)o; p.ldo = ldo; p.Sq = Sq; p.Skv = Skv; p.heads = (int)heads;
-  p.nqb = (int)((Sq + att8::QB - 1) / att8::QB);
-  p.ntiles = (int)((Skv + att8::KVB - 1) / att8::KVB);
-  p.thr = (float)icv_get_option_int("attn_defer_max_log2", 8);
-  ICV_REQUIRE((int64_t)p.heads * p.nqb < (1LL << 31), "icv_attention_fp8_fwd: grid too large");
-  switch (icv_get_option_int("attn8_variant", 5)) {
-    case 0: return att8::launch<0>(p, (hipStream_t)stream);
-    case 1: return att8::launch<1>(p, (hipStream_t)stream);
-    case 4: return att8::launch<4>(p, (hipStream_t)stream);
-    case 5: return att8::launch<5>(p, (hipStream_t)stream);
-  }
-  icv_set_error("icv_attention_fp8_fwd: unknown attn8_variant");
-  return 1;
+  return attn8_run(qq, ldqq, kq, ldkq, vt, amax, o, ldo, nullptr, 0, nullptr, 0, 0, Sq, Skv, heads, (hipStream_t)stream);
+}
+
+extern "C" int icv_attention_fp8_fwd_chunk(const void* qq, int64_t ldqq, const void* kq, int64_t ldkq, const void* vt,
+                                           const float* amax, void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml,
+                                           int64_t Sq, int64_t Skv, int64_t heads, int first, int last, void* stream) {
+  ICV_REQUIRE(qq && kq && vt && amax, "icv_attention_fp8_fwd_chunk: null pointer");
+  ICV_REQUIRE(Sq > 0 && Skv > 0 && heads > 0, "icv_attention_fp8_fwd_chunk: empty problem");
+  ICV_REQUIRE(ldqq % 16 == 0 && ldkq % 16 == 0, "icv_attention_fp8_fwd_chunk: leading dims must keep 16-byte row alignment");
+  ICV_REQUIRE((first && last) || (acc && ml && ldacc % 4 == 0), "icv_attention_fp8_fwd_chunk: carried state buffers required unless first && last");
+  ICV_REQUIRE(!last || (o && ldo % 4 == 0), "icv_attention_fp8_fwd_chunk: output required for the last chunk");
+  return attn8_run(qq, ldqq, kq, ldkq, vt, amax, o, ldo, acc, ldacc, ml, first ? 0 : 1, last ? 0 : 1, Sq, Skv, heads, (hipStream_t)stream);
 }

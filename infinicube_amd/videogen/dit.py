@@ -68,8 +68,8 @@ class WanDiT:
         self.fp8 = gemm_dtype == "fp8"
         if attn_dtype not in ("bf16", "fp8"):
             raise ValueError(f"attn_dtype must be 'bf16' or 'fp8', got {attn_dtype!r}")
-        # fp8 self-attention (e4m3 Q/K/V/P on the K=64 scaled MFMA, csrc/attn8.hip): single-rank runs only; cross-attention
-        # (512 + 257 keys, 1 % of the flops) and the sequence-parallel chunked path stay bf16
+        # fp8 self-attention (e4m3 Q/K/V/P on the K=64 scaled MFMA, csrc/attn8.hip), single-rank and sequence-parallel
+        # (each gathered K/V chunk is quantised on its own); cross-attention (512 + 257 keys, 1 % of the flops) stays bf16
         self.attn_fp8 = attn_dtype == "fp8"
         if self.fp8 and (cfg.dim % 128 or cfg.ffn_dim % 128):
             raise ValueError("fp8 GEMMs need dim and ffn_dim to be multiples of 128")
@@ -227,7 +227,11 @@ class WanDiT:
         self.qkv = a((3, n, d), BF16)
         self.att = a((n, d), BF16)
         self.ff = a((n, cfg.ffn_dim), BF16)
-        self.attn8_ws = ops.attention_fp8_buffers(n, n, d, cfg.num_heads) if (self.attn_fp8 and self.plan.world == 1) else None
+        self.attn8_ws = None
+        if self.attn_fp8:      # world > 1: the K/V side of the workspace holds one gathered chunk at a time
+            kv_rows = n if self.plan.world == 1 else self.plan.world * max(
+                b1 - b0 for b0, b1 in zip(chunk_bounds(n, sp_chunks)[:-1], chunk_bounds(n, sp_chunks)[1:]))
+            self.attn8_ws = ops.attention_fp8_buffers(n, kv_rows, d, cfg.num_heads)
         self.h8 = self.h8s = self.att8 = self.att8s = self.ff8 = self.ff8s = None
         if self.fp8:
             self.h8, self.h8s = a((n, d), FP8), a((n,), F32)
@@ -286,10 +290,17 @@ class WanDiT:
         online-softmax state in fp32 between launches, while later chunks are still in flight."""
         ops = self.ops
         C = len(bufs)
+        if self.attn8_ws is not None:
+            ops.attention_fp8_prepare(self.attn8_ws, H, q=q)            # queries once per layer, under the first transfer
         for c in range(C):
             self.kv_gather.wait(handles[c])
-            ops.attention_chunk(q, bufs[c][0], bufs[c][1], self.att, self.sp_acc, self.sp_ml, H, scale,
-                                first=(c == 0), last=(c == C - 1))
+            if self.attn8_ws is not None:
+                ops.attention_fp8_prepare(self.attn8_ws, H, k=bufs[c][0], v=bufs[c][1])
+                ops.attention_fp8_chunk(self.attn8_ws, q.shape[0], bufs[c][0].shape[0], self.att, self.sp_acc, self.sp_ml, H,
+                                        first=(c == 0), last=(c == C - 1))
+            else:
+                ops.attention_chunk(q, bufs[c][0], bufs[c][1], self.att, self.sp_acc, self.sp_ml, H, scale,
+                                    first=(c == 0), last=(c == C - 1))
 
     # ------------------------------------------------------------------------------------
     def encode_context(self, context: torch.Tensor, clip_fea: Optional[torch.Tensor] = None) -> ContextKV:

@@ -225,20 +225,43 @@ class HipOps:
         nbytes = int(self.lib.icv_attention_fp8_vt_bytes(Skv, heads))
         return (self.alloc((Sq, d), FP8), self.alloc((Skv, d), FP8), self.alloc((nbytes,), torch.uint8), self.alloc((3, heads), F32))
 
+    def attention_fp8_prepare(self, ws, heads: int, q=None, k=None, v=None):
+        """Quantise the queries and / or the keys + values of one attention into the workspace (per-head power-of-two
+        scales from the abs-max, e4m3 rows, transposed key-permuted V tiles)."""
+        qq, kq, vt, amax = ws
+        if q is not None:
+            _chk(q, BF16, "attention_fp8.q"); assert qq.shape[0] >= q.shape[0] and qq.shape[1] == q.shape[1]
+        if k is not None:
+            _chk(k, BF16, "attention_fp8.k"); _chk(v, BF16, "attention_fp8.v")
+            assert kq.shape[0] >= k.shape[0] and kq.shape[1] == k.shape[1] and v.shape == k.shape
+            assert vt.numel() >= int(self.lib.icv_attention_fp8_vt_bytes(k.shape[0], heads))
+        native.check(self.lib.icv_attention_fp8_prepare(
+            native.ptr(q), q.stride(0) if q is not None else 0, native.ptr(k), k.stride(0) if k is not None else 0,
+            native.ptr(v), v.stride(0) if v is not None else 0, q.shape[0] if q is not None else 0,
+            k.shape[0] if k is not None else 0, heads, qq.data_ptr() if q is not None else None, qq.stride(0),
+            kq.data_ptr() if k is not None else None, kq.stride(0), vt.data_ptr() if k is not None else None,
+            amax.data_ptr(), self._stream()), "icv_attention_fp8_prepare")
+
     def attention_fp8(self, q, k, v, o, heads: int, ws):
         """o = softmax2(q k^T) v with e4m3 operands; K must carry scale * log2(e) (the DiT's unit-scale convention).
         ``ws`` = attention_fp8_buffers(...) sized for these shapes."""
-        for t, nm in ((q, "q"), (k, "k"), (v, "v"), (o, "o")):
-            _chk(t, BF16, f"attention_fp8.{nm}")
+        _chk(o, BF16, "attention_fp8.o")
+        self.attention_fp8_prepare(ws, heads, q=q, k=k, v=v)
         qq, kq, vt, amax = ws
-        assert tuple(qq.shape) == tuple(q.shape) and tuple(kq.shape) == tuple(k.shape)
-        native.check(self.lib.icv_attention_fp8_prepare(
-            q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), q.shape[0], k.shape[0], heads,
-            qq.data_ptr(), qq.stride(0), kq.data_ptr(), kq.stride(0), vt.data_ptr(), amax.data_ptr(), self._stream()),
-            "icv_attention_fp8_prepare")
         native.check(self.lib.icv_attention_fp8_fwd(
             qq.data_ptr(), qq.stride(0), kq.data_ptr(), kq.stride(0), vt.data_ptr(), amax.data_ptr(), o.data_ptr(), o.stride(0),
             q.shape[0], k.shape[0], heads, self._stream()), "icv_attention_fp8_fwd")
+
+    def attention_fp8_chunk(self, ws, Sq: int, Skv: int, o, acc, ml, heads: int, first: bool, last: bool):
+        """fp8 attention of the prepared queries over the prepared chunk of keys / values, carried state as
+        attention_chunk (acc f32 [Sq, H*128], ml f32 [Sq, H, 2])."""
+        qq, kq, vt, amax = ws
+        if o is not None:
+            _chk(o, BF16, "attention_fp8_chunk.o")
+        native.check(self.lib.icv_attention_fp8_fwd_chunk(
+            qq.data_ptr(), qq.stride(0), kq.data_ptr(), kq.stride(0), vt.data_ptr(), amax.data_ptr(), native.ptr(o),
+            o.stride(0) if o is not None else 0, native.ptr(acc), acc.stride(0) if acc is not None else 0, native.ptr(ml),
+            Sq, Skv, heads, int(first), int(last), self._stream()), "icv_attention_fp8_fwd_chunk")
 
     def attention_chunk(self, q, k, v, o, acc, ml, heads: int, scale: float, first: bool, last: bool):
         """Attention over one chunk of keys with carried softmax state (acc f32 [Sq, H*128], ml f32

@@ -112,10 +112,46 @@ class OracleOps:
         o.copy_(R.attention(q.float(), k.float(), v.float(), heads, scale=scale).to(BF16))
 
     def attention_fp8_buffers(self, Sq, Skv, d, heads):
-        return ()
+        return {}
 
     def attention_fp8(self, q, k, v, o, heads, ws):
         o.copy_(R.attention_fp8(q.float(), k.float(), v.float(), heads).to(BF16))
+
+    def attention_fp8_prepare(self, ws, heads, q=None, k=None, v=None):
+        def qd(x):   # per-head power-of-two scale + e4m3 rounding, dequantised
+            S, d = x.shape
+            xh = x.float().reshape(S, heads, -1)
+            amax = xh.abs().amax(dim=(0, 2))
+            e = torch.where(amax > 0, torch.ceil(torch.log2(amax / R.FP8_MAX)), torch.zeros_like(amax))
+            return ((xh * torch.exp2(-e)[None, :, None]).to(FP8).float() * torch.exp2(e)[None, :, None]).reshape(S, d)
+        if q is not None:
+            ws["q"] = qd(q)
+        if k is not None:
+            ws["k"], ws["v"] = qd(k), qd(v)
+
+    def attention_fp8_chunk(self, ws, Sq, Skv, o, acc, ml, heads, first, last):
+        """Online softmax in log2 units over the prepared chunk (P rounded to e4m3 against the running max)."""
+        q, k, v = ws["q"][:Sq], ws["k"][:Skv], ws["v"][:Skv]
+        d = q.shape[1]
+        qh = q.reshape(Sq, heads, -1).transpose(0, 1)
+        kh = k.reshape(Skv, heads, -1).transpose(0, 1)
+        vh = v.reshape(Skv, heads, -1).transpose(0, 1)
+        s = qh @ kh.transpose(1, 2)
+        if first:
+            m_old = torch.full((heads, Sq), -1e30); l_old = torch.zeros((heads, Sq)); a_old = torch.zeros((heads, Sq, d // heads))
+        else:
+            m_old, l_old = ml[:, :, 0].t().clone(), ml[:, :, 1].t().clone()
+            a_old = acc.reshape(Sq, heads, -1).transpose(0, 1).clone()
+        m_new = torch.maximum(m_old, s.max(dim=-1).values)
+        alpha = torch.exp2(m_old - m_new)
+        pmat = torch.exp2(s - m_new[:, :, None])
+        l_new = l_old * alpha + pmat.sum(-1)
+        a_new = a_old * alpha[:, :, None] + pmat.to(FP8).float() @ vh
+        if last:
+            o.copy_((a_new / l_new[:, :, None]).transpose(0, 1).reshape(Sq, d).to(BF16))
+        else:
+            acc.copy_(a_new.transpose(0, 1).reshape(Sq, d))
+            ml[:, :, 0] = m_new.t(); ml[:, :, 1] = l_new.t()
 
     def attention_add(self, q, k, v, o, heads, scale):
         o.copy_((o.float() + R.attention(q.float(), k.float(), v.float(), heads, scale=scale)).to(BF16))

@@ -130,11 +130,13 @@ def test_loop_matches_oracle_and_time_cache():
     assert R.psnr(lat1, ref1) > 50.0
 
 
-@pytest.mark.parametrize("chunks,model,gemm_dtype", [(1, "tiny", "bf16"), (3, "tiny", "bf16"), (3, "tiny-i2v", "fp8")])
+@pytest.mark.parametrize("chunks,model,gemm_dtype", [(1, "tiny", "bf16"), (3, "tiny", "bf16"), (3, "tiny-i2v", "fp8"), (2, "tiny", "fp8+attn")])
 def test_inprocess_two_shards_equal_unsharded(chunks, model, gemm_dtype):
     """Simulate world=2 in one process: run both shards with a gather that concatenates their K/V.  The third case
     shards the i2v DiT in fp8 mode (row-sliced quantised QKV weights, per-shard conditioning-latent tokens)."""
     CFG = preset(model)
+    attn_dtype = "fp8" if gemm_dtype.endswith("+attn") else "bf16"      # 4th case: e4m3 self-attention, per-chunk K/V scales
+    gemm_dtype = gemm_dtype.split("+")[0]
     sd, bsd = syn.make_dit_state_dict(CFG), syn.make_buffer_embedder_state_dict(CFG)
     noise, c1, bl = syn.make_latent_noise(GRID), syn.make_text_context(CFG, 1), syn.make_buffer_latents(CFG, GRID)
     clip = syn.make_clip_features(CFG) if CFG.has_image_input else None
@@ -144,7 +146,7 @@ def test_inprocess_two_shards_equal_unsharded(chunks, model, gemm_dtype):
         bt = m.embed_buffers(bl)
         return m.embed_cond_latents(ycond, add_to=bt) if ycond is not None else bt
 
-    full = WanDiT(CFG, sd, OracleOps(), bsd, gemm_dtype=gemm_dtype).prepare(GRID)
+    full = WanDiT(CFG, sd, OracleOps(), bsd, gemm_dtype=gemm_dtype, attn_dtype=attn_dtype).prepare(GRID)
     full.forward_tokens(noise.clone(), full.encode_context(c1, clip), 300.0, additive(full), full.head_out[0])
     # lock-step emulation: layer-by-layer is awkward, so exploit determinism — shard r's K/V for layer i
     # equal rows [tok0, tok0+n) of the unsharded K/V; capture them from the full run via a recording ops.
@@ -156,7 +158,11 @@ def test_inprocess_two_shards_equal_unsharded(chunks, model, gemm_dtype):
                 rec.setdefault("kv", []).append((k.clone(), v.clone()))
             super().attention(q, k, v, o, heads, scale)
 
-    f2 = WanDiT(CFG, sd, RecOps(), bsd, gemm_dtype=gemm_dtype).prepare(GRID)
+        def attention_fp8(self, q, k, v, o, heads, ws):
+            rec.setdefault("kv", []).append((k.clone(), v.clone()))
+            super().attention_fp8(q, k, v, o, heads, ws)
+
+    f2 = WanDiT(CFG, sd, RecOps(), bsd, gemm_dtype=gemm_dtype, attn_dtype=attn_dtype).prepare(GRID)
     f2.forward_tokens(noise.clone(), f2.encode_context(c1, clip), 300.0, additive(f2), f2.head_out[0])
     outs = []
     for r in range(2):
@@ -188,13 +194,14 @@ def test_inprocess_two_shards_equal_unsharded(chunks, model, gemm_dtype):
             def wait(self, handle):
                 pass
 
-        m = WanDiT(CFG, sd, OracleOps(), bsd, gemm_dtype=gemm_dtype)
+        m = WanDiT(CFG, sd, OracleOps(), bsd, gemm_dtype=gemm_dtype, attn_dtype=attn_dtype)
         m.prepare(GRID, plan, kv_gather=FakeGather(), sp_chunks=chunks)   # world>1 without torch.distributed
         m.forward_tokens(noise.clone(), m.encode_context(c1, clip), 300.0, additive(m), m.head_out[0])
         outs.append(m.head_out[0].clone())
     got, want = torch.cat(outs, 0), full.head_out[0]
-    # chunked online softmax reorders fp32 sums (and a flipped bf16 rounding can propagate): rounding-level
-    assert float((got - want).norm() / want.norm()) < 2e-3
+    # chunked online softmax reorders fp32 sums (and a flipped bf16 rounding can propagate): rounding-level.  With e4m3
+    # attention every chunk has its own K / V scales and P is rounded against a different reference: fp8-level
+    assert float((got - want).norm() / want.norm()) < (6e-2 if attn_dtype == "fp8" else 2e-3)
 
 
 def _sp_worker(rank, world, port, q):

@@ -710,6 +710,18 @@ def test_attention_fp8(hip_ops, Sq, Skv, H):
     e8 = float((got - ref8).pow(2).mean().sqrt()) / rms
     e0 = float((got - ref).pow(2).mean().sqrt()) / rms
     assert e8 <= 0.03 and e0 <= 0.08, f"fp8 attention Sq={Sq} Skv={Skv}: rms err vs fp8 oracle {e8:.4f}, vs unquantised {e0:.4f}"
+    # key-axis chunks with carried state (sequence-parallel path): queries prepared once, every chunk prepared on its own
+    if Skv >= 640:
+        acc = torch.empty((Sq, d), device=DEV); ml = torch.empty((Sq, H, 2), device=DEV)
+        o3 = torch.zeros((Sq, d), dtype=torch.bfloat16, device=DEV)
+        cuts = [0, 100, 357, Skv]
+        hip_ops.attention_fp8_prepare(ws, H, q=q.to(DEV))
+        for c in range(3):
+            kc, vc = k[cuts[c]:cuts[c + 1]].to(DEV), v[cuts[c]:cuts[c + 1]].to(DEV)
+            hip_ops.attention_fp8_prepare(ws, H, k=kc, v=vc)
+            hip_ops.attention_fp8_chunk(ws, Sq, kc.shape[0], o3, acc, ml, H, first=(c == 0), last=(c == 2))
+        e3 = float((o3.float().cpu() - ref).pow(2).mean().sqrt()) / rms
+        assert e3 <= 0.08, f"chunked fp8 attention vs unquantised: {e3:.4f}"
 
 
 @pytest.mark.parametrize("Sq,Skv,H", [(300, 257, 2), (1, 1, 1), (513, 64, 3)])
