@@ -162,6 +162,7 @@ class WanVideoPipeline:
         # projections (BASELINE.json config #5).  Anything else = bf16, the reference's setting
         # [R infinicube/inference/guidance_buffer_generation.py:762].
         self.gemm_dtype = "fp8" if torch_dtype == torch.float8_e4m3fn else "bf16"
+        self.attn_dtype = self.gemm_dtype     # the fp8 mode also runs self-attention in e4m3 (no measurable accuracy cost)
         # multi-GPU layout when torch.distributed is initialised (seqpar.ParallelLayout): "auto" | "sp" | "cfg+sp"
         self.parallelism = "auto"
         self._layouts = {}
@@ -225,7 +226,7 @@ class WanVideoPipeline:
 
     def _get_engine(self):
         from .dit import WanDiT
-        key = (self.dit.version, self.buffer_embedder.version if self.buffer_embedder else -1, self.gemm_dtype)
+        key = (self.dit.version, self.buffer_embedder.version if self.buffer_embedder else -1, self.gemm_dtype, self.attn_dtype)
         if self._engine is None or self._engine_key != key:
             cfg = self.dit.cfg
             if self.buffer_embedder is not None and cfg.buffer_channels != self.buffer_embedder.buffer_channels:
@@ -233,7 +234,7 @@ class WanVideoPipeline:
                 cfg = dataclasses.replace(cfg, buffer_channels=self.buffer_embedder.buffer_channels)
             self._engine = WanDiT(cfg, self.dit.state_dict(), self._get_ops(),
                                   self.buffer_embedder.state_dict() if self.buffer_embedder else None,
-                                  gemm_dtype=self.gemm_dtype)
+                                  gemm_dtype=self.gemm_dtype, attn_dtype=self.attn_dtype)
             self._engine_key = key
         return self._engine
 

@@ -147,12 +147,12 @@ def test_image_to_video_pipeline_branch():
 def test_fp8_torch_dtype_selects_fp8_projections():
     sd = syn.make_dit_state_dict(CFG)
     pipe = WanVideoPipeline("cpu", torch.float8_e4m3fn, DiTHolder(sd, CFG), HashTextEncoder(CFG), PoolVAE(), ops=OracleOps())
-    assert pipe.gemm_dtype == "fp8"
+    assert pipe.gemm_dtype == "fp8" and pipe.attn_dtype == "fp8"
     kw = dict(prompt="a street", negative_prompt="bad", height=GRID.height, width=GRID.width, num_frames=GRID.num_frames,
               seed=0, num_inference_steps=2, return_latents=True)
     l8 = pipe(**kw)
     assert pipe._engine.fp8 and pipe._engine.layers[0]["f0_w"][0].dtype == torch.float8_e4m3fn
-    pipe.gemm_dtype = "bf16"                      # engine is rebuilt when the mode changes
+    pipe.gemm_dtype = pipe.attn_dtype = "bf16"    # engine is rebuilt when the mode changes
     l16 = pipe(**kw)
     assert not pipe._engine.fp8
     rel = float((l8 - l16).norm() / l16.norm())
