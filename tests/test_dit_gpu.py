@@ -379,6 +379,15 @@ def test_config1_wan_1p3b_17f_256p_10_steps(hip_ops):
     cos9 = float(torch.nn.functional.cosine_similarity((lat9.cpu() - noise).flatten(), (ref - noise).flatten(), dim=0))
     print(f"config #1, fp8 projections + fp8 self-attention: PSNR vs unquantised fp32 oracle {p9:.1f} dB, update cosine {cos9:.5f}")
     assert p9 >= 22.0 and cos9 >= 0.98, f"fp8 attention mode: PSNR {p9:.1f} dB, cosine {cos9}"
+    # ... and the e4m3 self-attention alone (bf16 projections): isolates what attention in fp8 costs
+    del m9
+    ma = WanDiT(cfg, sd, hip_ops, bsd, attn_dtype="fp8").prepare(grid)
+    lata = noise.clone().to("cuda:0")
+    ma.denoise(lata, ma.encode_context(c1), ma.encode_context(c2), ma.embed_buffers(bl), FlowMatchScheduler(steps), 5.0)
+    torch.cuda.synchronize()
+    pa = R.psnr(lata.cpu(), ref)
+    print(f"config #1, bf16 projections + fp8 self-attention: PSNR vs unquantised fp32 oracle {pa:.1f} dB")
+    assert pa >= 30.0
 
 
 def test_generator_end_to_end_on_gpu(tmp_path, monkeypatch):
