@@ -134,7 +134,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("ICV_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm
-        dist.init_process_group(backend=backend, **({"device_id": device} if backend == "nccl" else {}))
+        # no device_id: communicators are created lazily on first use (the classic unique-id path).  With device_id
+        # PyTorch initialises eagerly and builds the sub-groups of the cfg+sp layout with ncclCommSplit, which this
+        # build could not exercise on RCCL; torch.cuda.set_device above already binds the rank to its GPU.
+        dist.init_process_group(backend=backend)
 
     cfg = preset(args.model)
     grid = TokenGrid(args.frames, args.height, args.width)
