@@ -210,7 +210,7 @@ def main():
     def sync():
         torch.cuda.synchronize(device)
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[dev_index]) if dist.get_backend() == "nccl" else dist.barrier()
             torch.cuda.synchronize(device)
 
     xchg = BranchExchange(layout) if layout.mode == "cfg+sp" else None
