@@ -395,7 +395,7 @@ static int attn8_run(const void* qq, int64_t ldqq, const void* kq, int64_t ldkq,
   p.c.o = (bf16_t*)o; p.c.ldo = ldo; p.c.acc = acc; p.c.ldacc = ldacc; p.c.ml = ml; p.c.state_in = state_in; p.c.state_out = state_out;
   p.c.Sq = Sq; p.c.Skv = Skv; p.c.heads = (int)heads; p.c.nqb = p.nqb; p.c.sc = 1.0f; p.c.thr = p.thr;
   ICV_REQUIRE((int64_t)p.heads * p.nqb < (1LL << 31), "icv_attention_fp8_fwd: grid too large");
-  switch (icv_get_option_int("attn8_variant", 5)) {
+  switch (icv_get_option_int("attn8_variant", 0)) {
     case 0: return att8::launch<0>(p, st);
     case 1: return att8::launch<1>(p, st);
     case 4: return att8::launch<4>(p, st);
