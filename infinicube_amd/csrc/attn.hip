@@ -329,7 +329,7 @@ static int attn_route(const void* q, int64_t ldq, const void* k, int64_t ldk, co
                       int64_t Skv, int64_t heads, float scale, hipStream_t st) {
 #define ATT_ARGS q, ldq, k, ldk, v, ldv, o, ldo, acc, ldacc, ml, state_in, state_out, Sq, Skv, heads, scale
   switch (icv_get_option_int("attn_kernel", ATTN_KERNEL_DEFAULT)) {
-    case 7: return icv_attn7_dispatch(ATT_ARGS, icv_get_option_int("attn7_variant", 5), st);
+    case 7: return icv_attn7_dispatch(ATT_ARGS, icv_get_option_int("attn7_variant", 0), st);
     case 6: return icv_attn6_dispatch(ATT_ARGS, icv_get_option_int("attn6_variant", 5), st);
     case 5: return icv_attn5_dispatch(ATT_ARGS, 0, st);
     case 4: return icv_attn4_dispatch(ATT_ARGS, icv_get_option_int("attn4_variant", 4), st);

@@ -331,7 +331,7 @@ def test_attention7_variants(hip_ops, variant):
             assert torch.equal(o, o2), "non-deterministic attention output (LDS-DMA ring race?)"
             assert_bf16_close(o, ref, f"attn7 variant {variant} Sq={Sq} Skv={Skv}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
     finally:
-        hip_ops.lib.icv_set_option(b"attn_kernel", 7); hip_ops.lib.icv_set_option(b"attn7_variant", 5)
+        hip_ops.lib.icv_set_option(b"attn_kernel", 7); hip_ops.lib.icv_set_option(b"attn7_variant", 0)
 
 
 @pytest.mark.parametrize("kernel,unit", [(2, 1), (2, 0), (7, 1), (7, 0)])
