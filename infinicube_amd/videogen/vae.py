@@ -237,6 +237,16 @@ class WanVAE:
 
     def __init__(self, net: WanVAENet, device, dtype=torch.bfloat16):
         self.net, self.device, self.dtype = net.to(device=device, dtype=dtype).eval(), device, dtype
+        # weights and activations in NDHWC on the GPU: MIOpen's bf16 implicit-GEMM kernels are NHWC and otherwise transpose
+        # around every convolution (measured: encode 1.28 -> 1.11 s, decode 2.09 -> 1.92 s, search 48 -> 27 s, -3.4 GiB);
+        # ICV_VAE_CHANNELS_LAST=0 switches it off
+        self.channels_last = os.environ.get("ICV_VAE_CHANNELS_LAST", "1") == "1" and torch.device(device).type == "cuda"
+        if self.channels_last:
+            for m in self.net.modules():
+                if isinstance(m, nn.Conv3d):
+                    m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last_3d)
+                elif isinstance(m, nn.Conv2d):
+                    m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
 
     @staticmethod
     @contextlib.contextmanager
@@ -259,6 +269,8 @@ class WanVAE:
 
     def _encode(self, video, tiled=True, tile_size=(30, 52), tile_stride=(15, 26), **unused):
         x = video[None].to(device=self.device, dtype=self.dtype)
+        if self.channels_last:
+            x = x.contiguous(memory_format=torch.channels_last_3d)
         _, _, F_, H, W = x.shape
         if not tiled:
             return self.net.encode(x)[0].float()
@@ -276,6 +288,8 @@ class WanVAE:
 
     def _decode(self, latent, tiled=True, tile_size=(30, 52), tile_stride=(15, 26), **unused):
         z = latent[None].to(device=self.device, dtype=self.dtype)
+        if self.channels_last:
+            z = z.contiguous(memory_format=torch.channels_last_3d)
         _, _, T, H, W = z.shape
         if not tiled:
             return self.net.decode(z)[0].float()
