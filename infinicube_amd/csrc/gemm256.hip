@@ -40,6 +40,7 @@ struct Params {
   const float* resid; int64_t ldr;
   const float* gate;
   int tiles_m, tiles_n;
+  int gm;   // M-tiles per group of the grouped tile order
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
     const int q = nwg >> 3, r = nwg & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
   }
-  constexpr int GM = 4;
+  const int GM = p.gm;
   const int group_size = GM * p.tiles_n;
   const int g = wg / group_size;
   const int first_m = g * GM;
@@ -306,6 +307,7 @@ int icv_gemm256_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw,
   p.resid = resid; p.ldr = ldr; p.gate = gate;
   p.tiles_m = (int)((M + g256::BM - 1) / g256::BM);
   p.tiles_n = (int)((N + g256::BN - 1) / g256::BN);
+  p.gm = icv_get_option_int("gemm256_gm", 4);
   const bool m32 = icv_get_option_int("gemm256_mfma", 16) == 32;
   switch (epilogue) {
     case ICV_EPI_BF16: return m32 ? g256::launch<ICV_EPI_BF16, 32>(p, st) : g256::launch<ICV_EPI_BF16, 16>(p, st);
