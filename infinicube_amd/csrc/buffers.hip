@@ -16,19 +16,28 @@ struct CoordParams {
   int64_t N, H, W;
 };
 
+// (a0*b0 + a1*b1) + a2*b2 with every operation rounded on its own
+__device__ __forceinline__ float dot3(float a0, float b0, float a1, float b1, float a2, float b2) {
+  return __fadd_rn(__fadd_rn(__fmul_rn(a0, b0), __fmul_rn(a1, b1)), __fmul_rn(a2, b2));
+}
+
 __device__ __forceinline__ void point_cam0(const CoordParams& p, int64_t pix, float d, float out[3]) {
   const int64_t hw = p.H * p.W;
   const int n = (int)(pix / hw);
   const int64_t r = pix - (int64_t)n * hw;
   const float y = (float)(r / p.W), x = (float)(r % p.W);
-  // rays = Kinv (x, y, 1)
-  const float rx = p.kinv[0] * x + p.kinv[1] * y + p.kinv[2];
-  const float ry = p.kinv[3] * x + p.kinv[4] * y + p.kinv[5];
-  const float rz = p.kinv[6] * x + p.kinv[7] * y + p.kinv[8];
-  const float cx = d * rx, cy = d * ry, cz = d * rz;
+  // rays = Kinv (x, y, 1).  Byte outputs must match the reference bit for bit, so every product and sum is rounded
+  // separately, left to right, exactly like the reference's torch.matmul on these 3x3 / 4x4 operands (verified against
+  // its CPU output: no fused multiply-add anywhere; tests/golden/make_coord_buffer_golden.py) — hence the explicit
+  // round-to-nearest intrinsics instead of expressions hipcc may contract (the TU is also built -ffp-contract=off).
+  const float rx = dot3(p.kinv[0], x, p.kinv[1], y, p.kinv[2], 1.0f);
+  const float ry = dot3(p.kinv[3], x, p.kinv[4], y, p.kinv[5], 1.0f);
+  const float rz = dot3(p.kinv[6], x, p.kinv[7], y, p.kinv[8], 1.0f);
+  const float cx = __fmul_rn(d, rx), cy = __fmul_rn(d, ry), cz = __fmul_rn(d, rz);
   const float* m = p.tf + (int64_t)n * 16;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) out[i] = m[i * 4 + 0] * cx + m[i * 4 + 1] * cy + m[i * 4 + 2] * cz + m[i * 4 + 3];
+  for (int i = 0; i < 3; ++i)
+    out[i] = __fadd_rn(dot3(m[i * 4 + 0], cx, m[i * 4 + 1], cy, m[i * 4 + 2], cz), __fmul_rn(m[i * 4 + 3], 1.0f));
 }
 
 __global__ __launch_bounds__(256) void coord_valid_mask_kernel(CoordParams p, unsigned char* __restrict__ mask, int64_t total) {
@@ -67,19 +76,20 @@ __global__ __launch_bounds__(256) void coord_normalize_kernel(CoordParams p, flo
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       if (has_valid) {
-        float t = (pt[c] - mn[c]) / rg[c] * 2.0f - 1.0f;
+        // (clamp((pt - min) / range * 2 - 1, -1, 1) + 1) / 2, torch's op order [R infinicube/utils/buffer_utils.py:246-252]
+        float t = __fsub_rn(__fmul_rn(__fdiv_rn(__fsub_rn(pt[c], mn[c]), rg[c]), 2.0f), 1.0f);
         t = fminf(fmaxf(t, -1.0f), 1.0f);
-        v[c] = (t + 1.0f) / 2.0f;
+        v[c] = __fdiv_rn(__fadd_rn(t, 1.0f), 2.0f);
       } else {
-        v[c] = pt[c] * 0.5f;
+        v[c] = __fmul_rn(pt[c], 0.5f);
       }
     }
   }
   if (out_f32) { out_f32[i * 3 + 0] = v[0]; out_f32[i * 3 + 1] = v[1]; out_f32[i * 3 + 2] = v[2]; }
   if (out_u8) {   // the caller's `(buffer * 255).astype(np.uint8)`: truncation toward zero
-    out_u8[i * 3 + 0] = (unsigned char)(int)(v[0] * 255.0f);
-    out_u8[i * 3 + 1] = (unsigned char)(int)(v[1] * 255.0f);
-    out_u8[i * 3 + 2] = (unsigned char)(int)(v[2] * 255.0f);
+    out_u8[i * 3 + 0] = (unsigned char)(int)__fmul_rn(v[0], 255.0f);
+    out_u8[i * 3 + 1] = (unsigned char)(int)__fmul_rn(v[1], 255.0f);
+    out_u8[i * 3 + 2] = (unsigned char)(int)__fmul_rn(v[2], 255.0f);
   }
 }
 

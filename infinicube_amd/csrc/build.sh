@@ -13,7 +13,10 @@ mkdir -p "$here/build"
 for src in api elementwise gemm gemm256 gemm256w gemm_fp8 fp8 attn attn2 attn3 attn4 attn5 attn6 attn7 attn8 buffers; do
   obj="$here/build/$src.o"
   if [[ ! -f "$obj" || "$here/$src.hip" -nt "$obj" || "$here/icv_common.h" -nt "$obj" || "$here/attn_common.h" -nt "$obj" || "$root/include/icvideo.h" -nt "$obj" ]]; then
-    "$HIPCC" "${FLAGS[@]}" "$@" -c "$here/$src.hip" -o "$obj" &
+    extra=()
+    # buffers.hip produces BYTE outputs that must equal the reference's: no fused multiply-add contraction there
+    [[ "$src" == buffers ]] && extra=(-ffp-contract=off)
+    "$HIPCC" "${FLAGS[@]}" "${extra[@]}" "$@" -c "$here/$src.hip" -o "$obj" &
     pids+=($!)
   fi
   objs+=("$obj")

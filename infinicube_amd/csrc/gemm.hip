@@ -185,6 +185,9 @@ extern "C" int icv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t 
   ICV_REQUIRE(M > 0 && N > 0 && K >= 64 && K % 64 == 0, "icv_gemm_bf16: K=%lld must be a positive multiple of 64", (long long)K);
   ICV_REQUIRE(N < (1LL << 31), "icv_gemm_bf16: N=%lld too large", (long long)N);
   ICV_REQUIRE(N % 4 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldo % 4 == 0, "icv_gemm_bf16: N%%4, lda%%8, ldw%%8, ldo%%4 alignment");
+  // both kernels keep per-lane A / W source offsets as 32-bit byte offsets from the operand base
+  ICV_REQUIRE((double)M * (double)lda * 2.0 < 4294967296.0 && (double)N * (double)ldw * 2.0 < 4294967296.0,
+              "icv_gemm_bf16: operand spans >= 4 GiB (M*lda or N*ldw): split the rows");
   if (nsplit <= 0) nsplit = N;
   ICV_REQUIRE(nsplit % 4 == 0 && N % nsplit == 0, "icv_gemm_bf16: nsplit must divide N and be a multiple of 4");
   ICV_REQUIRE(epilogue != ICV_EPI_RESID_F32 || (resid && ldr % 4 == 0 && nsplit == N), "icv_gemm_bf16: RESID epilogue needs resid, ldr%%4==0, no split");

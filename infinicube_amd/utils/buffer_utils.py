@@ -55,6 +55,9 @@ def generate_coordinate_buffer_from_memory_global_norm(depth_buffer: torch.Tenso
         native.check(lib.icv_coord_gather_points(depth.data_ptr(), kinv, to_cam0.data_ptr(), n, h, w,
                                                  sample_idx.data_ptr(), sample_idx.numel(), sample.data_ptr(), stream),
                      "icv_coord_gather_points")
+        # the two quantiles of <= 100000 x 3 numbers are taken on the host like the reference's CPU call: a device
+        # quantile interpolates with a different rounding, and the uint8 buffer has to match bit for bit
+        sample = sample.cpu()
         lo = torch.quantile(sample, percentile, dim=0)
         hi = torch.quantile(sample, 1 - percentile, dim=0)
         mins, ranges = _f32_host(lo), _f32_host(torch.clamp(hi - lo, min=1e-7))

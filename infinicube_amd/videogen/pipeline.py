@@ -187,15 +187,18 @@ class WanVideoPipeline:
         """Load DiT / UMT5 / Wan-VAE from local files (never downloads).  Files are recognised by
         name, like the reference's three patterns [R infinicube/videogen/inference.py:67-69]."""
         pipe = cls(device=device, torch_dtype=torch_dtype)
+        # torch_dtype=float8_e4m3fn selects the DiT's fp8 MFMA mode only; the encoders outside the loop are stock
+        # torch modules that cannot run on unscaled e4m3 weights, so they load in bf16
+        aux_dtype = torch.bfloat16 if torch_dtype == torch.float8_e4m3fn else torch_dtype
         for mc in model_configs:
             pattern = mc.resolve()
             base = os.path.basename(pattern)
             if "clip" in base.lower():
                 from .clip_vision import load_clip_vision
-                pipe.image_encoder = load_clip_vision(pattern, device, torch_dtype)
+                pipe.image_encoder = load_clip_vision(pattern, device, aux_dtype)
             elif "t5" in base.lower():
                 from .text_encoder import load_umt5_encoder
-                pipe.text_encoder = load_umt5_encoder(pattern, device, torch_dtype, tokenizer_config)
+                pipe.text_encoder = load_umt5_encoder(pattern, device, aux_dtype, tokenizer_config)
             elif "vae" in base.lower():
                 from .vae import load_wan_vae
                 pipe.vae = load_wan_vae(pattern, device)
@@ -300,6 +303,8 @@ class WanVideoPipeline:
         g = torch.Generator(device="cpu")
         if seed is not None:
             g.manual_seed(int(seed))
+        else:
+            g.seed()     # upstream passes generator=None: a different noise on every unseeded call
         latent = torch.randn((1, 16) + grid.latent_shape()[1:], generator=g, dtype=torch.float32)[0]
         latent = ops.to_device(latent, torch.float32)
         # guidance buffers -> VAE latents -> tokens (step-invariant)

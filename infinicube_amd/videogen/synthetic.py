@@ -147,3 +147,59 @@ def make_dummy_buffers(grid: TokenGrid):
     co[..., 1] = np.linspace(0, 255, h, dtype=np.float32).astype(np.uint8)[None, :, None]
     co[..., 2] = np.linspace(0, 255, n, dtype=np.float32).astype(np.uint8)[:, None, None]
     return sem, co
+
+
+class PinholeStandIn:
+    """The one method of the reference's camera model that the coordinate-buffer function calls
+    (``get_intrinsics_matrix()`` [R infinicube/utils/buffer_utils.py:212])."""
+
+    def __init__(self, fx, fy, cx, cy):
+        self.k = torch.tensor([[fx, 0.0, cx], [0.0, fy, cy], [0.0, 0.0, 1.0]], dtype=torch.float32)
+
+    def get_intrinsics_matrix(self):
+        return self.k
+
+
+def make_scene_maps(grid: TokenGrid, device="cpu"):
+    """A synthetic street scene in the form stage 2 hands to the buffer functions
+    [R infinicube/inference/guidance_buffer_generation.py:690-713]: per frame a metric depth map (0 = sky /
+    infinitely far), a Waymo class-index map and a uint16 instance map, plus the pinhole camera and the
+    camera-to-world poses of a camera driving forward.  Ground plane 1.6 m under the camera, building
+    walls 9 m either side up to 12 m, sky above, and two box 'vehicles' that approach and drift.
+    Returns (depth f32 [N,H,W], semantic i32 [N,H,W], instance i32 [N,H,W], camera, poses f32 [N,4,4])."""
+    n, h, w = grid.num_frames, grid.height, grid.width
+    dev = torch.device(device)
+    fx = fy = 0.9 * w
+    cx, cy = w / 2.0, h * 0.55
+    cam = PinholeStandIn(fx, fy, cx, cy)
+    v, u = torch.meshgrid(torch.arange(h, dtype=torch.float32, device=dev), torch.arange(w, dtype=torch.float32, device=dev), indexing="ij")
+    dx, dy = (u + 0.5 - cx) / fx, (v + 0.5 - cy) / fy                 # ray direction (dx, dy, 1), OpenCV axes (y down)
+    inf = torch.full_like(dx, float("inf"))
+    z_ground = torch.where(dy > 1e-4, 1.6 / dy.clamp(min=1e-4), inf)
+    z_wall = torch.where(dx.abs() > 1e-4, 9.0 / dx.abs().clamp(min=1e-4), inf)
+    wall_ok = (-(dy * z_wall)) < 12.0 - 1.6                            # the wall ends 12 m above the ground
+    z_wall = torch.where(wall_ok, z_wall, inf)
+    base = torch.minimum(z_ground, z_wall)
+    base_sem = torch.where(z_ground <= z_wall, torch.full_like(dx, 18.0), torch.full_like(dx, 14.0))   # ROAD / BUILDING
+    depth = torch.empty((n, h, w), dtype=torch.float32, device=dev)
+    sem = torch.empty((n, h, w), dtype=torch.int32, device=dev)
+    inst = torch.zeros((n, h, w), dtype=torch.int32, device=dev)
+    poses = torch.eye(4, dtype=torch.float32).repeat(n, 1, 1)
+    for i in range(n):
+        d = torch.where(base > 150.0, torch.zeros_like(base), base)   # beyond the voxel world: sky (depth 0)
+        s = torch.where(d > 0, base_sem, torch.zeros_like(base_sem))
+        ins = torch.zeros_like(base)
+        for j, (x0, z0, vz, cls) in enumerate(((-2.5, 40.0, -0.25, 1), (3.0, 25.0, 0.05, 2))):   # CAR, TRUCK
+            zc = z0 + vz * i
+            if zc <= 3.0:
+                continue
+            ul, ur = cx + fx * (x0 - 1.0) / zc, cx + fx * (x0 + 1.0) / zc
+            vt, vb = cy + fy * (1.6 - 1.7) / zc, cy + fy * 1.6 / zc
+            box = (u >= ul) & (u < ur) & (v >= vt) & (v < vb) & ((d == 0) | (d > zc))
+            d = torch.where(box, torch.full_like(d, zc), d)
+            s = torch.where(box, torch.full_like(s, float(cls)), s)
+            ins = torch.where(box, torch.full_like(ins, float(j + 1)), ins)
+        depth[i], sem[i], inst[i] = d, s.to(torch.int32), ins.to(torch.int32)
+        poses[i, 2, 3] = 0.35 * i                                      # 3.5 m/s at 10 fps, straight ahead
+        poses[i, 0, 3] = 0.4 * float(torch.sin(torch.tensor(i / 15.0)))
+    return depth, sem, inst, cam, poses

@@ -38,14 +38,15 @@ Tensor = torch.Tensor
 def sinusoidal_embedding_1d(dim: int, position: Tensor) -> Tensor:
     """cat[cos(t f_i), sin(t f_i)], f_i = 10000^(-i/(dim/2)), fp64 (Appendix A.2)."""
     half = dim // 2
-    freqs = torch.pow(10000.0, -torch.arange(half, dtype=torch.float64) / half)
+    freqs = torch.pow(10000.0, -torch.arange(half, dtype=torch.float64) / half).to(position.device)
     ang = torch.outer(position.to(torch.float64).reshape(-1), freqs)
     return torch.cat([torch.cos(ang), torch.sin(ang)], dim=1)
 
 
 def time_embed(sd: Dict[str, Tensor], cfg, timestep: float, dtype=torch.float32) -> Tuple[Tensor, Tensor]:
     """returns (t [d], t_mod [6, d])."""
-    emb = sinusoidal_embedding_1d(cfg.freq_dim, torch.tensor([timestep], dtype=torch.float64)).to(dtype)
+    dev = sd["time_embedding.0.weight"].device   # the oracle runs wherever its weights live (CPU by default)
+    emb = sinusoidal_embedding_1d(cfg.freq_dim, torch.tensor([timestep], dtype=torch.float64)).to(device=dev, dtype=dtype)
     t = F.linear(F.silu(F.linear(emb, sd["time_embedding.0.weight"].to(dtype), sd["time_embedding.0.bias"].to(dtype))),
                  sd["time_embedding.2.weight"].to(dtype), sd["time_embedding.2.bias"].to(dtype))
     t_mod = F.linear(F.silu(t), sd["time_projection.1.weight"].to(dtype), sd["time_projection.1.bias"].to(dtype))
@@ -118,13 +119,24 @@ def modulate(x: Tensor, shift: Tensor, scale: Tensor) -> Tensor:
 
 
 def attention(q: Tensor, k: Tensor, v: Tensor, num_heads: int, scale: Optional[float] = None) -> Tensor:
-    """q [Sq, H*hd], k/v [Sk, H*hd] -> [Sq, H*hd]; non-causal softmax(q k^T * scale) v, scale = 1/sqrt(hd) by default."""
+    """q [Sq, H*hd], k/v [Sk, H*hd] -> [Sq, H*hd]; non-causal softmax(q k^T * scale) v, scale = 1/sqrt(hd) by default.
+    On CPU: torch's SDPA.  On a GPU (the full-size checker of tests/test_fullsize_gpu.py): the explicit
+    definition matmul -> softmax -> matmul over query chunks, so the checker depends on no fused attention
+    backend (and on nothing in libicvideo)."""
     Sq, Sk = q.shape[0], k.shape[0]
     qh = q.reshape(Sq, num_heads, -1).transpose(0, 1)
     kh = k.reshape(Sk, num_heads, -1).transpose(0, 1)
     vh = v.reshape(Sk, num_heads, -1).transpose(0, 1)
-    o = F.scaled_dot_product_attention(qh[None], kh[None], vh[None], scale=scale)[0]
-    return o.transpose(0, 1).reshape(Sq, -1)
+    if q.device.type == "cpu":
+        o = F.scaled_dot_product_attention(qh[None], kh[None], vh[None], scale=scale)[0]
+        return o.transpose(0, 1).reshape(Sq, -1)
+    sc = (1.0 / math.sqrt(qh.shape[-1])) if scale is None else scale
+    step = max(1, (1 << 31) // (4 * num_heads * Sk))      # <= 2 GiB of scores per chunk
+    outs = []
+    for r0 in range(0, Sq, step):
+        p = torch.softmax(torch.matmul(qh[:, r0: r0 + step], kh.transpose(1, 2)) * sc, dim=-1)
+        outs.append(torch.matmul(p, vh))
+    return torch.cat(outs, dim=1).transpose(0, 1).reshape(Sq, -1)
 
 
 def attention_fp8(q: Tensor, k: Tensor, v: Tensor, num_heads: int) -> Tensor:
@@ -266,7 +278,7 @@ def dit_forward(sd: Dict[str, Tensor], cfg, latent: Tensor, context: Tensor, tim
     x = patchify_tokens(latent.to(dtype), sd["patch_embedding.weight"].to(dtype), sd["patch_embedding.bias"].to(dtype))
     if buf_tokens is not None:
         x = x + buf_tokens.to(dtype)
-    freqs = rope_freqs_3d(cfg.head_dim, *grid)
+    freqs = rope_freqs_3d(cfg.head_dim, *grid).to(x.device)
     for i in range(cfg.num_layers if num_layers is None else num_layers):
         x = dit_block(sd, cfg, i, x, ctx, t_mod, freqs, dtype, ctx_img=ctx_img, fp8=fp8)
     if return_tokens:

@@ -1,0 +1,248 @@
+"""Parity at the sizes BASELINE.json is quoted on (configs #2, #3, #5): S = 37 440 tokens (93 f 480x832
+[R infinicube/inference/guidance_buffer_generation.py:79-82,744-745]) and S = 86 400 (93 f 720x1280).
+
+  * self-attention alone at full S, sampled query rows vs the CPU oracle (bf16 default route, key-chunked
+    carried-state route, e4m3 route);
+  * ONE DiT block at the real Wan2.1-14B (t2v) and 14B-i2v dimensions over ALL tokens, checked on a token
+    slice whose keys / values come from all S tokens (CPU oracle);
+  * config #2 end to end: Wan2.1-1.3B, S = 37 440, 10 flow-match steps with CFG and guidance buffers rendered
+    from a synthetic scene, against the SAME oracle code (oracle/wan_ref.py) executed in fp32 by stock PyTorch on
+    the GPU with the explicit matmul-softmax-matmul attention — a checker that shares nothing with libicvideo.
+Tolerances: SURVEY.md §8d (one forward: cosine >= 0.999, rel-L2 <= 2e-2; loop: PSNR >= 40 dB).
+"""
+import dataclasses
+import math
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wan_ref as R
+from infinicube_amd.videogen import synthetic as syn
+from infinicube_amd.videogen.config import GRID_480P, GRID_720P, preset
+from infinicube_amd.videogen.dit import WanDiT
+from infinicube_amd.videogen.scheduler import FlowMatchScheduler
+from infinicube_amd.videogen.seqpar import chunk_bounds
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+LN2 = math.log(2.0)
+FOLD = (1.0 / math.sqrt(128)) * math.log2(math.e)
+
+
+def _rnd(shape, seed, std=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * std
+
+
+def _attn_case(S, H, n_rows):
+    """bf16 q, k (carrying the folded softmax scale, as the DiT hands it over), v at full S and the sampled rows.
+    Some sampled queries get a strongly matching key deep in the sequence (tiles 3, S/128, the last) so the
+    running reference of the lazy-max path is outgrown late, not only in the first tile."""
+    d = H * 128
+    q = _rnd((S, d), 901).to(torch.bfloat16)
+    kf = _rnd((S, d), 902)
+    v = _rnd((S, d), 903).to(torch.bfloat16)
+    g = torch.Generator().manual_seed(904)
+    rows = torch.sort(torch.randperm(S, generator=g)[:n_rows]).values
+    rows[0], rows[-1] = 0, S - 1
+    for j, key in enumerate((3 * 64 + 5, S // 2 + 17, S - 1, S - 64 * 9 - 3)):
+        kf[key] = q[rows[7 * j + 1]].float() * (3.0 + j)
+    k = (kf * FOLD).to(torch.bfloat16)
+    return q, k, v, rows
+
+
+def _check_rows(o, ref, what, rms_bound=2.0 ** -7, abs_floor=2.0 ** -5):
+    got, ref = o.float().cpu(), ref.float()
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    rms = ref.pow(2).mean().sqrt()
+    rms_err = (got - ref).pow(2).mean().sqrt()
+    assert rms_err <= rms_bound * rms, f"{what}: rms err {rms_err:.4g} > {rms_bound:.3g} * rms {rms:.4g}"
+    bad = (got - ref).abs() > (2.0 ** -7) * ref.abs() + abs_floor * rms
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} outside tol, max err {(got - ref).abs().max():.4g}"
+
+
+@pytest.mark.parametrize("S", [GRID_480P.S, GRID_720P.S])
+def test_attention_full_size(hip_ops, S):
+    """K6 at the metric's own sequence lengths (585 / 1350 key tiles per row): the default route (attn7, unit scale,
+    lazy max), the key-chunked carried-state route the sequence-parallel path uses (4 ramped chunks), and the e4m3
+    route, each checked on 512 sampled query rows against the CPU oracle."""
+    H = 2
+    q, k, v, rows = _attn_case(S, H, 512)
+    ref = R.attention(q[rows].float(), k.float(), v.float(), H, scale=LN2)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    o = torch.zeros((S, H * 128), dtype=torch.bfloat16, device=DEV)
+    hip_ops.attention(qd, kd, vd, o, H, LN2)
+    _check_rows(o[rows.to(DEV)], ref, f"attention S={S}")
+    o2 = torch.zeros_like(o)
+    hip_ops.attention(qd, kd, vd, o2, H, LN2)
+    assert torch.equal(o, o2), "full-size attention is not deterministic"
+    # key chunks with carried (O, m, l) state
+    acc = torch.empty((S, H * 128), device=DEV)
+    ml = torch.empty((S, H, 2), device=DEV)
+    b = chunk_bounds(S, 4)
+    o3 = torch.zeros_like(o)
+    for c in range(4):
+        hip_ops.attention_chunk(qd, kd[b[c]:b[c + 1]], vd[b[c]:b[c + 1]], o3, acc, ml, H, LN2, first=(c == 0), last=(c == 3))
+    _check_rows(o3[rows.to(DEV)], ref, f"chunked attention S={S}")
+    # e4m3 operands (config #5's mode): vs the oracle with the same per-head power-of-two quantisation
+    ws = hip_ops.attention_fp8_buffers(S, S, H * 128, H)
+    o8 = torch.zeros_like(o)
+    hip_ops.attention_fp8(qd, kd, vd, o8, H, ws)
+    sub = rows[:128]
+    ref8 = R.attention_fp8(q[sub].float(), k.float(), v.float(), H)
+    got8 = o8[sub.to(DEV)].float().cpu()
+    assert torch.isfinite(got8).all()
+    rel8 = float((got8 - ref8).pow(2).mean().sqrt() / ref8.pow(2).mean().sqrt())
+    rel8_exact = float((got8 - ref[:128]).pow(2).mean().sqrt() / ref[:128].pow(2).mean().sqrt())
+    print(f"S={S}: fp8 attention rms err vs e4m3 oracle {rel8:.4f}, vs exact {rel8_exact:.4f}")
+    assert rel8 <= 0.03, f"fp8 attention S={S}: rms err {rel8} vs the oracle with the same quantisation"
+
+
+def _block_case(model, grid, n_slice, fp8=False):
+    """One block at the model's real width over ALL S tokens on the GPU; the CPU oracle recomputes the tokens of one
+    slice (LayerNorm/modulate and the K, V projections + RoPE for all tokens, everything else for the slice)."""
+    cfg = dataclasses.replace(preset(model), num_layers=1)
+    sd = syn.make_dit_state_dict(cfg, seed=0, dtype=torch.bfloat16)
+    bsd = syn.make_buffer_embedder_state_dict(cfg, dtype=torch.bfloat16)
+    sdr, bsdr = {k: v.float() for k, v in sd.items()}, {k: v.float() for k, v in bsd.items()}
+    noise, ctx, bl = syn.make_latent_noise(grid), syn.make_text_context(cfg, 1), syn.make_buffer_latents(cfg, grid)
+    clip = syn.make_clip_features(cfg) if cfg.has_image_input else None
+    y = syn.make_cond_latents(cfg, grid) if cfg.has_image_input else None
+    ts = 731.0
+    return cfg, sd, bsd, sdr, bsdr, noise, ctx, bl, clip, y, ts
+
+
+def _oracle_block_slice(sdr, bsdr, cfg, grid, noise, ctx, bl, clip, y, ts, sl, fp8):
+    f32 = torch.float32
+    lat = noise if y is None else torch.cat([noise, y], 0)
+    x_all = R.patchify_tokens(lat, sdr["patch_embedding.weight"], sdr["patch_embedding.bias"]) + R.buffer_embed(bsdr, bl)
+    _, t_mod = R.time_embed(sdr, cfg, ts)
+    ctx_e = R.text_embed(sdr, ctx)
+    ctx_img = R.image_embed(sdr, clip) if clip is not None else None
+    freqs = R.rope_freqs_3d(cfg.head_dim, grid.T, grid.Hp, grid.Wp)
+    p = "blocks.0"
+    lin = R._lin8 if fp8 else R._lin
+    mod = sdr[f"{p}.modulation"].reshape(6, cfg.dim) + t_mod
+    h_all = R.modulate(R.layer_norm(x_all, None, None, cfg.eps), mod[0], mod[1])
+    k_all = R.rope_apply(R.rms_norm(lin(sdr, f"{p}.self_attn.k", h_all, f32), sdr[f"{p}.self_attn.norm_k.weight"], cfg.eps), freqs, cfg.num_heads)
+    v_all = lin(sdr, f"{p}.self_attn.v", h_all, f32)
+    del h_all
+    x_out = R.dit_block(sdr, cfg, 0, x_all[sl], ctx_e, t_mod, freqs[sl], kv_override=lambda k, v: (k_all, v_all),
+                        ctx_img=ctx_img, fp8=fp8)
+    return x_all[sl], x_out
+
+
+def _run_block(hip_ops, model, grid, sl, gemm_dtype="bf16", attn_dtype="bf16"):
+    cfg, sd, bsd, sdr, bsdr, noise, ctx, bl, clip, y, ts = _block_case(model, grid, sl)
+    m = WanDiT(cfg, sd, hip_ops, bsd, gemm_dtype=gemm_dtype, attn_dtype=attn_dtype).prepare(grid, graphs=False)
+    ck = m.encode_context(ctx, clip)
+    bt = m.embed_buffers(bl)
+    if y is not None:
+        bt = m.embed_cond_latents(y, add_to=bt)
+    lat = noise.to(DEV)
+    m.forward_tokens(lat, ck, ts, bt, m.head_out[0], num_layers=0)
+    x_in = m.x[sl].clone()
+    m.forward_tokens(lat, ck, ts, bt, m.head_out[0], num_layers=1)
+    torch.cuda.synchronize()
+    x_out = m.x[sl].float().cpu()
+    x_in = x_in.float().cpu()
+    del m
+    t0 = time.time()
+    rx_in, rx_out = _oracle_block_slice(sdr, bsdr, cfg, grid, noise, ctx, bl, clip, y, ts, sl, fp8=(gemm_dtype == "fp8"))
+    t_cpu = time.time() - t0
+    u, ur = x_out - x_in, rx_out - rx_in                       # the block's update of the residual stream
+    rel_in = float((x_in - rx_in).norm() / rx_in.norm())
+    rel = float((u - ur).norm() / ur.norm())
+    cos = float(torch.nn.functional.cosine_similarity(u.flatten(), ur.flatten(), dim=0))
+    print(f"{model} S={grid.S} {gemm_dtype}/{attn_dtype}: block-update rel-L2 {rel:.4g}, cosine {cos:.6f}, "
+          f"input rel-L2 {rel_in:.3g}, oracle {t_cpu:.1f}s on CPU")
+    return rel_in, rel, cos
+
+
+def test_layer_14b_full_S(hip_ops):
+    """Config #3's layer: d = 5120, ffn = 13824, 40 heads, S = 37 440 — every kernel of a block (K1, K3-K10) at the
+    benchmarked shape, checked on tokens [17000, 19048) (mid-grid RoPE offsets; keys / values from all tokens)."""
+    rel_in, rel, cos = _run_block(hip_ops, "14b", GRID_480P, slice(17000, 17000 + 2048))
+    assert rel_in <= 1e-3, f"patch + buffer embed at 14B width: rel-L2 {rel_in}"
+    assert cos >= 0.999 and rel <= 2e-2, f"14B block at S=37440: rel-L2 {rel}, cosine {cos}"
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp8"])
+def test_layer_14b_i2v_720p(hip_ops, mode):
+    """Config #5's layer: Wan2.1-14B i2v (36 input channels, CLIP cross-attention branch) at 93 f 720x1280,
+    S = 86 400.  bf16 against the oracle; fp8 (e4m3 projections + e4m3 self-attention, what
+    torch_dtype=float8_e4m3fn selects) against the oracle with the same row quantisation of the projections."""
+    sl = slice(40000, 40000 + 1024)
+    if mode == "bf16":
+        rel_in, rel, cos = _run_block(hip_ops, "14b-i2v", GRID_720P, sl)
+        assert rel_in <= 1e-3
+        assert cos >= 0.999 and rel <= 2e-2, f"14B i2v block at S=86400: rel-L2 {rel}, cosine {cos}"
+    else:
+        rel_in, rel, cos = _run_block(hip_ops, "14b-i2v", GRID_720P, sl, gemm_dtype="fp8", attn_dtype="fp8")
+        assert rel_in <= 1e-3
+        assert cos >= 0.998 and rel <= 6e-2, f"14B i2v fp8 block at S=86400: rel-L2 {rel}, cosine {cos}"
+
+
+def _frames_u8(latent, vae):
+    v = vae.decode(latent.float().cpu())
+    return ((v.clamp(-1, 1) + 1.0) * 127.5).round().to(torch.uint8)
+
+
+def frame_psnr(lat_a, lat_b, vae):
+    """PSNR of the DECODED uint8 frames (peak 255), the same decoder on both arms."""
+    a, b = _frames_u8(lat_a, vae).double(), _frames_u8(lat_b, vae).double()
+    mse = float(((a - b) ** 2).mean())
+    return float("inf") if mse == 0 else 10.0 * math.log10(255.0 ** 2 / mse)
+
+
+def test_config2_wan_1p3b_93f_480p(hip_ops):
+    """BASELINE.json config #2: Wan2.1-1.3B t2v, 93 frames 480x832 (S = 37 440), guidance buffers rendered from a
+    synthetic scene through the product's own buffer kernels (depth -> coordinate buffer, class / instance maps ->
+    colour buffer, uint8), stand-in VAE encode, 10 flow-match steps with CFG.  HIP loop vs oracle/wan_ref.py run in
+    fp32 on the GPU by stock PyTorch.  Bars: final-latent PSNR >= 40 dB, decoded-frame PSNR (peak 255) >= 40 dB."""
+    from infinicube_amd.utils.buffer_utils import generate_coordinate_buffer_from_memory_global_norm
+    from infinicube_amd.utils.semantic_utils import generate_rgb_semantic_buffer, semantic_to_color
+    from infinicube_amd.videogen.pipeline import _video_to_tensor
+    from infinicube_amd.videogen.standins import PoolVAE
+    from PIL import Image
+    cfg, grid = preset("1.3b"), GRID_480P
+    torch.manual_seed(0); np.random.seed(0)
+    depth, sem, inst, cam, poses = syn.make_scene_maps(grid, DEV)
+    coord_u8 = generate_coordinate_buffer_from_memory_global_norm(depth, cam, poses, return_uint8=True).cpu().numpy()
+    sem_rgb = (semantic_to_color(sem) * 255).astype(np.uint8)
+    sem_u8 = generate_rgb_semantic_buffer(sem_rgb, inst.cpu().numpy().astype(np.uint16))
+    assert coord_u8.shape == sem_u8.shape == (93, 480, 832, 3)
+    assert (coord_u8 == 255).all(-1).mean() > 0.05, "the scene has sky (coordinate buffer = 1.0 there)"
+    vae = PoolVAE()
+    lats = [vae.encode(_video_to_tensor([Image.fromarray(f) for f in buf], grid.height, grid.width)) for buf in (sem_u8, coord_u8)]
+    bl = torch.cat(lats, 0).float()
+    sd = syn.make_dit_state_dict(cfg, seed=0, dtype=torch.bfloat16)
+    bsd = syn.make_buffer_embedder_state_dict(cfg, dtype=torch.bfloat16)
+    noise = syn.make_latent_noise(grid)
+    c1, c2 = syn.make_text_context(cfg, 1), syn.make_text_context(cfg, 2)
+    steps = 10
+    m = WanDiT(cfg, sd, hip_ops, bsd).prepare(grid)
+    lat = noise.clone().to(DEV)
+    t0 = time.time()
+    m.denoise(lat, m.encode_context(c1), m.encode_context(c2), m.embed_buffers(bl), FlowMatchScheduler(steps), 5.0)
+    torch.cuda.synchronize()
+    t_hip = time.time() - t0
+    lat = lat.cpu()
+    del m
+    torch.cuda.empty_cache()
+    # the checker: the oracle's own code on GPU tensors, fp32 (no bf16 anywhere except the shared weight values)
+    sdr = {k: v.float().to(DEV) for k, v in sd.items()}
+    bsdr = {k: v.float().to(DEV) for k, v in bsd.items()}
+    t0 = time.time()
+    ref = R.denoise_loop(sdr, bsdr, cfg, noise.to(DEV), c1.to(DEV), c2.to(DEV), bl.to(DEV), num_steps=steps)
+    torch.cuda.synchronize()
+    t_ref = time.time() - t0
+    ref = ref.cpu()
+    p = R.psnr(lat, ref)
+    pf = frame_psnr(lat, ref, vae)
+    cos = float(torch.nn.functional.cosine_similarity((lat - noise).flatten(), (ref - noise).flatten(), dim=0))
+    print(f"config #2: HIP {t_hip:.1f}s, fp32 torch oracle on GPU {t_ref:.1f}s, latent PSNR {p:.1f} dB, "
+          f"decoded-frame PSNR {pf:.1f} dB, update cosine {cos:.5f}")
+    assert p >= 40.0 and pf >= 40.0 and cos >= 0.999, f"config #2 parity: latent {p:.1f} dB, frames {pf:.1f} dB, cosine {cos}"
