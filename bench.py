@@ -38,6 +38,7 @@ from infinicube_amd.videogen.scheduler import FlowMatchScheduler  # noqa: E402
 from infinicube_amd.videogen.seqpar import BranchExchange, ParallelLayout  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_FP8_TFLOPS = 5000.0    # dense fp8 (K=64/128 scaled) MFMA peak, same guide
 CFG_SCALE = 5.0
 
 
@@ -113,6 +114,9 @@ def main():
     ap.add_argument("--parallelism", default=os.environ.get("ICV_PARALLELISM", "auto"), choices=["auto", "sp", "cfg+sp"],
                     help="N>1: 'sp' = token shards over all N ranks, both CFG forwards on every rank; 'cfg+sp' = cond / "
                          "uncond forwards on two groups of N/2 ranks, token shards inside a group (auto when N is even)")
+    ap.add_argument("--kv-exchange", default=os.environ.get("ICV_KV_EXCHANGE", "allgather"), choices=["allgather", "p2p"],
+                    help="N>1: K|V rows travel by all_gather_into_tensor (RCCL's schedule) or by grouped send/recv to every "
+                         "peer (the direct, fully-connected schedule; seqpar.KVGather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -152,7 +156,7 @@ def main():
     del sd, bsd
     # graphs off: the bench times individual attention launches with events (at the metric's size the loop is GPU-bound
     # and "auto" would not capture anyway)
-    model.prepare(grid, plan, sp_chunks=args.sp_chunks, group=layout.sp_group, graphs=False)
+    model.prepare(grid, plan, sp_chunks=args.sp_chunks, group=layout.sp_group, graphs=False, kv_exchange=args.kv_exchange)
     clip = syn.make_clip_features(cfg) if cfg.has_image_input else None
     ctx_c = model.encode_context(syn.make_text_context(cfg, 1), clip)
     ctx_u = model.encode_context(syn.make_text_context(cfg, 2), clip)
@@ -219,14 +223,36 @@ def main():
         model.denoise(latent, ctx_c if layout.branch in (None, 0) else None, ctx_u if layout.branch in (None, 1) else None,
                       buf, sched, CFG_SCALE, steps=[(first + i) % total_steps for i in range(count)], branch_exchange=xchg)
 
+    from infinicube_amd import native
     run_steps(0, args.warmup)
     sync()
     record["on"] = True
+    if model.kv_gather is not None:
+        model.kv_gather.timing = []          # (event before, event after) each wait on a K|V chunk: exposed transfer time
+        model.kv_gather.n_collectives = 0
+    calls0 = native.N_CALLS[0]
     t0 = time.perf_counter()
     run_steps(args.warmup, args.steps)
+    t_enqueued = time.perf_counter() - t0    # the host has ISSUED every launch of the timed steps (GPU still running)
     sync()
     elapsed = time.perf_counter() - t0
     record["on"] = False
+    abi_calls = native.N_CALLS[0] - calls0
+    comm = None
+    if world > 1:
+        waits = (model.kv_gather.timing or []) if model.kv_gather is not None else []   # cfg+sp at N=2: no K|V exchange at all
+        exposed_ms = sum(a.elapsed_time(b) for a, b in waits)
+        n_coll = model.kv_gather.n_collectives if model.kv_gather is not None else 0
+        tt = torch.tensor([exposed_ms, float(len(waits)), float(n_coll)], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        comm = {"rccl_ranks": world, "kv_exchange": args.kv_exchange, "sp_chunks": args.sp_chunks,
+                "kv_group_ranks": layout.sp_world,
+                "kv_exchanges_per_step_per_rank": tt[2].item() / args.steps,
+                "kv_bytes_sent_per_exchange_layer": 2 * 2 * plan.n_tok * cfg.dim if layout.sp_world > 1 else 0,
+                "exposed_kv_wait_ms_per_step": tt[0].item() / args.steps,      # max over ranks of the compute-stream stalls
+                "kv_chunk_waits_per_step": tt[1].item() / args.steps}
+        if model.kv_gather is not None:
+            model.kv_gather.timing = None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -242,6 +268,7 @@ def main():
         attn_flops = 4.0 * plan.n_tok * grid.S * cfg.dim        # per launch on this rank (4 S^2 d)
     attn_tflops = attn_flops / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
     f_step = 2.0 * dit_forward_flops(cfg, grid.S)
+    attn_peak = PEAK_BF16_TFLOPS if args.attn_dtype == "bf16" else PEAK_FP8_TFLOPS   # the dominant kernel's own MFMA peak
 
     traffic = None
     try:   # HBM bytes per self-attention launch, measured offline with rocprofv3 PMC passes (see profiles/)
@@ -274,6 +301,8 @@ def main():
                     f"cfg2 x sp{layout.sp_world} (cond / uncond forwards on two groups of {layout.sp_world} ranks; token-sequence shards and "
                     f"K/V all-gather in {args.sp_chunks} chunks inside a group; one velocity swap per step between the groups)"),
                 "wallclock_50_steps_s": 50.0 * elapsed / args.steps,
+                "c_abi_calls_per_forward": abi_calls / (args.steps * (1 if layout.mode == "cfg+sp" else 2)),
+                "host_enqueue_ms_per_step": 1e3 * t_enqueued / args.steps,
                 "algorithmic_pflop_per_step": f_step / 1e15,
                 "model_tflops_all_gpus": f_step * args.steps / elapsed / 1e12,
                 "frac_of_bf16_mfma_peak": f_step * args.steps / elapsed / 1e12 / (PEAK_BF16_TFLOPS * world),
@@ -281,12 +310,14 @@ def main():
             "roofline": {
                 "kernel": "att7::attn7_kernel (self-attention, K6)" if args.attn_dtype == "bf16" else
                           "att8::attn8_kernel + its quantise pre-pass (e4m3 self-attention, K6)",
-                "bound": "mfma", "achieved": attn_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": attn_tflops / PEAK_BF16_TFLOPS, "traffic": traffic,
+                "bound": "mfma", "achieved": attn_tflops, "peak": attn_peak, "unit": "TFLOP/s",
+                "frac": attn_tflops / attn_peak, "traffic": traffic,
                 "avg_launch_ms": attn_ms, "launches_timed": len(attn_events),
                 "algorithmic_flop_per_launch": attn_flops,
             },
         }
+        if comm is not None:
+            out["multi_gpu"] = comm
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or min(os.cpu_count() or 1, 32)  # >32 threads oversubscribes these GEMM sizes
             out["cpu_baseline"] = cpu_baseline(cfg, grid, threads)

@@ -88,7 +88,11 @@ def lib() -> ctypes.CDLL:
     return l
 
 
+N_CALLS = [0]   # C-ABI calls issued by this process (one call = one kernel launch, or a few); bench.py reports it
+
+
 def check(rc: int, what: str = "") -> None:
+    N_CALLS[0] += 1
     if rc != 0:
         msg = lib().icv_last_error()
         raise NativeError(f"{what or 'libicvideo'} failed (rc={rc}): {msg.decode() if msg else '?'}")

@@ -10,9 +10,10 @@ HBM layout, the step-invariant caches and the sequence-parallel schedule:
     x        f32  [n, d]        residual stream (fp32: 288 GB of HBM3E makes this free, and it
                                 removes the bf16 round-off random walk over 3 adds x L layers x 100 forwards)
     h        bf16 [n, d]        LN/modulate output -> GEMM A operand
-    qkv      bf16 [3, n, d]     q | k | v planes written by ONE fused QKV GEMM (split epilogue), so
-                                the K and V planes are contiguous all-gather send buffers
-    kv_full  bf16 [2, S, d]     gathered K, V (world > 1 only)
+    qkv      bf16 [3, n, d]     q | k | v planes written by ONE fused QKV GEMM (split epilogue)
+    kv_loc   bf16 [n, 2d]       world > 1: this shard's keys and values as ONE matrix (row = k(d) | v(d)) written by the
+                                K/V half of the QKV GEMM, so one collective per row-chunk moves both
+    kv_full  bf16 [S, 2d]       world > 1: the gathered rows of every rank (chunk-major, rank-major inside)
     att      bf16 [n, d]        attention output -> O-projection A operand
     ff       bf16 [n, ffn]      GELU(FFN1) output
     weights  bf16 [N, K]        torch Linear layout == the K-contiguous B operand of the MFMA GEMM
@@ -205,7 +206,7 @@ class WanDiT:
     GRAPH_MAX_TOKENS = 8192   # graphs="auto": only sizes whose forward is made of many short kernels (cfg #1: S = 2240)
 
     def prepare(self, grid: TokenGrid, plan: Optional[ShardPlan] = None, kv_gather=None, sp_chunks: int = 4,
-                group=None, graphs=False):
+                group=None, graphs=False, kv_exchange: Optional[str] = None):
         """Allocate the per-generation workspace for this token grid / shard.  ``group`` = the process group the
         K/V all-gather runs in (seqpar.ParallelLayout.sp_group; None = the default group).
         ``graphs``: replay each DiT forward (its ~25 launches x L layers) as ONE hipGraph instead of issuing the
@@ -260,29 +261,30 @@ class WanDiT:
         self.dual_stream = os.environ.get("ICV_DUAL_STREAM", "0") == "1" and self.plan.world == 1 and self._is_gpu()
         self._twin = None
         if self.plan.world > 1:
-            self.kv_full = a((2, S, d), BF16)                      # gathered K, V (chunk-major, rank-major inside)
+            self.kv_loc = a((n, 2 * d), BF16)                      # local k | v rows (one exchange moves both)
+            self.kv_full = a((S, 2 * d), BF16)                     # gathered rows (chunk-major, rank-major inside)
             self.sp_acc = a((n, d), F32)                           # carried O accumulator between key chunks
             self.sp_ml = a((n, cfg.num_heads, 2), F32)             # carried (running max, row sum)
             self.sp_bounds = chunk_bounds(n, sp_chunks)
-            self.kv_gather = kv_gather or KVGather(self.plan, group)
+            self.kv_gather = kv_gather or KVGather(self.plan, group, kv_exchange)
         else:
-            self.kv_full, self.kv_gather = None, None
+            self.kv_loc, self.kv_full, self.kv_gather = None, None, None
         return self
 
     def _is_gpu(self) -> bool:
         dev = getattr(self.ops, "device", None)
         return dev is not None and torch.device(dev).type == "cuda"
 
-    def _sp_start_gather(self, k, v):
-        """K13: enqueue the all-gather of every K/V row-chunk (RCCL runs them back to back on its own
+    def _sp_start_gather(self):
+        """K13: enqueue the exchange of every K|V row-chunk (RCCL runs them back to back on its own
         stream; chunk c = rows [r0, r1) of EVERY rank's shard, rank-major)."""
-        world, b = self.plan.world, self.sp_bounds
+        world, b, d = self.plan.world, self.sp_bounds, self.cfg.dim
         handles, bufs = [], []
         for c in range(len(b) - 1):
             r0, r1 = b[c], b[c + 1]
-            kf, vf = self.kv_full[0, world * r0: world * r1], self.kv_full[1, world * r0: world * r1]
-            bufs.append((kf, vf))
-            handles.append(self.kv_gather.start(k[r0:r1], v[r0:r1], kf, vf))
+            full = self.kv_full[world * r0: world * r1]
+            bufs.append((full[:, :d], full[:, d:]))            # strided views: the kernels take a row stride
+            handles.append(self.kv_gather.start(self.kv_loc[r0:r1], full))
         return handles, bufs
 
     def _sp_attention(self, q, handles, bufs, H, scale):
@@ -452,9 +454,9 @@ class WanDiT:
             h = self._norm(shift=sh1, scale=sc1, eps=eps)                                   # K3
             if plan.world > 1:
                 # K and V first, so their all-gather (K13) is already moving while Q is projected
-                self._mm(h, lw["wqkv"], lw["bqkv"], self.qkv[1:], EPI_BF16, rows=slice(d, 3 * d), nsplit=d)  # K4 (k, v)
-                ops.rmsnorm_rope(k, lw["nk"], eps=eps, rope=self.rope, tok0=plan.tok0)               # K5 (k)
-                handles, bufs = self._sp_start_gather(k, v)
+                self._mm(h, lw["wqkv"], lw["bqkv"], self.kv_loc, EPI_BF16, rows=slice(d, 3 * d))            # K4 (k | v rows)
+                ops.rmsnorm_rope(self.kv_loc[:, :d], lw["nk"], eps=eps, rope=self.rope, tok0=plan.tok0)      # K5 (k)
+                handles, bufs = self._sp_start_gather()
                 self._mm(h, lw["wqkv"], lw["bqkv"], q, EPI_BF16, rows=slice(0, d))                   # K4 (q)
                 ops.rmsnorm_rope(q, lw["nq"], eps=eps, rope=self.rope, tok0=plan.tok0)               # K5 (q)
                 self._sp_attention(q, handles, bufs, H, scale)                                       # K6

@@ -36,6 +36,15 @@ def _strip_prefix_group(state_dict: Dict[str, torch.Tensor], prefix: str) -> Dic
     return {k.replace(prefix, ""): v for k, v in state_dict.items() if k.startswith(prefix)}
 
 
+def _is_rank0() -> bool:
+    """Under a multi-rank launch every rank holds the full result; only one of them writes the mp4."""
+    try:
+        import torch.distributed as dist
+        return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+    except Exception:  # pragma: no cover
+        return True
+
+
 class WanVideoGenerator:
     """Buffer-conditioned Wan2.1 video generation (semantic + coordinate guidance buffers).
 
@@ -51,6 +60,16 @@ class WanVideoGenerator:
         self.device = device
         self.torch_dtype = torch_dtype
         self.buffer_channels = buffer_channels
+
+        # N-GPU mode behind the unchanged caller: ICV_WORLD=N starts N-1 persistent per-GPU workers that build the same
+        # generator (multigpu.py); they load their weights while this process loads its own
+        from . import multigpu
+        self._pool = None
+        world = multigpu.requested_world()
+        if world > 1:
+            self._pool = multigpu.WorkerPool(world, dict(
+                checkpoint_path=checkpoint_path, device=device, torch_dtype=torch_dtype, buffer_channels=buffer_channels,
+                enable_vram_management=enable_vram_management, use_wan_1pt3b=use_wan_1pt3b))
 
         model_id, shown = _BASE_MODELS[bool(use_wan_1pt3b)]
         print(f"Loading {shown} base model...")
@@ -68,6 +87,8 @@ class WanVideoGenerator:
             print("Enabling VRAM management...")
             self.pipe.enable_vram_management()
 
+        if self._pool is not None:
+            self._pool.wait_ready()
         print("✓ WanVideoGenerator initialization complete")
 
     # A2 ---------------------------------------------------------------------------------------
@@ -120,11 +141,14 @@ class WanVideoGenerator:
         coordinate_frames = self._ndarray_to_pil_list(coordinate_buffer)
 
         print("Executing video generation...")
+        if self._pool is not None:     # the other ranks run the same request on their token shards / CFG branch
+            self._pool.generate(semantic_buffer, coordinate_buffer,
+                                dict(prompt=prompt, negative_prompt=negative_prompt, seed=seed, tiled=tiled), self.pipe)
         video = self.pipe(prompt=prompt, negative_prompt=negative_prompt, semantic_buffer_video=semantic_frames,
                           coordinate_buffer_video=coordinate_frames, height=height, width=width,
                           num_frames=num_frames, seed=seed, tiled=tiled)
 
-        if output_path is not None:
+        if output_path is not None and _is_rank0():
             print(f"Saving video to: {output_path}")
             save_video(video, output_path, fps=fps, quality=quality)
             print("✓ Video saved")

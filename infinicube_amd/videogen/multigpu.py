@@ -1,0 +1,200 @@
+"""Multi-GPU generation behind the UNCHANGED single-process caller.
+
+InfiniCube's stage 2 builds ONE ``WanVideoGenerator`` in its own process with the literal ``device="cuda:0"`` and never
+touches ``torch.distributed`` [R infinicube/inference/guidance_buffer_generation.py:755-782]; launching that script N
+times under ``torch.distributed.run`` would render the voxel world N times and is a change of the caller's contract.
+So the N-GPU mode lives behind the constructor: with ``ICV_WORLD=N`` (or ``auto``) in the environment the caller's
+process becomes rank 0 on GPU 0 and ``WorkerPool`` starts N-1 persistent worker processes (one per further GPU, this
+module's ``__main__``), each of which builds the same generator on ``cuda:<rank>``, joins one process group
+(``nccl`` = RCCL over xGMI; the K/V exchange and the velocity swap of seqpar.py run in it) and then serves
+``generate`` commands.  Per call rank 0 broadcasts the request (prompt, seed, sampling settings and the two uint8
+buffers, over a gloo control group on the host), every rank runs ``WanVideoPipeline.__call__`` on its token shard /
+CFG branch, and only rank 0 decodes the latent, returns the frames and writes the mp4.
+
+Not a scheduler or a serving layer: one generator, one request at a time, exactly the reference's usage.
+"""
+from __future__ import annotations
+
+import atexit
+import datetime
+import importlib
+import os
+import pickle
+import socket
+import subprocess
+import sys
+import tempfile
+import time
+from typing import Optional
+
+import numpy as np
+import torch
+
+# pipeline attributes rank 0 may have changed since construction; sent with every request so the ranks cannot drift
+_PIPE_SETTINGS = ("num_inference_steps", "cfg_scale", "sigma_shift", "parallelism", "sp_chunks", "kv_exchange")
+
+
+def requested_world() -> int:
+    """ICV_WORLD = N | auto (= every visible GPU).  1 inside a worker, when unset, or when the process already is a
+    rank of somebody else's job (torch.distributed initialised / launched by torch.distributed.run)."""
+    v = os.environ.get("ICV_WORLD", "").strip().lower()
+    if not v or os.environ.get("ICV_WORKER_RANK") is not None:
+        return 1
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return 1
+    if v == "auto":
+        return max(1, torch.cuda.device_count())
+    n = int(v)
+    if n < 1:
+        raise ValueError(f"ICV_WORLD must be a positive integer or 'auto', got {v!r}")
+    return n
+
+
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _resolve(spec: str):
+    mod, _, fn = spec.partition(":")
+    return getattr(importlib.import_module(mod), fn)
+
+
+class WorkerPool:
+    """Rank 0's handle on the N-1 worker processes and the process group they share."""
+
+    def __init__(self, world: int, ctor_kwargs: dict, backend: Optional[str] = None):
+        import torch.distributed as dist
+        self.world, self.dist = world, dist
+        self.backend = backend or os.environ.get("ICV_DIST_BACKEND", "nccl")
+        self.timeout_s = float(os.environ.get("ICV_WORLD_TIMEOUT_S", "3600"))
+        port = _free_port()
+        init_method = f"tcp://127.0.0.1:{port}"
+        self._dir = tempfile.mkdtemp(prefix="icv_world_")
+        spec = dict(ctor=ctor_kwargs, backend=self.backend, init_method=init_method, timeout_s=self.timeout_s,
+                    factory=os.environ.get("ICV_WORKER_FACTORY"))
+        spec_path = os.path.join(self._dir, "spec.pkl")
+        with open(spec_path, "wb") as f:
+            pickle.dump(spec, f)
+        self.procs = []
+        for r in range(1, world):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), ICV_WORKER_RANK=str(r),
+                       ICV_WORKER_SPEC=spec_path, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            env.pop("ICV_WORLD", None)
+            log = open(os.path.join(self._dir, f"worker{r}.log"), "wb")
+            self.procs.append((subprocess.Popen([sys.executable, "-m", "infinicube_amd.videogen.multigpu"], env=env,
+                                                stdout=log, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL), log))
+        # this process is rank 0 on GPU 0 ("cuda:0" already means that; LOCAL_RANK makes it explicit for resolve_device)
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        try:
+            dist.init_process_group(self.backend, init_method=init_method, rank=0, world_size=world,
+                                    timeout=datetime.timedelta(seconds=self.timeout_s))
+            self.ctrl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=self.timeout_s))
+        except Exception:
+            self._kill()
+            raise
+        self._closed = False
+        atexit.register(self.close)
+        print(f"[icvideo] {world} ranks: this process + {world - 1} workers (backend {self.backend}; logs in {self._dir})", file=sys.stderr)
+
+    # -- rank 0 side -------------------------------------------------------------------------------
+    def _check_alive(self):
+        for i, (p, _) in enumerate(self.procs):
+            rc = p.poll()
+            if rc is not None:
+                tail = ""
+                try:
+                    with open(os.path.join(self._dir, f"worker{i + 1}.log"), "rb") as f:
+                        tail = f.read()[-2000:].decode(errors="replace")
+                except OSError:
+                    pass
+                raise RuntimeError(f"multi-GPU worker rank {i + 1} exited with code {rc}:\n{tail}")
+
+    def wait_ready(self):
+        """Every rank has built its generator (weights resident)."""
+        self._check_alive()
+        self.dist.barrier(group=self.ctrl)
+
+    def generate(self, semantic: np.ndarray, coordinate: np.ndarray, call_kwargs: dict, pipe) -> None:
+        """Hand one request to the workers; the caller then runs its own share through ``pipe(...)``."""
+        self._check_alive()
+        msg = dict(cmd="generate", shape=tuple(semantic.shape), call=call_kwargs,
+                   settings={k: getattr(pipe, k) for k in _PIPE_SETTINGS if hasattr(pipe, k)})
+        self.dist.broadcast_object_list([msg], src=0, group=self.ctrl)
+        for arr in (semantic, coordinate):
+            self.dist.broadcast(torch.from_numpy(np.ascontiguousarray(arr)), src=0, group=self.ctrl)
+
+    def close(self):
+        if getattr(self, "_closed", True):
+            return
+        self._closed = True
+        try:
+            if all(p.poll() is None for p, _ in self.procs):
+                self.dist.broadcast_object_list([dict(cmd="exit")], src=0, group=self.ctrl)
+            deadline = time.time() + 30
+            for p, _ in self.procs:
+                try:
+                    p.wait(timeout=max(0.1, deadline - time.time()))
+                except subprocess.TimeoutExpired:
+                    pass
+        finally:
+            self._kill()
+            try:
+                if self.dist.is_initialized():
+                    self.dist.destroy_process_group()
+            except Exception:
+                pass
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                os.environ.pop(k, None)
+
+    def _kill(self):
+        for p, log in self.procs:
+            if p.poll() is None:
+                p.kill()          # exactly the PIDs this pool started
+                p.wait()
+            log.close()
+
+
+# -- worker side ---------------------------------------------------------------------------------------
+def worker_main() -> int:
+    import torch.distributed as dist
+    with open(os.environ["ICV_WORKER_SPEC"], "rb") as f:
+        spec = pickle.load(f)
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    to = datetime.timedelta(seconds=spec["timeout_s"])
+    dist.init_process_group(spec["backend"], init_method=spec["init_method"], rank=rank, world_size=world, timeout=to)
+    ctrl = dist.new_group(backend="gloo", timeout=to)
+    from .inference import WanVideoGenerator
+    factory = _resolve(spec["factory"]) if spec.get("factory") else None
+    gen = WanVideoGenerator(**spec["ctor"], pipeline_factory=factory)   # device "cuda:0" resolves to cuda:LOCAL_RANK
+    dist.barrier(group=ctrl)
+    print(f"[worker {rank}] ready", flush=True)
+    while True:
+        box = [None]
+        dist.broadcast_object_list(box, src=0, group=ctrl)
+        msg = box[0]
+        if msg["cmd"] == "exit":
+            break
+        bufs = []
+        for _ in range(2):
+            t = torch.empty(msg["shape"], dtype=torch.uint8)
+            dist.broadcast(t, src=0, group=ctrl)
+            bufs.append(t.numpy())
+        for k, v in msg["settings"].items():
+            setattr(gen.pipe, k, v)
+        n, h, w, _ = msg["shape"]
+        c = msg["call"]
+        gen.pipe(prompt=c["prompt"], negative_prompt=c["negative_prompt"], semantic_buffer_video=gen._ndarray_to_pil_list(bufs[0]),
+                 coordinate_buffer_video=gen._ndarray_to_pil_list(bufs[1]), height=h, width=w, num_frames=n, seed=c["seed"],
+                 tiled=c["tiled"], return_latents=True)      # rank 0 alone decodes, returns frames and writes the mp4
+        print(f"[worker {rank}] request done", flush=True)
+    dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(worker_main())

@@ -164,7 +164,9 @@ class WanVideoPipeline:
         self.gemm_dtype = "fp8" if torch_dtype == torch.float8_e4m3fn else "bf16"
         self.attn_dtype = self.gemm_dtype     # the fp8 mode also runs self-attention in e4m3 (no measurable accuracy cost)
         # multi-GPU layout when torch.distributed is initialised (seqpar.ParallelLayout): "auto" | "sp" | "cfg+sp"
-        self.parallelism = "auto"
+        self.parallelism = os.environ.get("ICV_PARALLELISM", "auto")
+        self.sp_chunks = int(os.environ.get("ICV_SP_CHUNKS", "4"))       # K/V exchange chunks per layer (overlap depth)
+        self.kv_exchange = os.environ.get("ICV_KV_EXCHANGE") or None     # "allgather" | "p2p" (seqpar.KVGather)
         self._layouts = {}
         self.torch_dtype = torch_dtype
         self.dit = dit
@@ -223,9 +225,22 @@ class WanVideoPipeline:
     def _get_ops(self):
         if self._ops is None:
             from .ops import HipOps
-            dev = "cuda:0" if str(self.device) == "cuda" else self.device
-            self._ops = HipOps(dev)   # raises loudly without GPU / native library: no fallback
+            self._ops = HipOps(self.resolve_device(self.device))   # raises loudly without GPU / native library: no fallback
         return self._ops
+
+    @staticmethod
+    def resolve_device(device) -> str:
+        """One process drives one GPU.  The reference's caller passes the literal ``"cuda:0"``
+        [R infinicube/inference/guidance_buffer_generation.py:761]; when this process is one rank of a multi-GPU job
+        (LOCAL_RANK set by torch.distributed.run or by multigpu.WorkerPool) that literal means "my GPU", i.e.
+        ``cuda:LOCAL_RANK`` - otherwise every rank would land on GPU 0."""
+        dev = str(device)
+        if not dev.startswith("cuda"):
+            return dev
+        lr = os.environ.get("LOCAL_RANK")
+        if lr is not None and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            return f"cuda:{int(lr)}"
+        return "cuda:0" if dev == "cuda" else dev
 
     def _get_engine(self):
         from .dit import WanDiT
@@ -282,7 +297,7 @@ class WanVideoPipeline:
             self._layouts[lkey] = ParallelLayout.make(world, rank, self.parallelism, use_cfg=cfg_scale != 1.0)
         layout = self._layouts[lkey]
         plan = layout.shard_plan(grid.S)
-        engine.prepare(grid, plan, group=layout.sp_group)
+        engine.prepare(grid, plan, group=layout.sp_group, sp_chunks=self.sp_chunks, kv_exchange=self.kv_exchange)
         self.scheduler = FlowMatchScheduler(num_inference_steps, sigma_shift)
         # i2v (BASELINE.json config #5): CLIP tokens + conditioning latent of the first frame, once per call
         i2v = engine.cfg.has_image_input

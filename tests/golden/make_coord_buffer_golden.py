@@ -98,6 +98,31 @@ def main():
         out[f"{name}_seed"] = np.array([1234 + seed])
         out[f"{name}_coord"] = res.numpy().astype(np.float32)
         out[f"{name}_coord_u8"] = (res * 255).cpu().numpy().astype(np.uint8)     # the caller's conversion
+        # The handful of numbers the reference derives on the HOST before its per-pixel work (K^-1, pose_0^-1 pose_n,
+        # the two quantiles of the sample), by the same torch calls in the same order.  LAPACK / BLAS results differ in
+        # the last bit between CPU models, so the per-pixel kernels are pinned bit for bit from THESE values
+        # (tests/test_buffers.py::test_hip_kernels_bit_exact_from_reference_host_values), whatever host they run beside.
+        tp, td = torch.from_numpy(poses), torch.from_numpy(depth)
+        k = torch.tensor([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], dtype=torch.float32)
+        to0 = torch.einsum("ij,bjk->bik", torch.inverse(tp[0]), tp)
+        du = sys.modules["infinicube.utils.depth_utils"]
+        pts = du.unproject_depth_torch(td, to0, k[None].repeat(n, 1, 1))
+        pts[td == 0] = 1e7
+        flat = pts.reshape(-1, 3)
+        valid = flat[flat[:, 2] < 1e6]
+        mins, ranges = np.zeros(3, np.float32), np.ones(3, np.float32)
+        if valid.shape[0] > 0:
+            torch.manual_seed(1234 + seed)
+            smp = valid[torch.randperm(valid.shape[0])[:100000]]
+            lo, hi = torch.quantile(smp, 0.05, dim=0), torch.quantile(smp, 0.95, dim=0)
+            mins, ranges = lo.numpy(), torch.clamp(hi - lo, min=1e-7).numpy()
+            chk = (torch.clamp((pts - lo) / torch.clamp(hi - lo, min=1e-7) * 2.0 - 1.0, -1.0, 1.0) + 1.0) / 2.0
+            chk[td == 0] = 1.0
+            assert torch.equal(chk, res), "host-value replay does not reproduce the reference output"
+        out[f"{name}_kinv"] = torch.inverse(k).numpy()
+        out[f"{name}_to_cam0"] = to0.numpy()
+        out[f"{name}_mins"], out[f"{name}_ranges"] = mins.astype(np.float32), ranges.astype(np.float32)
+        out[f"{name}_has_valid"] = np.array([int(valid.shape[0] > 0)])
         print(name, res.shape, float(res.min()), float(res.max()), "valid", int((depth != 0).sum()))
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT) // 1024, "KiB")

@@ -1,0 +1,20 @@
+"""Pipeline factory shared by the rank-0 test process and the worker processes of tests/test_multigpu_workers.py
+(resolved in the workers through ICV_WORKER_FACTORY="mgpu_factory:factory"): the product's host code with the TEST-ONLY
+oracle operator set and the stand-in encoders, on CPU."""
+import torch
+
+from infinicube_amd.videogen import synthetic as syn
+from infinicube_amd.videogen.config import TokenGrid, preset
+from infinicube_amd.videogen.pipeline import DiTHolder, WanVideoPipeline
+from infinicube_amd.videogen.standins import HashTextEncoder, PoolVAE
+from oracle_ops import OracleOps
+
+CFG, GRID = preset("tiny"), TokenGrid(9, 64, 96)
+
+
+def factory(torch_dtype, device, model_configs):
+    torch.set_num_threads(2)
+    pipe = WanVideoPipeline(device, torch_dtype, DiTHolder(syn.make_dit_state_dict(CFG), CFG), HashTextEncoder(CFG), PoolVAE(),
+                            ops=OracleOps())
+    pipe.num_inference_steps = 2
+    return pipe

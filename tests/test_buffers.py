@@ -45,16 +45,55 @@ def test_oracle_unproject_identity_pose():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", CASES)
+def test_hip_kernels_bit_exact_from_reference_host_values(name):
+    """The per-pixel byte work, pinned bit for bit: the three HIP kernels (through the C ABI) fed the few numbers the
+    reference derives on the host (K^-1, pose_0^-1 pose_n, the sample quantiles - stored in the golden file by the
+    generator script from the reference's own torch calls) must reproduce the reference's float32 buffer AND the
+    caller's uint8 buffer exactly.  (Those host numbers come from LAPACK / BLAS and differ in the last bit between CPU
+    models - this test is independent of the host it runs beside; the function-level test below is not.)"""
+    import ctypes
+    from infinicube_amd import native
+    lib = native.lib()
+    depth = torch.from_numpy(G[f"{name}_depth"]).to("cuda:0")
+    n, h, w = depth.shape
+    cf = lambda a: (ctypes.c_float * a.size)(*[float(x) for x in a.reshape(-1)])   # noqa: E731
+    kinv, tf = cf(G[f"{name}_kinv"]), torch.from_numpy(G[f"{name}_to_cam0"]).contiguous().to("cuda:0")
+    mins, ranges, hv = cf(G[f"{name}_mins"]), cf(G[f"{name}_ranges"]), int(G[f"{name}_has_valid"][0])
+    of = torch.empty((n, h, w, 3), dtype=torch.float32, device="cuda:0")
+    ou = torch.empty((n, h, w, 3), dtype=torch.uint8, device="cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    native.check(lib.icv_coord_normalize(depth.data_ptr(), kinv, tf.data_ptr(), n, h, w, mins, ranges, hv, of.data_ptr(), ou.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert np.array_equal(of.cpu().numpy(), G[f"{name}_coord"]), "float32 coordinate buffer differs from the reference's"
+    assert np.array_equal(ou.cpu().numpy(), G[f"{name}_coord_u8"]), "uint8 coordinate buffer differs from the reference's"
+    # the valid mask and the gathered sample points are the reference's too (flattened order)
+    mask = torch.empty((n * h * w,), dtype=torch.uint8, device="cuda:0")
+    native.check(lib.icv_coord_valid_mask(depth.data_ptr(), kinv, tf.data_ptr(), n, h, w, mask.data_ptr(), st))
+    assert int(mask.sum()) == int((G[f"{name}_depth"] != 0).sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
 def test_hip_matches_reference_golden(name):
     from infinicube.utils.buffer_utils import generate_coordinate_buffer_from_memory_global_norm as gen
     depth, poses, cam, seed, want, want_u8 = _case(name)
+    # does THIS host's LAPACK reproduce the host-side numbers of the machine the golden was made on?
+    k = cam.get_intrinsics_matrix()
+    same_host_math = (np.array_equal(torch.inverse(k).numpy(), G[f"{name}_kinv"]) and np.array_equal(
+        torch.einsum("ij,bjk->bik", torch.inverse(poses[0]), poses).numpy(), G[f"{name}_to_cam0"]))
     torch.manual_seed(seed)
     got = gen(depth, cam, poses, percentile=0.05).cpu()
     assert got.shape == want.shape and got.dtype == torch.float32
-    assert torch.equal(got, want), f"coordinate buffer differs from the reference's output: max {float((got - want).abs().max())}"
     torch.manual_seed(seed)
     u8 = gen(depth, cam, poses, percentile=0.05, return_uint8=True).cpu().numpy()
-    assert np.array_equal(u8, want_u8), "the uint8 coordinate buffer must match the reference byte for byte"
+    if same_host_math:
+        assert torch.equal(got, want), f"coordinate buffer differs from the reference's output: max {float((got - want).abs().max())}"
+        assert np.array_equal(u8, want_u8), "the uint8 coordinate buffer must match the reference byte for byte"
+    else:   # another CPU model: K^-1 / pose products differ in the last bit, so does everything downstream
+        print(f"[{name}] host inverse/einsum differ from the golden's host in the last bit: comparing within 4 ulp")
+        assert float((got - want).abs().max()) <= 4 * 2.0 ** -24
+        diff = np.abs(u8.astype(np.int16) - want_u8.astype(np.int16))
+        assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
 
 
 @pytest.mark.gpu

@@ -232,7 +232,9 @@ def test_sequence_parallel_path_on_one_gpu(hip_ops, chunks, model, gemm_dtype):
             def __init__(self):
                 self.layer, self.calls, self.r0 = 0, 0, 0
 
-            def start(self, k_rows, v_rows, k_out, v_out):
+            def start(self, rows, out):     # rows [m, 2d] = k | v of this chunk, out [world*m, 2d]
+                dd = rows.shape[1] // 2
+                k_rows, v_rows, k_out, v_out = rows[:, :dd], rows[:, dd:], out[:, :dd], out[:, dd:]
                 kf, vf = rec[self.layer]
                 m = k_rows.shape[0]
                 r0 = self.r0
@@ -302,13 +304,13 @@ def test_sequence_parallel_gather_on_rccl_stream(hip_ops):
             def __init__(self):
                 self.layer, self.calls, self.r0 = 0, 0, 0
 
-            def start(self, k_rows, v_rows, k_out, v_out):
+            def start(self, rows, out):     # rows [m, 2d] = k | v of this chunk, out [world*m, 2d]
+                dd = rows.shape[1] // 2
                 kf, vf = rec[self.layer]
-                m, r0, peer = k_rows.shape[0], self.r0, 1 - r
-                k_out[peer * m:(peer + 1) * m].copy_(kf[peer * n + r0: peer * n + r0 + m])
-                v_out[peer * m:(peer + 1) * m].copy_(vf[peer * n + r0: peer * n + r0 + m])
-                h = (dist.all_gather_into_tensor(k_out[r * m:(r + 1) * m], k_rows, async_op=True),
-                     dist.all_gather_into_tensor(v_out[r * m:(r + 1) * m], v_rows, async_op=True))
+                m, r0, peer = rows.shape[0], self.r0, 1 - r
+                out[peer * m:(peer + 1) * m, :dd].copy_(kf[peer * n + r0: peer * n + r0 + m])
+                out[peer * m:(peer + 1) * m, dd:].copy_(vf[peer * n + r0: peer * n + r0 + m])
+                h = (dist.all_gather_into_tensor(out[r * m:(r + 1) * m], rows, async_op=True),)
                 self.calls += 1
                 self.r0 += m
                 if self.calls % chunks == 0:

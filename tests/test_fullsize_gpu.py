@@ -165,7 +165,7 @@ def test_layer_14b_full_S(hip_ops):
     """Config #3's layer: d = 5120, ffn = 13824, 40 heads, S = 37 440 — every kernel of a block (K1, K3-K10) at the
     benchmarked shape, checked on tokens [17000, 19048) (mid-grid RoPE offsets; keys / values from all tokens)."""
     rel_in, rel, cos = _run_block(hip_ops, "14b", GRID_480P, slice(17000, 17000 + 2048))
-    assert rel_in <= 1e-3, f"patch + buffer embed at 14B width: rel-L2 {rel_in}"
+    assert rel_in <= 2.0 ** -8, f"patch + buffer embed at 14B width: rel-L2 {rel_in}"   # bf16 patch operand: 2^-9 relative rounding
     assert cos >= 0.999 and rel <= 2e-2, f"14B block at S=37440: rel-L2 {rel}, cosine {cos}"
 
 
@@ -177,11 +177,11 @@ def test_layer_14b_i2v_720p(hip_ops, mode):
     sl = slice(40000, 40000 + 1024)
     if mode == "bf16":
         rel_in, rel, cos = _run_block(hip_ops, "14b-i2v", GRID_720P, sl)
-        assert rel_in <= 1e-3
+        assert rel_in <= 2.0 ** -8
         assert cos >= 0.999 and rel <= 2e-2, f"14B i2v block at S=86400: rel-L2 {rel}, cosine {cos}"
     else:
         rel_in, rel, cos = _run_block(hip_ops, "14b-i2v", GRID_720P, sl, gemm_dtype="fp8", attn_dtype="fp8")
-        assert rel_in <= 1e-3
+        assert rel_in <= 2.0 ** -8
         assert cos >= 0.998 and rel <= 6e-2, f"14B i2v fp8 block at S=86400: rel-L2 {rel}, cosine {cos}"
 
 

@@ -174,7 +174,9 @@ def test_inprocess_two_shards_equal_unsharded(chunks, model, gemm_dtype):
             def __init__(self):
                 self.layer, self.calls, self.r0 = 0, 0, 0
 
-            def start(self, k_rows, v_rows, k_out, v_out):
+            def start(self, rows, out):     # rows [m, 2d] = k | v of this chunk, out [world*m, 2d]
+                dd = rows.shape[1] // 2
+                k_rows, v_rows, k_out, v_out = rows[:, :dd], rows[:, dd:], out[:, :dd], out[:, dd:]
                 kf, vf = rec["kv"][self.layer]
                 m, r0 = k_rows.shape[0], self.r0
                 # this chunk = rows [r0, r0 + m) of the local shard (RoPE offsets, shard indexing).  CPU GEMM blocking
@@ -204,7 +206,7 @@ def test_inprocess_two_shards_equal_unsharded(chunks, model, gemm_dtype):
     assert float((got - want).norm() / want.norm()) < (6e-2 if attn_dtype == "fp8" else 2e-3)
 
 
-def _sp_worker(rank, world, port, q):
+def _sp_worker(rank, world, port, q, kv_exchange="allgather"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -212,8 +214,8 @@ def _sp_worker(rank, world, port, q):
         torch.set_num_threads(2)
         sd, bsd, noise, c1, c2, bl = _inputs()
         plan = ShardPlan.make(GRID.S, world, rank)
-        m = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID, plan)
-        assert isinstance(m.kv_gather, KVGather)
+        m = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID, plan, kv_exchange=kv_exchange)
+        assert isinstance(m.kv_gather, KVGather) and m.kv_gather.mode == kv_exchange
         lat = noise.clone()
         m.denoise(lat, m.encode_context(c1), m.encode_context(c2), m.embed_buffers(bl), FlowMatchScheduler(3), 5.0)
         lat = gather_latent(lat, plan, GRID)
@@ -222,15 +224,18 @@ def _sp_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_gloo_world2_sequence_parallel_equals_single():
+@pytest.mark.parametrize("kv_exchange", ["allgather", "p2p"])
+def test_gloo_world2_sequence_parallel_equals_single(kv_exchange):
+    """Token-sequence parallel denoise loop over two real processes; the K|V rows travel by all-gather or by the
+    direct send/recv-to-every-peer schedule (seqpar.KVGather mode "p2p")."""
     sd, bsd, noise, c1, c2, bl = _inputs()
     single = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID)
     ref = noise.clone()
     single.denoise(ref, single.encode_context(c1), single.encode_context(c2), single.embed_buffers(bl), FlowMatchScheduler(3), 5.0)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_sp_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() + 13 * len(kv_exchange)) % 2000
+    procs = [ctx.Process(target=_sp_worker, args=(r, 2, port, q, kv_exchange)) for r in range(2)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=300) for _ in range(2))
@@ -258,7 +263,7 @@ def test_parallel_layout_arithmetic():
         ParallelLayout.make(2, 0, "tp")
 
 
-def _layout_worker(rank, world, port, q, mode):
+def _layout_worker(rank, world, port, q, mode, kv_exchange="allgather"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -267,7 +272,7 @@ def _layout_worker(rank, world, port, q, mode):
         sd, bsd, noise, c1, c2, bl = _inputs()
         lay = ParallelLayout.make(world, rank, mode)
         plan = lay.shard_plan(GRID.S)
-        m = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID, plan, group=lay.sp_group)
+        m = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID, plan, group=lay.sp_group, kv_exchange=kv_exchange)
         lat = noise.clone()
         if lay.mode == "cfg+sp":
             m.denoise(lat, m.encode_context(c1) if lay.branch == 0 else None, m.encode_context(c2) if lay.branch == 1 else None,
@@ -280,8 +285,9 @@ def _layout_worker(rank, world, port, q, mode):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "cfg+sp"), (4, "cfg+sp")])
-def test_gloo_cfg_branch_parallel_equals_single(world, mode):
+@pytest.mark.parametrize("world,mode,kv_exchange", [(2, "cfg+sp", "allgather"), (4, "cfg+sp", "allgather"), (4, "cfg+sp", "p2p"),
+                                                   (3, "sp", "p2p")])
+def test_gloo_cfg_branch_parallel_equals_single(world, mode, kv_exchange):
     """cfg+sp layout over real processes (gloo): world 2 = one rank per CFG branch and no K/V exchange; world 4 =
     two branch groups x two token shards (group-local K/V all-gather + the per-step velocity swap)."""
     sd, bsd, noise, c1, c2, bl = _inputs()
@@ -290,8 +296,8 @@ def test_gloo_cfg_branch_parallel_equals_single(world, mode):
     single.denoise(ref, single.encode_context(c1), single.encode_context(c2), single.embed_buffers(bl), FlowMatchScheduler(3), 5.0)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() + 7 * world) % 2000
-    procs = [ctx.Process(target=_layout_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    port = 31500 + (os.getpid() + 7 * world + 101 * len(kv_exchange)) % 2000
+    procs = [ctx.Process(target=_layout_worker, args=(r, world, port, q, mode, kv_exchange)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=600) for _ in range(world))
@@ -300,7 +306,7 @@ def test_gloo_cfg_branch_parallel_equals_single(world, mode):
         assert p.exitcode == 0
     for r in range(1, world):
         assert torch.equal(got[0], got[r]), f"rank {r} ended with a different latent than rank 0"
-    if world == 2:      # no sharding at all: per-token math identical to the single-process run
+    if world == 2 and mode == "cfg+sp":      # no sharding at all: per-token math identical to the single-process run
         assert float((got[0] - ref).norm() / ref.norm()) < 1e-5
     assert float((got[0] - ref).norm() / ref.norm()) < 2e-3 and R.psnr(got[0], ref) > 55.0
     with pytest.raises(ValueError, match="exactly one"):

@@ -1,0 +1,95 @@
+"""ICV_WORLD=N: the unchanged single-process caller [R infinicube/inference/guidance_buffer_generation.py:755-782]
+gets N ranks from inside the constructor (multigpu.WorkerPool).  Real processes over gloo on CPU; the whole path goes
+through WanVideoGenerator.generate -> WanVideoPipeline.__call__ on every rank."""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+from safetensors.torch import save_file
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _checkpoint(tmp_path):
+    import mgpu_factory as F
+    from infinicube_amd.videogen import synthetic as syn
+    bsd = syn.make_buffer_embedder_state_dict(F.CFG)
+    path = str(tmp_path / "step-1.safetensors")
+    save_file({"buffer_embedder." + k: v for k, v in bsd.items()}, path)
+    return path
+
+
+def _run(path, tmp_path, out_name):
+    import mgpu_factory as F
+    from infinicube.videogen import WanVideoGenerator
+    from infinicube_amd.videogen import synthetic as syn
+    sem, co = syn.make_dummy_buffers(F.GRID)
+    co[:, :, : F.GRID.width // 2] //= 2
+    out = str(tmp_path / out_name)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        g = WanVideoGenerator(path, device="cpu", use_wan_1pt3b=True, pipeline_factory=F.factory)
+        frames = g.generate(sem, co, seed=3, output_path=out)
+        frames2 = g.generate(sem, co, seed=4)
+    return g, np.stack([np.asarray(f) for f in frames]), np.stack([np.asarray(f) for f in frames2]), out, buf.getvalue()
+
+
+@pytest.mark.parametrize("world,parallelism,kv_exchange", [(2, "auto", "allgather"), (3, "sp", "p2p")])
+def test_generator_spawns_workers_and_matches_single_process(tmp_path, monkeypatch, world, parallelism, kv_exchange):
+    path = _checkpoint(tmp_path)
+    _, ref1, ref2, out_single, log_single = _run(path, tmp_path, "single.mp4")
+    assert os.path.getsize(out_single) > 0
+    monkeypatch.setenv("ICV_WORLD", str(world))
+    monkeypatch.setenv("ICV_DIST_BACKEND", "gloo")
+    monkeypatch.setenv("ICV_WORKER_FACTORY", "mgpu_factory:factory")
+    monkeypatch.setenv("ICV_PARALLELISM", parallelism)
+    monkeypatch.setenv("ICV_KV_EXCHANGE", kv_exchange)
+    monkeypatch.setenv("ICV_WORLD_TIMEOUT_S", "300")
+    monkeypatch.setenv("PYTHONPATH", os.pathsep.join([os.path.dirname(HERE), HERE, os.environ.get("PYTHONPATH", "")]))
+    g = None
+    try:
+        g, got1, got2, out_multi, log_multi = _run(path, tmp_path, "multi.mp4")
+        import torch.distributed as dist
+        assert dist.is_initialized() and dist.get_world_size() == world and g._pool is not None
+        assert log_multi == log_single.replace("single.mp4", "multi.mp4"), "the caller-visible progress lines must not change"
+        assert os.path.getsize(out_multi) > 0
+        # sharded attention reorders fp32 sums (and bf16 storage roundings can flip): frames agree to rounding
+        for a, b in ((ref1, got1), (ref2, got2)):
+            assert a.shape == b.shape
+            d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+            assert d.max() <= 2 and (d > 0).mean() < 0.02, f"N-rank frames differ from the single-process frames: max {d.max()}, {100 * (d > 0).mean():.2f} % pixels"
+        assert not np.array_equal(got1, got2), "the seed of the second request must reach every rank"
+    finally:
+        if g is not None and g._pool is not None:
+            g._pool.close()
+    import torch.distributed as dist
+    assert not dist.is_initialized()
+
+
+def test_requested_world_parsing(monkeypatch):
+    from infinicube_amd.videogen import multigpu
+    monkeypatch.delenv("ICV_WORLD", raising=False)
+    assert multigpu.requested_world() == 1
+    monkeypatch.setenv("ICV_WORLD", "4")
+    assert multigpu.requested_world() == 4
+    monkeypatch.setenv("ICV_WORKER_RANK", "2")       # inside a worker: never recurse
+    assert multigpu.requested_world() == 1
+    monkeypatch.delenv("ICV_WORKER_RANK")
+    monkeypatch.setenv("ICV_WORLD", "0")
+    with pytest.raises(ValueError):
+        multigpu.requested_world()
+
+
+def test_device_literal_maps_to_local_rank(monkeypatch):
+    from infinicube_amd.videogen.pipeline import WanVideoPipeline as P
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert P.resolve_device("cuda:0") == "cuda:0" and P.resolve_device("cuda") == "cuda:0" and P.resolve_device("cpu") == "cpu"
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    assert P.resolve_device("cuda:0") == "cuda:0"        # LOCAL_RANK alone (world 1) changes nothing
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    assert P.resolve_device("cuda:0") == "cuda:5" and P.resolve_device("cuda") == "cuda:5" and P.resolve_device("cpu") == "cpu"
