@@ -169,10 +169,13 @@ int icv_patchify(const float* latent, int64_t C, int64_t T, int64_t H8, int64_t 
 /* ---- K11 tail + K12: unpatchify + CFG combine + Euler step, fused -------------------------
  * For local tokens r in [0, n_tok): v = hu + cfg_scale * (hc - hu) (hu may be NULL -> v = hc);
  * latent[c, f, 2hp+y, 2wp+z] += v[r, (y*2+z)*C + c] * dsigma.   hc/hu f32 [n_tok, 4*C] (ldh).
- * If vel_out != NULL the combined velocity is also scattered there (same layout as latent). */
+ * If vel_out != NULL the combined velocity is also scattered there (same layout as latent).
+ * round_bf16 != 0 ("reference rounding"): every intermediate a torch_dtype=bf16 pipeline materialises — both model
+ * outputs, (hc - hu), cfg * (.), hu + (.), v * dsigma and the updated latent — is rounded to bf16 (values stay in
+ * f32 storage); 0 = exact f32 arithmetic (default). */
 int icv_unpatchify_cfg_euler(float* latent, float* vel_out, const float* hc, const float* hu,
                              int64_t ldh, float cfg_scale, float dsigma, int64_t C, int64_t T,
-                             int64_t H8, int64_t W8, int64_t tok0, int64_t n_tok, void* stream);
+                             int64_t H8, int64_t W8, int64_t tok0, int64_t n_tok, int round_bf16, void* stream);
 
 /* ---- coordinate guidance buffer (producer of the hot path's input) ---------------
  * Replaces `generate_coordinate_buffer_from_memory_global_norm` [R infinicube/utils/buffer_utils.py:180-265]
@@ -205,6 +208,13 @@ int icv_semantic_to_color(const int* semantics, int64_t n, const float* class_rg
                           float* out_f32, unsigned char* out_u8, void* stream);
 int icv_instance_overlay_u8(const unsigned char* semantics_rgb, const int* instance, int64_t n,
                             const unsigned char* instance_rgb_lut65536, unsigned char* out, void* stream);
+
+/* ---- depth wire format ----------------------------------------------------------
+ * icv_depth_to_u16 replaces `(depth_np * 100).astype(np.uint16)`, the payload of every
+ * `NNNNNN.voxel_depth_100.front.png` member of `voxel_depth_100_<res>_front.tar`
+ * [R infinicube/inference/guidance_buffer_generation.py:668-672]: out[i] = (uint16)(int64)(depth[i] * scale),
+ * one rounded f32 multiply, truncation toward zero, wrap modulo 2^16.  depth f32 [n] (16-byte aligned), out u16 [n]. */
+int icv_depth_to_u16(const float* depth, int64_t n, float scale, unsigned short* out, void* stream);
 
 /* ---- dtype plumbing: f32 -> bf16 (round-to-nearest-even), n elements ---------------------- */
 int icv_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);

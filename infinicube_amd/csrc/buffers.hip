@@ -187,3 +187,31 @@ extern "C" int icv_instance_overlay_u8(const unsigned char* semantics_rgb, const
                      semantics_rgb, instance, n, instance_rgb_lut65536, out);
   return icv_check_launch("icv_instance_overlay_u8");
 }
+
+// ---------------------------------------------------------------------------------------------
+// the depth wire format of stage 2, `voxel_depth_100_*.tar` members =
+// `(depth * 100).astype(np.uint16)` [R infinicube/inference/guidance_buffer_generation.py:668-670]: one rounded f32
+// multiply, truncation toward zero, wrap modulo 2^16 (numpy's float -> uint16 cast goes through a 64-bit integer on
+// x86-64).  HBM-bound: 4 B read + 2 B written per pixel, so only the 2-byte image crosses PCIe for PNG encoding.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void depth_to_u16_kernel(const float* __restrict__ depth, unsigned short* __restrict__ out,
+                                                           float scale, int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const float4 d = *reinterpret_cast<const float4*>(depth + i);
+    ushort4 o;
+    o.x = (unsigned short)(long long)__fmul_rn(d.x, scale); o.y = (unsigned short)(long long)__fmul_rn(d.y, scale);
+    o.z = (unsigned short)(long long)__fmul_rn(d.z, scale); o.w = (unsigned short)(long long)__fmul_rn(d.w, scale);
+    *reinterpret_cast<ushort4*>(out + i) = o;
+  } else {
+    for (int64_t j = i; j < n; ++j) out[j] = (unsigned short)(long long)__fmul_rn(depth[j], scale);
+  }
+}
+
+extern "C" int icv_depth_to_u16(const float* depth, int64_t n, float scale, unsigned short* out, void* stream) {
+  ICV_REQUIRE(depth && out && n > 0, "icv_depth_to_u16: bad arguments");
+  ICV_REQUIRE(((uintptr_t)depth % 16 == 0) && ((uintptr_t)out % 8 == 0), "icv_depth_to_u16: buffers must be 16-byte / 8-byte aligned");
+  const int64_t threads = (n + 3) / 4;
+  hipLaunchKernelGGL(depth_to_u16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, depth, out, scale, n);
+  return icv_check_launch("icv_depth_to_u16");
+}

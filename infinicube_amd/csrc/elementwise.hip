@@ -295,7 +295,7 @@ extern "C" int icv_patchify(const float* latent, int64_t C, int64_t T, int64_t H
 __global__ __launch_bounds__(256) void unpatchify_cfg_euler_kernel(
     float* __restrict__ lat, float* __restrict__ vel, const float* __restrict__ hc,
     const float* __restrict__ hu, int64_t ldh, float cfg, float dsigma, int C, int T, int H8,
-    int W8, int64_t tok0, int64_t n_tok) {
+    int W8, int64_t tok0, int64_t n_tok, int round_bf16) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n_tok * 2 * C) return;
   const int c = (int)(idx % C);
@@ -308,16 +308,30 @@ __global__ __launch_bounds__(256) void unpatchify_cfg_euler_kernel(
   const int f = (int)(tok / ((int64_t)Wp * Hp));
   const int64_t h0 = r * ldh + (int64_t)(y * 2) * C + c;
   float v0 = hc[h0], v1 = hc[h0 + C];
-  if (hu) {
-    const float u0 = hu[h0], u1 = hu[h0 + C];
-    v0 = u0 + cfg * (v0 - u0);
-    v1 = u1 + cfg * (v1 - u1);
-  }
   const int64_t li = (((int64_t)c * T + f) * H8 + 2 * hp + y) * W8 + 2 * wp;
   float2* lp = reinterpret_cast<float2*>(lat + li);
   float2 l = *lp;
-  l.x += v0 * dsigma;
-  l.y += v1 * dsigma;
+  if (round_bf16) {
+    // "reference rounding": a pipeline that keeps noise_pred and the latents in torch_dtype = bf16 rounds after every
+    // tensor op — the model outputs, (c - u), cfg * (.), u + (.), v * dsigma and the updated latent ([EXT], ORACLE_RISKS.md)
+    auto rb = [](float x) { return bf16_to_f32((bf16_t)f32_to_bf16_bits(x)); };
+    v0 = rb(v0); v1 = rb(v1);
+    if (hu) {
+      const float u0 = rb(hu[h0]), u1 = rb(hu[h0 + C]);
+      v0 = rb(u0 + rb(cfg * rb(v0 - u0)));
+      v1 = rb(u1 + rb(cfg * rb(v1 - u1)));
+    }
+    l.x = rb(rb(l.x) + rb(v0 * dsigma));
+    l.y = rb(rb(l.y) + rb(v1 * dsigma));
+  } else {
+    if (hu) {
+      const float u0 = hu[h0], u1 = hu[h0 + C];
+      v0 = u0 + cfg * (v0 - u0);
+      v1 = u1 + cfg * (v1 - u1);
+    }
+    l.x += v0 * dsigma;
+    l.y += v1 * dsigma;
+  }
   *lp = l;
   if (vel) *reinterpret_cast<float2*>(vel + li) = make_float2(v0, v1);
 }
@@ -325,13 +339,13 @@ __global__ __launch_bounds__(256) void unpatchify_cfg_euler_kernel(
 extern "C" int icv_unpatchify_cfg_euler(float* latent, float* vel_out, const float* hc,
                                         const float* hu, int64_t ldh, float cfg_scale,
                                         float dsigma, int64_t C, int64_t T, int64_t H8, int64_t W8,
-                                        int64_t tok0, int64_t n_tok, void* stream) {
+                                        int64_t tok0, int64_t n_tok, int round_bf16, void* stream) {
   ICV_REQUIRE(H8 % 2 == 0 && W8 % 2 == 0 && n_tok > 0 && ldh >= 4 * C, "icv_unpatchify_cfg_euler: bad shape");
   ICV_REQUIRE(tok0 >= 0 && tok0 + n_tok <= T * (H8 / 2) * (W8 / 2), "icv_unpatchify_cfg_euler: token range");
   const int64_t total = n_tok * 2 * C;
   hipLaunchKernelGGL(unpatchify_cfg_euler_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
                      0, (hipStream_t)stream, latent, vel_out, hc, hu, ldh, cfg_scale, dsigma,
-                     (int)C, (int)T, (int)H8, (int)W8, tok0, n_tok);
+                     (int)C, (int)T, (int)H8, (int)W8, tok0, n_tok, round_bf16);
   return icv_check_launch("icv_unpatchify_cfg_euler");
 }
 

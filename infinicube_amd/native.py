@@ -44,10 +44,11 @@ SIGNATURES = {
     "icv_attention_fp8_fwd_chunk": (c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, c_int, c_int, _P]),
     "icv_attention_fwd_chunk": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _F, c_int, c_int, _P]),
     "icv_patchify": (c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
-    "icv_unpatchify_cfg_euler": (c_int, [_P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _I, _I, _P]),
+    "icv_unpatchify_cfg_euler": (c_int, [_P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _I, _I, c_int, _P]),
     "icv_cast_f32_to_bf16": (c_int, [_P, _P, _I, _P]),
     "icv_semantic_to_color": (c_int, [_P, _I, _P, c_int, _P, _P, _P]),
     "icv_instance_overlay_u8": (c_int, [_P, _P, _I, _P, _P, _P]),
+    "icv_depth_to_u16": (c_int, [_P, _I, _F, _P, _P]),
     "icv_coord_valid_mask": (c_int, [_P, ctypes.POINTER(c_float), _P, _I, _I, _I, _P, _P]),
     "icv_coord_gather_points": (c_int, [_P, ctypes.POINTER(c_float), _P, _I, _I, _I, _P, _I, _P, _P]),
     "icv_coord_normalize": (c_int, [_P, ctypes.POINTER(c_float), _P, _I, _I, _I, ctypes.POINTER(c_float),

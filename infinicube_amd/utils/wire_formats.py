@@ -1,0 +1,206 @@
+"""Stage-2 artefacts on disk: what stage 3 and the fork's trainer read back.
+
+Same names and arguments as the reference's writers:
+  * ``write_to_tar(sample, output_file, __key__=None)``            [R infinicube/utils/wds_utils.py:300-313]
+  * ``imageencoder_imageio_png(image)``                            [R infinicube/data_process/waymo_utils.py:32-44]
+  * ``write_video_file(frames, output_file, fps=30, use_jiahui_params=True)``  [R infinicube/utils/fileio_utils.py:58-140]
+and the block of ``generate_guidance_buffer_and_save`` that assembles the five tars and three mp4s
+[R infinicube/inference/guidance_buffer_generation.py:645-728] as ``write_guidance_buffer_artifacts``.
+
+The reference delegates the tar framing to ``webdataset.TarWriter`` and the PNG / mp4 encoding to ``imageio``
+(both un-pinned in pyproject.toml:17-19, neither installed here) — [EXT]: what follows restates webdataset's published
+TarWriter (one member per sample key, name ``<__key__>.<key>``, keys sorted, mode 0o444, owner/group "bigdata",
+values encoded by extension: bytes as is, ``.npy`` through ``numpy.lib.format.write_array``, ``.json`` through
+``json.dumps``, ``.pyd``/``.pickle`` through pickle) with the standard library's ``tarfile``.  Member PAYLOADS that
+are numpy / pickle / raw bytes are byte-identical by construction; PNG payloads are lossless, so they decode to the
+same uint16 arrays, but the deflate stream depends on the encoder build (PIL here, imageio->PIL there) and tar
+headers carry the write time — neither is a parity surface.  ``read_tar_sample`` is the reader stage 3 uses
+(``get_sample(url)`` with the default ``npraw`` image spec [R infinicube/utils/wds_utils.py:239-271]).
+"""
+from __future__ import annotations
+
+import io
+import json
+import os
+import pickle
+import tarfile
+import time
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence, Union
+
+import numpy as np
+
+TAR_MODE, TAR_OWNER = 0o0444, "bigdata"        # webdataset.TarWriter defaults
+X264_PARAMS = ["-preset", "veryslow", "-crf", "23.5", "-g", "250", "-bf", "3", "-sc_threshold", "60", "-qcomp", "0.5",
+               "-psy-rd", "0.3:0", "-aq-mode", "2", "-aq-strength", "0.8", "-me_method", "umh", "-flags", "+cgop",
+               "-movflags", "+faststart"]      # the reference's libx264 parameter set [R infinicube/utils/fileio_utils.py:80-103]
+
+
+def imageencoder_imageio_png(image: np.ndarray) -> bytes:
+    """ndarray -> PNG bytes; uint16 [H, W] becomes a 16-bit greyscale PNG (the depth x100 and instance-id members)."""
+    from PIL import Image
+    arr = np.ascontiguousarray(image)
+    if arr.dtype == np.uint16 and arr.ndim == 2:
+        im = Image.frombuffer("I;16", (arr.shape[1], arr.shape[0]), arr.astype("<u2").tobytes(), "raw", "I;16", 0, 1)
+    elif arr.dtype == np.uint8:
+        im = Image.fromarray(arr)
+    else:
+        raise TypeError(f"PNG members are uint8 or 2-D uint16 arrays, got {arr.dtype} {arr.shape}")
+    with io.BytesIO() as out:
+        im.save(out, format="PNG")
+        return out.getvalue()
+
+
+def _encode(key: str, value) -> bytes:
+    """webdataset's encode_based_on_extension for the extensions stage 2 writes."""
+    if isinstance(value, (bytes, bytearray, memoryview)):
+        return bytes(value)
+    if isinstance(value, str):
+        return value.encode("utf-8")
+    ext = key.rsplit(".", 1)[-1].lower()
+    if ext == "npy":
+        with io.BytesIO() as out:
+            np.lib.format.write_array(out, np.asarray(value))
+            return out.getvalue()
+    if ext in ("json", "jsn"):
+        return json.dumps(value).encode("utf-8")
+    if ext in ("pyd", "pickle"):
+        return pickle.dumps(value)
+    if ext == "png":
+        return imageencoder_imageio_png(np.asarray(value))
+    raise ValueError(f"no encoder for tar member {key!r} of type {type(value)}")
+
+
+def write_to_tar(sample: Dict, output_file: Union[str, Path], __key__: Optional[str] = None) -> None:
+    if __key__ is not None:
+        sample["__key__"] = __key__
+    if "__key__" not in sample:
+        raise ValueError("object must contain a __key__")
+    output_file = Path(output_file)
+    output_file.parent.mkdir(parents=True, exist_ok=True)
+    key = sample["__key__"]
+    with tarfile.open(str(output_file), "w") as tar:
+        for k in sorted(sample.keys()):
+            if k.startswith("_"):
+                continue
+            payload = _encode(k, sample[k])
+            ti = tarfile.TarInfo(f"{key}.{k}")
+            ti.size, ti.mtime, ti.mode, ti.uname, ti.gname = len(payload), time.time(), TAR_MODE, TAR_OWNER, TAR_OWNER
+            tar.addfile(ti, io.BytesIO(payload))
+    print(f"Saved {output_file}")
+
+
+def read_tar_sample(path: Union[str, Path]) -> Dict:
+    """The first (only) sample of a stage-2 tar as stage 3 sees it: members grouped under the key up to the first
+    dot of the basename; ``.npy`` -> ndarray, ``.png`` -> raw ndarray (uint16 stays uint16), ``.json`` -> object,
+    ``.pyd``/``.pickle`` -> object, anything else bytes."""
+    from PIL import Image
+    out: Dict = {}
+    with tarfile.open(str(path), "r") as tar:
+        for ti in tar:
+            if not ti.isfile():
+                continue
+            base = os.path.basename(ti.name)
+            key, _, suffix = base.partition(".")
+            if "__key__" in out and out["__key__"] != key:
+                break
+            out["__key__"] = key
+            data = tar.extractfile(ti).read()
+            ext = suffix.rsplit(".", 1)[-1].lower()
+            if ext == "npy":
+                out[suffix] = np.lib.format.read_array(io.BytesIO(data), allow_pickle=False)
+            elif ext == "png":
+                out[suffix] = np.asarray(Image.open(io.BytesIO(data)))
+            elif ext in ("json", "jsn"):
+                out[suffix] = json.loads(data)
+            elif ext in ("pyd", "pickle"):
+                out[suffix] = pickle.loads(data)
+            else:
+                out[suffix] = data
+    return out
+
+
+def write_video_file(frames, output_file: Union[str, Path], fps: int = 30, use_jiahui_params: bool = True) -> None:
+    """frames: list of [H,W,3] uint8 | [N,H,W,3] array | dict index -> frame (or PNG bytes).  libx264 with the
+    reference's parameter set through imageio's FFMPEG plugin when imageio is installed (the reference's
+    environment); otherwise the built-in Motion-JPEG muxer, announced on stdout (videogen/mp4mux.py)."""
+    output_file = Path(output_file).as_posix()
+    Path(output_file).parent.mkdir(parents=True, exist_ok=True)
+    if not output_file.endswith(".mp4"):
+        output_file = Path(output_file).with_suffix(".mp4").as_posix()
+    assert len(frames) > 0
+    if isinstance(frames, np.ndarray):
+        frames = [f for f in frames]
+    if isinstance(frames, dict):
+        from PIL import Image
+        keys = sorted(k for k in frames.keys() if k != "__key__")
+        frames = [np.asarray(Image.open(io.BytesIO(frames[k]))) if isinstance(frames[k], bytes) else frames[k] for k in keys]
+    try:
+        import imageio.v3 as iio
+    except ImportError:
+        from ..videogen.mp4mux import write_mjpeg_mp4
+        print(f"  (imageio not installed: writing {output_file} as Motion-JPEG mp4 instead of libx264)")
+        from PIL import Image
+        write_mjpeg_mp4([Image.fromarray(np.ascontiguousarray(f)).convert("RGB") for f in frames], output_file, fps=fps, quality=8)
+        return
+    iio.imwrite(output_file, frames, plugin="FFMPEG", fps=fps, codec="libx264",
+                output_params=X264_PARAMS if use_jiahui_params else [])
+
+
+def depth_to_uint16_x100(depth_buffer) -> np.ndarray:
+    """``(depth * 100).astype(np.uint16)`` for a whole [N,H,W] depth buffer resident in HBM: quantised by the HIP
+    kernel (4 B read + 2 B written per pixel), only the uint16 image crosses PCIe.  A CPU tensor / ndarray is
+    uploaded first; there is no CPU fallback."""
+    import torch
+    from .. import native
+    lib = native.lib()
+    if not torch.cuda.is_available():
+        raise native.NativeError("depth_to_uint16_x100: no GPU visible to PyTorch-ROCm; there is no CPU fallback")
+    d = torch.as_tensor(depth_buffer)
+    dev = d.device if d.device.type == "cuda" else torch.device("cuda:0")
+    d = d.to(device=dev, dtype=torch.float32).contiguous()
+    out = torch.empty(d.shape, dtype=torch.uint16, device=dev)
+    native.check(lib.icv_depth_to_u16(d.data_ptr(), d.numel(), 100.0, out.data_ptr(),
+                                      torch.cuda.current_stream(dev).cuda_stream), "icv_depth_to_u16")
+    return out.cpu().numpy()
+
+
+def write_guidance_buffer_artifacts(output_folder: Union[str, Path], clip: str, depth_buffer, instance_buffer,
+                                    camera_poses, intrinsics: np.ndarray, semantic_frames: Sequence[np.ndarray],
+                                    coordinate_frames: Sequence[np.ndarray], depth_vis_frames: Optional[Sequence[np.ndarray]] = None,
+                                    resolution: str = "480p", dynamic_object_info: Optional[Dict] = None,
+                                    depth_u16: Optional[np.ndarray] = None) -> Dict[str, Path]:
+    """The file set of one stage-2 pass, named and laid out as the reference writes it
+    [R infinicube/inference/guidance_buffer_generation.py:645-728]: ``voxel_depth_100_<res>_front.tar`` (uint16 depth
+    x100 PNGs), ``instance_buffer_<res>_front.tar`` (uint16 ids), ``pose.tar`` (one [4,4] .npy per frame),
+    ``intrinsic.tar`` ([fx, fy, cx, cy, w, h]), the three buffer mp4s at fps 10, optionally ``dynamic_object_info.tar``.
+    ``depth_u16`` lets a caller pass an already-quantised buffer (tests on CPU); otherwise the HIP kernel makes it."""
+    import torch
+    folder = Path(output_folder)
+    n = len(semantic_frames)
+    du16 = depth_u16 if depth_u16 is not None else depth_to_uint16_x100(depth_buffer)
+    inst = torch.as_tensor(instance_buffer).cpu().numpy().astype(np.uint16)
+    poses = torch.as_tensor(camera_poses).cpu().numpy()
+    depth_sample = {f"{i:06d}.voxel_depth_100.front.png": imageencoder_imageio_png(du16[i]) for i in range(n)}
+    instance_sample = {f"{i:06d}.instance_buffer.front.png": imageencoder_imageio_png(inst[i]) for i in range(n)}
+    pose_sample = {f"{i:06d}.pose.front.npy": poses[i] for i in range(n)}
+    files = {
+        "depth": folder / f"voxel_depth_100_{resolution}_front.tar",
+        "instance": folder / f"instance_buffer_{resolution}_front.tar",
+        "pose": folder / "pose.tar", "intrinsic": folder / "intrinsic.tar",
+        "semantic_video": folder / f"semantic_buffer_video_{resolution}_front.mp4",
+        "coordinate_video": folder / f"coordinate_buffer_video_{resolution}_front.mp4",
+    }
+    write_to_tar(depth_sample, files["depth"], __key__=clip)
+    write_to_tar(instance_sample, files["instance"], __key__=clip)
+    write_to_tar(pose_sample, files["pose"], __key__=clip)
+    write_to_tar({"intrinsic.front.npy": np.asarray(intrinsics)}, files["intrinsic"], __key__=clip)
+    if dynamic_object_info is not None:
+        files["dynamic_object_info"] = folder / "dynamic_object_info.tar"
+        write_to_tar(dict(dynamic_object_info), files["dynamic_object_info"], __key__=clip)
+    write_video_file(list(semantic_frames), files["semantic_video"], fps=10)
+    if depth_vis_frames is not None:
+        files["depth_vis_video"] = folder / f"depth_vis_video_{resolution}_front.mp4"
+        write_video_file(list(depth_vis_frames), files["depth_vis_video"], fps=10)
+    write_video_file(list(coordinate_frames), files["coordinate_video"], fps=10)
+    return files

@@ -502,12 +502,13 @@ class WanDiT:
     def denoise(self, latent: torch.Tensor, ctx_cond: Optional[ContextKV], ctx_uncond: Optional[ContextKV],
                 buf_tokens: Optional[torch.Tensor], scheduler: FlowMatchScheduler,
                 cfg_scale: float = 5.0, steps: Optional[range] = None, on_step=None,
-                branch_exchange=None) -> torch.Tensor:
+                branch_exchange=None, round_bf16: bool = False) -> torch.Tensor:
         """The hot loop: per step 2 DiT forwards (cond, uncond) + fused unpatchify/CFG/Euler.
         ``latent`` f32 [C,T,H8,W8] is updated IN PLACE for this rank's tokens.
         ``branch_exchange`` (seqpar.BranchExchange, cfg+sp layout): this rank runs ONE forward per step — the
         cond one if it was given ``ctx_cond`` only, the uncond one if ``ctx_uncond`` only — and swaps velocity
-        tokens with the rank that runs the other branch on the same token shard."""
+        tokens with the rank that runs the other branch on the same token shard.
+        ``round_bf16``: "reference rounding" of the CFG combine and the Euler update (icv_unpatchify_cfg_euler)."""
         ops, plan = self.ops, self.plan
         if branch_exchange is not None:
             if (ctx_cond is None) == (ctx_uncond is None) or cfg_scale == 1.0:
@@ -517,7 +518,7 @@ class WanDiT:
                 self.forward_tokens(latent, own_ctx, scheduler.timesteps[i], buf_tokens, self.head_own)
                 branch_exchange(self.head_own, self.head_out)           # slot 0 = cond, slot 1 = uncond
                 ops.unpatchify_cfg_euler(latent, self.head_out[0], self.head_out[1], cfg_scale,
-                                         scheduler.dsigma(i), plan.tok0, plan.n_tok)
+                                         scheduler.dsigma(i), plan.tok0, plan.n_tok, round_bf16=round_bf16)
                 if on_step is not None:
                     on_step(i, latent)
             return latent
@@ -540,7 +541,7 @@ class WanDiT:
                 if use_cfg:
                     self.forward_tokens(latent, ctx_uncond, ts, buf_tokens, self.head_out[1])
             ops.unpatchify_cfg_euler(latent, self.head_out[0], self.head_out[1] if use_cfg else None,
-                                     cfg_scale, scheduler.dsigma(i), plan.tok0, plan.n_tok)
+                                     cfg_scale, scheduler.dsigma(i), plan.tok0, plan.n_tok, round_bf16=round_bf16)
             if on_step is not None:
                 on_step(i, latent)
         return latent

@@ -286,13 +286,13 @@ class HipOps:
         native.check(self.lib.icv_patchify(latent.data_ptr(), C, T, H8, W8, out.data_ptr(),
                                            out.stride(0), tok0, n_tok, self._stream()), "icv_patchify")
 
-    def unpatchify_cfg_euler(self, latent, hc, hu, cfg_scale, dsigma, tok0, n_tok, vel_out=None):
+    def unpatchify_cfg_euler(self, latent, hc, hu, cfg_scale, dsigma, tok0, n_tok, vel_out=None, round_bf16=False):
         _chk(latent, F32, "euler.latent"); _chk(hc, F32, "euler.hc")
         assert latent.is_contiguous()
         C, T, H8, W8 = latent.shape
         native.check(self.lib.icv_unpatchify_cfg_euler(
             latent.data_ptr(), native.ptr(vel_out), hc.data_ptr(), native.ptr(hu), hc.stride(0),
-            cfg_scale, dsigma, C, T, H8, W8, tok0, n_tok, self._stream()), "icv_unpatchify_cfg_euler")
+            cfg_scale, dsigma, C, T, H8, W8, tok0, n_tok, int(bool(round_bf16)), self._stream()), "icv_unpatchify_cfg_euler")
 
     def cast_bf16(self, src, out):
         _chk(src, F32, "cast.src"); _chk(out, BF16, "cast.out")

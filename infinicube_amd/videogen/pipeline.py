@@ -176,7 +176,12 @@ class WanVideoPipeline:
         # sampling defaults of the fork's __call__ ([EXT]); the reference never
         # overrides them [R infinicube/videogen/inference.py:216-226], so they are attributes here
         self.num_inference_steps, self.cfg_scale, self.sigma_shift = 50, 5.0, 5.0
-        self.scheduler = FlowMatchScheduler(self.num_inference_steps, self.sigma_shift)
+        # ICV_REFERENCE_ROUNDING=1 / pipe.reference_rounding = True: reproduce the rounding points of a pipeline that keeps
+        # timestep, noise, noise_pred and latents in torch_dtype=bf16 ([EXT] upstream DiffSynth; ORACLE_RISKS.md R1-R3).
+        # Default False: exact float timestep, fp32 noise / latents / CFG / Euler (more accurate; not what a bf16
+        # checkpoint was sampled with during fine-tuning validation).
+        self.reference_rounding = os.environ.get("ICV_REFERENCE_ROUNDING", "0") == "1"
+        self.scheduler = FlowMatchScheduler(self.num_inference_steps, self.sigma_shift, self.reference_rounding)
         self._ops = ops
         self._engine = None
         self._engine_key = None
@@ -298,7 +303,7 @@ class WanVideoPipeline:
         layout = self._layouts[lkey]
         plan = layout.shard_plan(grid.S)
         engine.prepare(grid, plan, group=layout.sp_group, sp_chunks=self.sp_chunks, kv_exchange=self.kv_exchange)
-        self.scheduler = FlowMatchScheduler(num_inference_steps, sigma_shift)
+        self.scheduler = FlowMatchScheduler(num_inference_steps, sigma_shift, self.reference_rounding)
         # i2v (BASELINE.json config #5): CLIP tokens + conditioning latent of the first frame, once per call
         i2v = engine.cfg.has_image_input
         clip_fea = None
@@ -321,6 +326,8 @@ class WanVideoPipeline:
         else:
             g.seed()     # upstream passes generator=None: a different noise on every unseeded call
         latent = torch.randn((1, 16) + grid.latent_shape()[1:], generator=g, dtype=torch.float32)[0]
+        if self.reference_rounding:
+            latent = latent.to(torch.bfloat16).to(torch.float32)
         latent = ops.to_device(latent, torch.float32)
         # guidance buffers -> VAE latents -> tokens (step-invariant)
         buf_tokens = None
@@ -340,7 +347,8 @@ class WanVideoPipeline:
         if progress_bar_cmd is not None:
             it = progress_bar_cmd(it)
         engine.denoise(latent, ctx_c, ctx_u, buf_tokens, self.scheduler, cfg_scale, steps=it,
-                       branch_exchange=BranchExchange(layout) if layout.mode == "cfg+sp" else None)
+                       branch_exchange=BranchExchange(layout) if layout.mode == "cfg+sp" else None,
+                       round_bf16=self.reference_rounding)
         latent = gather_latent(latent, plan, grid, group=layout.sp_group)
         if return_latents:
             return latent

@@ -23,13 +23,28 @@ def flow_match_sigmas(num_steps: int, shift: float = 5.0, sigma_max: float = 1.0
     return out
 
 
+def round_through_bf16(x: float) -> float:
+    """The float nearest-even-rounded to bfloat16 (8 significant bits): 937.5 -> 936.0."""
+    import struct
+    (u,) = struct.unpack("<I", struct.pack("<f", x))
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return struct.unpack("<f", struct.pack("<I", u))[0]
+
+
 class FlowMatchScheduler:
-    def __init__(self, num_inference_steps: int = 50, shift: float = 5.0):
+    """``reference_rounding``: the timestep fed to the DiT is 1000 sigma rounded to bfloat16, as a pipeline that casts
+    ``timestep.to(torch_dtype)`` before the sinusoidal embedding does ([EXT], ORACLE_RISKS.md R1); the sigmas of the
+    Euler update stay exact either way."""
+
+    def __init__(self, num_inference_steps: int = 50, shift: float = 5.0, reference_rounding: bool = False):
+        self.reference_rounding = reference_rounding
         self.set_timesteps(num_inference_steps, shift)
 
     def set_timesteps(self, num_inference_steps: int, shift: float = 5.0):
         self.sigmas = flow_match_sigmas(num_inference_steps, shift)
         self.timesteps = [s * 1000.0 for s in self.sigmas]
+        if self.reference_rounding:
+            self.timesteps = [round_through_bf16(t) for t in self.timesteps]
 
     def dsigma(self, i: int) -> float:
         """sigma_{i+1} - sigma_i with sigma_N = 0 (the Euler step multiplier)."""

@@ -297,21 +297,28 @@ def flow_match_sigmas(num_steps: int, shift: float = 5.0) -> Tensor:
 def denoise_loop(sd, bsd, cfg, noise: Tensor, ctx_cond: Tensor, ctx_uncond: Tensor,
                  buffer_latents: Optional[Tensor], num_steps: int = 50, cfg_scale: float = 5.0,
                  shift: float = 5.0, dtype=torch.float32, trace: Optional[list] = None,
-                 clip_fea: Optional[Tensor] = None, y: Optional[Tensor] = None, fp8: bool = False) -> Tensor:
-    """for sigma in sigmas: v = v_u + s (v_c - v_u); x += v (sigma_next - sigma)."""
+                 clip_fea: Optional[Tensor] = None, y: Optional[Tensor] = None, fp8: bool = False,
+                 reference_rounding: bool = False) -> Tensor:
+    """for sigma in sigmas: v = v_u + s (v_c - v_u); x += v (sigma_next - sigma).
+    ``reference_rounding`` ([EXT], ORACLE_RISKS.md R1-R3): the rounding points of a pipeline that keeps timestep,
+    noise, noise_pred and latents in torch_dtype = bf16: timestep -> bf16 before the sinusoidal embedding, noise ->
+    bf16, every tensor op of the CFG combine and the Euler update rounded to bf16."""
     sig = flow_match_sigmas(num_steps, shift)
     buf = buffer_embed(bsd, buffer_latents, dtype) if buffer_latents is not None else None
-    x = noise.to(dtype).clone()
+    rb = (lambda t: t.to(torch.bfloat16).to(dtype)) if reference_rounding else (lambda t: t)   # noqa: E731
+    x = rb(noise.to(dtype).clone())
     for i in range(num_steps):
         ts = float(sig[i]) * 1000.0
-        v_c = dit_forward(sd, cfg, x, ctx_cond, ts, buf, dtype, clip_fea=clip_fea, y=y, fp8=fp8)
+        if reference_rounding:
+            ts = float(torch.tensor(ts, dtype=torch.float32).to(torch.bfloat16))
+        v_c = rb(dit_forward(sd, cfg, x, ctx_cond, ts, buf, dtype, clip_fea=clip_fea, y=y, fp8=fp8))
         if cfg_scale != 1.0:
-            v_u = dit_forward(sd, cfg, x, ctx_uncond, ts, buf, dtype, clip_fea=clip_fea, y=y, fp8=fp8)
-            v = v_u + cfg_scale * (v_c - v_u)
+            v_u = rb(dit_forward(sd, cfg, x, ctx_uncond, ts, buf, dtype, clip_fea=clip_fea, y=y, fp8=fp8))
+            v = rb(v_u + rb(cfg_scale * rb(v_c - v_u)))
         else:
             v = v_c
         nxt = float(sig[i + 1]) if i + 1 < num_steps else 0.0
-        x = x + v * (nxt - float(sig[i]))
+        x = rb(x + rb(v * (nxt - float(sig[i]))))
         if trace is not None:
             trace.append(x.clone())
     return x

@@ -188,9 +188,22 @@ class OracleOps:
         tok = latent.reshape(C, T, Hp, 2, Wp, 2).permute(1, 2, 4, 0, 3, 5).reshape(T * Hp * Wp, C * 4)
         out[:, : C * 4].copy_(tok[tok0: tok0 + n_tok].to(BF16))
 
-    def unpatchify_cfg_euler(self, latent, hc, hu, cfg_scale, dsigma, tok0, n_tok, vel_out=None):
+    def unpatchify_cfg_euler(self, latent, hc, hu, cfg_scale, dsigma, tok0, n_tok, vel_out=None, round_bf16=False):
         C, T, H8, W8 = latent.shape
         Hp, Wp = H8 // 2, W8 // 2
+        if round_bf16:
+            rb = lambda t: t.to(torch.bfloat16).to(F32)   # noqa: E731
+            v = rb(hc) if hu is None else rb(rb(hu) + rb(cfg_scale * rb(rb(hc) - rb(hu))))
+            full = torch.zeros((T * Hp * Wp, 4 * C), dtype=F32)
+            full[tok0: tok0 + n_tok] = v
+            vel = R.unpatchify(full, (T, Hp, Wp), C)
+            mask = torch.zeros((T * Hp * Wp, 4 * C), dtype=F32)
+            mask[tok0: tok0 + n_tok] = 1.0
+            m = R.unpatchify(mask, (T, Hp, Wp), C)
+            latent.copy_(torch.where(m > 0, rb(rb(latent) + rb(vel * dsigma)), latent))
+            if vel_out is not None:
+                vel_out.copy_(torch.where(m > 0, vel, vel_out))
+            return
         v = hc if hu is None else hu + cfg_scale * (hc - hu)
         full = torch.zeros((T * Hp * Wp, 4 * C), dtype=F32)
         full[tok0: tok0 + n_tok] = v

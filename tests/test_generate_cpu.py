@@ -159,6 +159,59 @@ def test_fp8_torch_dtype_selects_fp8_projections():
     assert 0 < rel < 0.1, f"fp8 vs bf16 latents rel-L2 {rel}"
 
 
+def test_reference_rounding_switch_matches_oracle():
+    """pipe.reference_rounding: bf16-rounded timestep (937.5 -> 936), bf16 noise, bf16-rounded CFG combine / Euler update —
+    the host pipeline (with the oracle operator set) follows the oracle's restatement of the same rounding points, and
+    the switch changes the result (ORACLE_RISKS.md R1-R3)."""
+    from oracle import wan_ref as R
+    from infinicube_amd.videogen.scheduler import FlowMatchScheduler, round_through_bf16
+    assert round_through_bf16(937.5) == 936.0 and FlowMatchScheduler(4, 5.0, True).timesteps[1] == round_through_bf16(FlowMatchScheduler(4).timesteps[1])
+    sd, bsd = syn.make_dit_state_dict(CFG), syn.make_buffer_embedder_state_dict(CFG)
+    pipe = WanVideoPipeline("cpu", torch.bfloat16, DiTHolder(sd, CFG), HashTextEncoder(CFG), PoolVAE(), ops=OracleOps())
+    pipe.initialize_buffer_embedder(16, zero_init=True).load_state_dict(bsd)
+    sem, co = syn.make_dummy_buffers(GRID)
+    from PIL import Image
+    kw = dict(prompt="a street", negative_prompt="bad", semantic_buffer_video=[Image.fromarray(f) for f in sem],
+              coordinate_buffer_video=[Image.fromarray(f) for f in co], height=GRID.height, width=GRID.width,
+              num_frames=GRID.num_frames, seed=0, num_inference_steps=3, return_latents=True)
+    plain = pipe(**kw)
+    pipe.reference_rounding = True
+    rounded = pipe(**kw)
+    assert not torch.equal(plain, rounded)
+    assert torch.equal(rounded, rounded.to(torch.bfloat16).float()), "with reference rounding the latent is bf16-representable"
+    # oracle arm with the same rounding points
+    from infinicube_amd.videogen.pipeline import _video_to_tensor
+    vae, te = PoolVAE(), HashTextEncoder(CFG)
+    bl = torch.cat([vae.encode(_video_to_tensor(kw[k], GRID.height, GRID.width)) for k in ("semantic_buffer_video", "coordinate_buffer_video")], 0)
+    noise = syn.make_latent_noise(GRID, seed=0)
+    sdr, bsdr = R.round_state_dict_to_bf16(sd), R.round_state_dict_to_bf16(bsd)
+    ref = R.denoise_loop(sdr, bsdr, CFG, noise, te.encode("a street"), te.encode("bad"), bl, num_steps=3, reference_rounding=True)
+    assert R.psnr(rounded, ref) > 40.0, R.psnr(rounded, ref)
+    ref_plain = R.denoise_loop(sdr, bsdr, CFG, noise, te.encode("a street"), te.encode("bad"), bl, num_steps=3)
+    assert R.psnr(rounded, ref) > R.psnr(rounded, ref_plain), "the rounded pipeline must sit closer to the rounded oracle than to the exact one"
+
+
+def test_from_pretrained_fp8_keeps_encoders_in_bf16(tmp_path, monkeypatch):
+    """torch_dtype=float8_e4m3fn selects the DiT's fp8 mode; the UMT5 / CLIP / VAE loaders must not be handed e4m3."""
+    import infinicube_amd.videogen.clip_vision as cv
+    import infinicube_amd.videogen.text_encoder as te
+    import infinicube_amd.videogen.vae as vae
+    seen = {}
+    monkeypatch.setattr(te, "load_umt5_encoder", lambda pat, dev, dt, tok=None: seen.setdefault("t5", dt) and HashTextEncoder(CFG))
+    monkeypatch.setattr(cv, "load_clip_vision", lambda pat, dev, dt: seen.setdefault("clip", dt))
+    monkeypatch.setattr(vae, "load_wan_vae", lambda pat, dev: PoolVAE())
+    d = tmp_path / "m"
+    d.mkdir()
+    save_file({k: v.contiguous() for k, v in syn.make_dit_state_dict(CFG).items()}, str(d / "diffusion_pytorch_model.safetensors"))
+    mcs = [ModelConfig(path=str(d / n)) for n in ("diffusion_pytorch_model*.safetensors", "models_t5_umt5-xxl-enc-bf16.pth",
+                                                  "Wan2.1_VAE.pth", "models_clip_open-clip-xlm-roberta-large-vit-huge-14.pth")]
+    pipe = WanVideoPipeline.from_pretrained(torch_dtype=torch.float8_e4m3fn, device="cpu", model_configs=mcs)
+    assert pipe.gemm_dtype == "fp8" and seen == {"t5": torch.bfloat16, "clip": torch.bfloat16}
+    seen.clear()
+    WanVideoPipeline.from_pretrained(torch_dtype=torch.float16, device="cpu", model_configs=mcs)
+    assert seen == {"t5": torch.float16, "clip": torch.float16}
+
+
 def test_checkpoint_inventory(tmp_path, capsys):
     """Counterpart of the reference's download script: the same six (model_id, pattern) entries, present / missing,
     and the architecture implied by a DiT shard's tensor shapes."""

@@ -533,6 +533,25 @@ def test_patchify_and_unpatchify_euler(hip_ops):
     assert torch.allclose(lat_g2.cpu(), lat + R.unpatchify(full_c, (T, Hp, Wp), C) * 0.5, atol=1e-5)
 
 
+def test_unpatchify_cfg_euler_reference_rounding(hip_ops):
+    """round_bf16 = 1: every intermediate of the CFG combine and the Euler update rounded through bf16, bit for bit
+    equal to the host restatement (tests/oracle_ops.py), and different from the exact path."""
+    from oracle_ops import OracleOps
+    C, T, H8, W8 = 16, 3, 8, 12
+    tok0, n = 5, 40
+    lat = rnd((C, T, H8, W8), 95, 2.0)
+    hc, hu = rnd((n, 64), 96), rnd((n, 64), 97)
+    for with_u in (True, False):
+        want = lat.clone()
+        OracleOps().unpatchify_cfg_euler(want, hc, hu if with_u else None, 5.0, -0.0371, tok0, n, round_bf16=True)
+        got = lat.clone().to(DEV)
+        hip_ops.unpatchify_cfg_euler(got, hc.to(DEV), hu.to(DEV) if with_u else None, 5.0, -0.0371, tok0, n, round_bf16=True)
+        assert torch.equal(got.cpu(), want), "reference-rounding Euler update differs from the host restatement"
+        exact = lat.clone().to(DEV)
+        hip_ops.unpatchify_cfg_euler(exact, hc.to(DEV), hu.to(DEV) if with_u else None, 5.0, -0.0371, tok0, n)
+        assert not torch.equal(exact.cpu(), want)
+
+
 def test_error_reporting(hip_ops):
     from infinicube_amd import native
     a = torch.zeros((8, 100), dtype=torch.bfloat16, device=DEV)   # K = 100 not a multiple of 64
