@@ -34,6 +34,15 @@ int icv_get_option_int(const char* name, int dflt) {
   return it == g_opts.end() ? dflt : it->second;
 }
 extern "C" int icv_set_option(const char* name, int value) {
+  // "require_experiments": succeeds only in a library built with ICV_EXPERIMENTS=1 (the A/B kernels under experiments/)
+  if (name && std::string(name) == "require_experiments") {
+#ifdef ICV_EXPERIMENTS
+    return 0;
+#else
+    icv_set_error("this libicvideo was built without ICV_EXPERIMENTS=1");
+    return 1;
+#endif
+  }
   if (!name) {
     icv_set_error("icv_set_option: null name");
     return 1;

@@ -1,5 +1,5 @@
 // Flash attention forward, second structure: same math, fragments and LDS
-// images as attn.hip (see there for the MFMA / key-permutation / swizzle design), but
+// images as experiments/attn1.hip (see there for the MFMA / key-permutation / swizzle design), but
 //   * KV tile = 128 keys staged per barrier pair, consumed as two 64-key halves: ONE COMPLETE half
 //     (K reads -> 16 QK^T MFMAs -> softmax -> V tr-reads -> 16 PV MFMAs) per barrier interval, i.e.
 //     32 MFMAs per wave per barrier instead of 16, and no accumulator is live across a barrier;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(512) void attn2_kernel(Params p) {
   uint4 kreg0, kreg1, kreg2, kreg3, vreg0, vreg1, vreg2, vreg3;
   // Steady state: the tile base is wave-uniform (SGPR pair) and each thread adds a fixed 32-bit byte offset, so a
   // tile costs 8 loads and no address VALU; only a partial last tile takes the clamped 64-bit path.  (The kernel
-  // is bound by the VALU issue port the MFMAs share — measured with s_memtime in attn6.hip — so every VALU
+  // is bound by the VALU issue port the MFMAs share — measured with s_memtime in experiments/attn6.hip — so every VALU
   // instruction removed from the loop is MFMA issue time.)
   const unsigned koff0 = (unsigned)(((int64_t)sk0 * p.ldk + sc0 * 8) * 2), kstep = (unsigned)(32 * p.ldk * 2);
   const unsigned voff0 = (unsigned)(((int64_t)sk0 * p.ldv + sc0 * 8) * 2), vstep = (unsigned)(32 * p.ldv * 2);
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(512) void attn2_kernel(Params p) {
   const int nt = (int)((p.Skv + KVB - 1) / KVB);
   A2_LOAD_TILE(0);
   A2_WRITE_TILE(smem);
-  // retire every prologue load with a wait the waitcnt pass can see (see attn.hip)
+  // retire every prologue load with a wait the waitcnt pass can see (see experiments/attn1.hip)
   __builtin_amdgcn_s_waitcnt(0x0F70);
   A2_BARRIER();
   if (nt > 1) A2_LOAD_TILE(1);

@@ -1,4 +1,4 @@
-// Flash attention forward: attn4.hip's LDS-DMA ring (no staging VGPRs, counted vmcnt, one barrier per 64-key tile)
+// Flash attention forward: experiments/attn4.hip's LDS-DMA ring (no staging VGPRs, counted vmcnt, one barrier per 64-key tile)
 // with the vector-side diet of attn2.hip, which the freed registers make affordable:
 //   * lazy max: P = exp2(S - m_ref) is taken against the current reference and the 16-key partial row sum (needed
 //     anyway) bounds every P; only when it exceeds 2^thr is the block's true max taken, O/l rescaled, P recomputed;
@@ -7,7 +7,7 @@
 //     S^T chain, so there is neither a per-element fma nor a per-tile accumulator initialisation;
 //   * DMA addresses: tile base in an SGPR pair + four fixed 32-bit per-lane byte offsets (saddr form of
 //     global_load_lds_dwordx4); only a partial last tile takes the clamped 64-bit path.
-// Everything else (fragments, swizzled LDS images, ring invariants, stagger option) is attn4.hip's: see there.
+// Everything else (fragments, swizzled LDS images, ring invariants, stagger option) is experiments/attn4.hip's: see there.
 #include "attn_common.h"
 
 namespace att7 {

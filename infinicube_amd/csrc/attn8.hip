@@ -181,7 +181,7 @@ __global__ __launch_bounds__(512) void attn8_kernel(Params p) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) qf[s] = read32(reinterpret_cast<const char*>(qp + s * 64), reinterpret_cast<const char*>(qp + s * 64 + 16));
   }
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // retire ordinary loads before any LDS-DMA is in flight (see attn4.hip)
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // retire ordinary loads before any LDS-DMA is in flight (see experiments/attn4.hip)
 
   f32x16 ot[4];
   float m_run, l_run;

@@ -1,7 +1,7 @@
-// Pieces shared by the flash-attention kernel variants (attn2.hip default, attn3.hip, attn4.hip):
+// Pieces shared by the flash-attention kernel variants (attn7.hip default, attn2.hip, and the experiments/ family):
 // launch parameters, (head, query-block) work-item mapping, the transposed LDS read, the carried
 // online-softmax state (load / init) and the epilogue (state write-back or normalised bf16 output).
-// Fragment conventions (see attn.hip for the derivation): a wave owns 32 query rows, query = lane&31;
+// Fragment conventions (see experiments/attn1.hip for the derivation): a wave owns 32 query rows, query = lane&31;
 // O^T accumulator ot[d0][r] = O[q][d = d0*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)]; the row sum l is kept as
 // two half-lane partials (lanes q and q+32).
 #pragma once

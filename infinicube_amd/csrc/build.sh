@@ -1,6 +1,8 @@
 #!/usr/bin/env bash
 # Build libicvideo.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
 # Usage: infinicube_amd/csrc/build.sh [extra hipcc flags]
+#        ICV_EXPERIMENTS=1 infinicube_amd/csrc/build.sh   also compiles the measured-slower A/B kernels under experiments/
+#        (attention families 1, 3, 4, 5, 6 and the 4-wave GEMM) into the library; the shipped build leaves them out.
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 root="$(cd "$here/../.." && pwd)"
@@ -10,8 +12,15 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$root/include" -I"$here" -W
 objs=()
 pids=()
 mkdir -p "$here/build"
-for src in api elementwise gemm gemm256 gemm256w gemm_fp8 fp8 attn attn2 attn3 attn4 attn5 attn6 attn7 attn8 buffers; do
-  obj="$here/build/$src.o"
+srcs=(api elementwise gemm gemm256 gemm_fp8 fp8 attention attn2 attn7 attn8 buffers)
+tag=""
+if [[ "${ICV_EXPERIMENTS:-0}" == "1" ]]; then
+  srcs+=(experiments/attn1 experiments/attn3 experiments/attn4 experiments/attn5 experiments/attn6 experiments/gemm256w)
+  FLAGS+=(-DICV_EXPERIMENTS)
+  tag="x"          # separate object files: the two configurations differ in -DICV_EXPERIMENTS
+fi
+for src in "${srcs[@]}"; do
+  obj="$here/build/$(basename "$src")$tag.o"
   if [[ ! -f "$obj" || "$here/$src.hip" -nt "$obj" || "$here/icv_common.h" -nt "$obj" || "$here/attn_common.h" -nt "$obj" || "$root/include/icvideo.h" -nt "$obj" ]]; then
     extra=()
     # buffers.hip produces BYTE outputs that must equal the reference's: no fused multiply-add contraction there

@@ -1,4 +1,5 @@
-// Flash attention forward for the DiT (SURVEY.md §8a-3 K6 self-attention, K9 cross-attention):
+// EXPERIMENT (icv_set_option("attn_kernel", 1); built only with ICV_EXPERIMENTS=1): the first attention kernel of this
+// repo, kept for A/B.  Flash attention forward for the DiT (SURVEY.md §8a-3 K6 self-attention, K9 cross-attention):
 // non-causal, head_dim 128, bf16 in/out, fp32 softmax + accumulation, arbitrary Sq / Skv.
 //
 // Structure (CDNA4, wave64, v_mfma_f32_32x32x16_bf16):
@@ -294,71 +295,9 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
 
 }  // namespace
 
-int icv_attn2_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
-                       void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml, int state_in,
-                       int state_out, int64_t Sq, int64_t Skv, int64_t heads, float scale, int var,
-                       hipStream_t st);
-
-int icv_attn3_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
-                       void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml, int state_in,
-                       int state_out, int64_t Sq, int64_t Skv, int64_t heads, float scale, int var,
-                       hipStream_t st);
-
-int icv_attn7_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
-                       void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml, int state_in,
-                       int state_out, int64_t Sq, int64_t Skv, int64_t heads, float scale, int var,
-                       hipStream_t st);
-int icv_attn6_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
-                       void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml, int state_in,
-                       int state_out, int64_t Sq, int64_t Skv, int64_t heads, float scale, int var,
-                       hipStream_t st);
-int icv_attn5_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
-                       void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml, int state_in,
-                       int state_out, int64_t Sq, int64_t Skv, int64_t heads, float scale, int var,
-                       hipStream_t st);
-int icv_attn4_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
-                       void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml, int state_in,
-                       int state_out, int64_t Sq, int64_t Skv, int64_t heads, float scale, int var,
-                       hipStream_t st);
-
-// Kernel family selection (icv_set_option("attn_kernel", n)): 7 = attn7.hip (default: LDS-DMA ring + lazy max + unit
-// scale), 2 = attn2.hip, 3..6 = the experiments kept for A/B, 1 = attn.hip (icv_attention_fwd only).
-constexpr int ATTN_KERNEL_DEFAULT = 7;
-static int attn_route(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
-                      int64_t ldo, float* acc, int64_t ldacc, float* ml, int state_in, int state_out, int64_t Sq,
-                      int64_t Skv, int64_t heads, float scale, hipStream_t st) {
-#define ATT_ARGS q, ldq, k, ldk, v, ldv, o, ldo, acc, ldacc, ml, state_in, state_out, Sq, Skv, heads, scale
-  switch (icv_get_option_int("attn_kernel", ATTN_KERNEL_DEFAULT)) {
-    case 7: return icv_attn7_dispatch(ATT_ARGS, icv_get_option_int("attn7_variant", 0), st);
-    case 6: return icv_attn6_dispatch(ATT_ARGS, icv_get_option_int("attn6_variant", 5), st);
-    case 5: return icv_attn5_dispatch(ATT_ARGS, 0, st);
-    case 4: return icv_attn4_dispatch(ATT_ARGS, icv_get_option_int("attn4_variant", 4), st);
-    case 3: return icv_attn3_dispatch(ATT_ARGS, icv_get_option_int("attn3_variant", 0), st);
-    default: return icv_attn2_dispatch(ATT_ARGS, icv_get_option_int("attn2_variant", 12), st);
-  }
-#undef ATT_ARGS
-}
-
-extern "C" int icv_attention_fwd_chunk(const void* q, int64_t ldq, const void* k, int64_t ldk,
-                                       const void* v, int64_t ldv, void* o, int64_t ldo, float* acc,
-                                       int64_t ldacc, float* ml, int64_t Sq, int64_t Skv,
-                                       int64_t heads, float scale, int first, int last, void* stream) {
-  ICV_REQUIRE(q && k && v, "icv_attention_fwd_chunk: null pointer");
-  ICV_REQUIRE(Sq > 0 && Skv > 0 && heads > 0, "icv_attention_fwd_chunk: empty problem");
-  ICV_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0, "icv_attention_fwd_chunk: leading dims must keep 16-byte row alignment");
-  ICV_REQUIRE((first && last) || (acc && ml && ldacc % 4 == 0), "icv_attention_fwd_chunk: carried state buffers required unless first && last");
-  ICV_REQUIRE(!last || (o && ldo % 4 == 0), "icv_attention_fwd_chunk: output required for the last chunk");
-  return attn_route(q, ldq, k, ldk, v, ldv, o, ldo, acc, ldacc, ml, first ? 0 : 1, last ? 0 : 1, Sq, Skv, heads, scale, (hipStream_t)stream);
-}
-
-extern "C" int icv_attention_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk,
-                                 const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
-                                 int64_t Skv, int64_t heads, float scale, void* stream) {
-  ICV_REQUIRE(q && k && v && o, "icv_attention_fwd: null pointer");
-  ICV_REQUIRE(Sq > 0 && Skv > 0 && heads > 0, "icv_attention_fwd: empty problem (Sq=%lld Skv=%lld heads=%lld)", (long long)Sq, (long long)Skv, (long long)heads);
-  ICV_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "icv_attention_fwd: leading dims must keep 16-byte row alignment");
-  if (icv_get_option_int("attn_kernel", ATTN_KERNEL_DEFAULT) != 1)
-    return attn_route(q, ldq, k, ldk, v, ldv, o, ldo, nullptr, 0, nullptr, 0, 0, Sq, Skv, heads, scale, (hipStream_t)stream);
+// attn_kernel = 1: icv_attention_fwd only (no carried state)
+int icv_attn1_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
+                       int64_t ldo, int64_t Sq, int64_t Skv, int64_t heads, float scale, void* stream) {
   AttnParams p;
   p.q = (const bf16_t*)q; p.ldq = ldq; p.k = (const bf16_t*)k; p.ldk = ldk;
   p.v = (const bf16_t*)v; p.ldv = ldv; p.o = (bf16_t*)o; p.ldo = ldo;
@@ -378,13 +317,4 @@ extern "C" int icv_attention_fwd(const void* q, int64_t ldq, const void* k, int6
     default: icv_set_error("icv_attention_fwd: unknown attn_variant %d", var); return 1;
   }
   return icv_check_launch("icv_attention_fwd");
-}
-
-extern "C" int icv_attention_fwd_add(const void* q, int64_t ldq, const void* k, int64_t ldk,
-                                     const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
-                                     int64_t Skv, int64_t heads, float scale, void* stream) {
-  ICV_REQUIRE(q && k && v && o, "icv_attention_fwd_add: null pointer");
-  ICV_REQUIRE(Sq > 0 && Skv > 0 && heads > 0, "icv_attention_fwd_add: empty problem (Sq=%lld Skv=%lld heads=%lld)", (long long)Sq, (long long)Skv, (long long)heads);
-  ICV_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "icv_attention_fwd_add: leading dims must keep 16-byte row alignment");
-  return attn_route(q, ldq, k, ldk, v, ldv, o, ldo, nullptr, 0, nullptr, 0, 2, Sq, Skv, heads, scale, (hipStream_t)stream);
 }

@@ -197,9 +197,15 @@ extern "C" int icv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t 
   // quantisation-adjusted throughput; option gemm256 = 0 / 1 forces one kernel, 2 (default) = heuristic.
   if (N % 256 == 0 && M >= 256) {
     const int mode = icv_get_option_int("gemm256", 2);
-    if (mode == 3)   // experiment: 4 waves x (128 x 128), one wave per SIMD (gemm256w.hip)
+    if (mode == 3) {  // experiment: 4 waves x (128 x 128), one wave per SIMD (experiments/gemm256w.hip)
+#ifdef ICV_EXPERIMENTS
       return icv_gemm256w_dispatch(A, lda, W, ldw, bias, M, N, K, epilogue, out, ldo, nsplit, split_stride,
                                    resid, ldr, gate, (hipStream_t)stream);
+#else
+      icv_set_error("gemm256 = 3 is an experiment: rebuild libicvideo with ICV_EXPERIMENTS=1");
+      return 1;
+#endif
+    }
     bool use256 = mode == 1;
     if (mode == 2) {
       static int n_cu = 0;

@@ -155,7 +155,7 @@ def _run_block(hip_ops, model, grid, sl, gemm_dtype="bf16", attn_dtype="bf16"):
     u, ur = x_out - x_in, rx_out - rx_in                       # the block's update of the residual stream
     rel_in = float((x_in - rx_in).norm() / rx_in.norm())
     rel = float((u - ur).norm() / ur.norm())
-    cos = float(torch.nn.functional.cosine_similarity(u.flatten(), ur.flatten(), dim=0))
+    cos = float(torch.nn.functional.cosine_similarity(u.flatten().double(), ur.flatten().double(), dim=0))
     print(f"{model} S={grid.S} {gemm_dtype}/{attn_dtype}: block-update rel-L2 {rel:.4g}, cosine {cos:.6f}, "
           f"input rel-L2 {rel_in:.3g}, oracle {t_cpu:.1f}s on CPU")
     return rel_in, rel, cos
@@ -242,7 +242,7 @@ def test_config2_wan_1p3b_93f_480p(hip_ops):
     ref = ref.cpu()
     p = R.psnr(lat, ref)
     pf = frame_psnr(lat, ref, vae)
-    cos = float(torch.nn.functional.cosine_similarity((lat - noise).flatten(), (ref - noise).flatten(), dim=0))
+    cos = float(torch.nn.functional.cosine_similarity((lat - noise).flatten().double(), (ref - noise).flatten().double(), dim=0))
     print(f"config #2: HIP {t_hip:.1f}s, fp32 torch oracle on GPU {t_ref:.1f}s, latent PSNR {p:.1f} dB, "
           f"decoded-frame PSNR {pf:.1f} dB, update cosine {cos:.5f}")
     assert p >= 40.0 and pf >= 40.0 and cos >= 0.999, f"config #2 parity: latent {p:.1f} dB, frames {pf:.1f} dB, cosine {cos}"
