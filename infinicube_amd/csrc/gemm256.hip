@@ -11,6 +11,10 @@
 // unit image: [128 rows][8 chunks of 16 B], physical chunk = logical ^ ((row>>1)&7) applied on the
 // DMA *source* address and mirrored on ds_read_b128 (conflict-free, see gemm.hip).
 //
+// Two main-loop schedules (template SCH bit 0; A/B switch "gemm256_sched"):
+//   * SCH&1 (DEFAULT): two phases of 32 MFMAs per K-tile — half the barriers; measured +3.4..5 % on every DiT shape
+//     (14B QKV 1286 -> 1334, FFN1 1270 -> 1322 TF/s same box; see the loop for its RAW / WAR invariants);
+//   * the original four phases of 16 MFMAs, described here:
 // Per K-tile t (stage s = t&1), every phase = L-segment ; barrier ; 16 MFMA ; barrier :
 //   ph1: read a0,b0 | DMA B1(t+1)->s^1 | vmcnt(8) |  a0 x b0
 //   ph2: read b1    | DMA A1(t+1)->s^1 | vmcnt(8) |  a0 x b1
@@ -22,6 +26,10 @@
 //   WAR: a slot is re-staged >= 2 phases after its last ds_read (A0: read ph1, DMA ph3).
 //   Tail tiles re-load the last tile (clamped k) so the counted waits stay uniform.
 #include "icv_common.h"
+
+#ifndef G256_SCHED_DEFAULT
+#define G256_SCHED_DEFAULT 3
+#endif
 
 namespace g256 {
 
@@ -65,8 +73,12 @@ __device__ __forceinline__ void dma_unit(const char* __restrict__ base, const un
 }
 
 // MF = 16: v_mfma_f32_16x16x32_bf16 fragments (8x4 per wave);  MF = 32: v_mfma_f32_32x32x16_bf16 (4x2 per wave)
-template <int EPI, int MF>
+// SCH bit 0: two phases of 32 MFMAs per K-tile instead of four of 16 (half the barriers; see the loop);
+//     bit 1: RESID epilogue issues the residual loads of 16 fragments before consuming any (the A/B fragment
+//            registers are dead by then), instead of one load -> wait -> store round trip per fragment.
+template <int EPI, int MF, int SCH>
 __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
+  constexpr bool TWO_PHASE = (SCH & 1) != 0, BATCH_EPI = (SCH & 2) != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -151,7 +163,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
   dma_unit(Ab, offA[1], kbyte(0), smem + U_A1 * UNIT_BYTES, wave);
   dma_unit(Ab, offA[0], kbyte(1), smem + STAGE_BYTES + U_A0 * UNIT_BYTES, wave);
   dma_unit(Wb, offB[0], kbyte(1), smem + STAGE_BYTES + U_B0 * UNIT_BYTES, wave);
-  G256_VMCNT8();     // A0(0), B0(0) landed (4 younger units in flight)
+  if (TWO_PHASE) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // A0(0), B0(0), B1(0) landed (3 younger units in flight)
+  else G256_VMCNT8();     // A0(0), B0(0) landed (4 younger units in flight)
   G256_BARRIER();
   if (wr == 1) G256_BARRIER();  // stagger: group 1 runs one barrier behind group 0
 
@@ -175,6 +188,52 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
     __builtin_amdgcn_sched_barrier(0);                                                          \
   }
 
+  if (TWO_PHASE) {
+    // Two phases per K-tile t (stage s = t&1), each = L-segment ; barrier ; 32 MFMA ; barrier :
+    //   P1: read a0,b0,b1 | DMA B1(t+1),A1(t+1) -> s^1 | vmcnt(8) |  a0 x b0, a0 x b1
+    //   P2: read a1       | DMA A0(t+2),B0(t+2) -> s   | vmcnt(6) |  a1 x b0, a1 x b1
+    // RAW: A1(t) is retired by P1's vmcnt(8) (4 younger units stay in flight) and read in P2; B1(t+1) (and the older
+    //      A0/B0(t+1)) by P2's vmcnt(6) and read in P1(t+1): always one phase after the wait + barrier.
+    // WAR: A0/B0 of a stage are re-staged in the phase after their last read (P1 -> P2) — every L-segment therefore
+    //      retires its own ds_reads (lgkmcnt(0)) before its barrier, so no read is still pending when the other wave
+    //      group issues the DMA two barriers later; A1/B1 are re-staged three / four barriers after their last read.
+    for (int t = 0; t < nt; ++t) {
+      char* cur = smem + (t & 1) * STAGE_BYTES;
+      char* oth = smem + ((t + 1) & 1) * STAGE_BYTES;
+      // ---------------- phase 1: a0 x (b0, b1) ----------------
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+        for (int j = 0; j < NBF; ++j) {
+          b0f[j][ks] = *reinterpret_cast<const bf16x8*>(cur + U_B0 * UNIT_BYTES + b_off[ks] + j * FROWS);
+          b1f[j][ks] = *reinterpret_cast<const bf16x8*>(cur + U_B1 * UNIT_BYTES + b_off[ks] + j * FROWS);
+        }
+#pragma unroll
+        for (int i = 0; i < NAF; ++i)
+          af[i][ks] = *reinterpret_cast<const bf16x8*>(cur + U_A0 * UNIT_BYTES + a_off[ks] + i * FROWS);
+      }
+      dma_unit(Wb, offB[1], kbyte(t + 1), oth + U_B1 * UNIT_BYTES, wave);
+      dma_unit(Ab, offA[1], kbyte(t + 1), oth + U_A1 * UNIT_BYTES, wave);
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      G256_BARRIER();
+      G256_MFMA(0, b0f, 0);
+      G256_MFMA(0, b1f, 1);
+      G256_BARRIER();
+      // ---------------- phase 2: a1 x (b0, b1) ----------------
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int i = 0; i < NAF; ++i)
+          af[i][ks] = *reinterpret_cast<const bf16x8*>(cur + U_A1 * UNIT_BYTES + a_off[ks] + i * FROWS);
+      dma_unit(Ab, offA[0], kbyte(t + 2), cur + U_A0 * UNIT_BYTES, wave);
+      dma_unit(Wb, offB[0], kbyte(t + 2), cur + U_B0 * UNIT_BYTES, wave);
+      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+      G256_BARRIER();
+      G256_MFMA(1, b0f, 0);
+      G256_MFMA(1, b1f, 1);
+      G256_BARRIER();
+    }
+  } else
   for (int t = 0; t < nt; ++t) {
     char* cur = smem + (t & 1) * STAGE_BYTES;
     char* oth = smem + ((t + 1) & 1) * STAGE_BYTES;
@@ -256,7 +315,45 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
       }                                                                                                \
     }                                                                                                  \
   }
-  if (MF == 16) {
+  if (MF == 16 && EPI == ICV_EPI_RESID_F32 && BATCH_EPI) {
+    // x[m, n] = resid[m, n] + gate[n] * (acc + bias[n]) with the 16 residual loads of a half (4 x 4 fragments) in
+    // flight together: 64 VGPRs, the size of the dead A/B fragments.  N % 256 == 0 here, so every n is in range;
+    // rows past M (partial last m-tile) load a clamped row and skip the store.
+    float4 bs[4], gt[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + wc * 64 + (j >> 1) * 32 + (j & 1) * 16 + kq * 4;
+      bs[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      gt[j] = p.gate ? *reinterpret_cast<const float4*>(p.gate + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      float4 rs[4][4];
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const int64_t m = m0 + wr * 128 + hf * 64 + ii * 16 + fr;
+        const int64_t mc = m < p.M ? m : p.M - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          rs[ii][j] = *reinterpret_cast<const float4*>(p.resid + mc * p.ldr + n0 + wc * 64 + (j >> 1) * 32 + (j & 1) * 16 + kq * 4);
+      }
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const int64_t m = m0 + wr * 128 + hf * 64 + ii * 16 + fr;
+        if (m < p.M) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int64_t n = n0 + wc * 64 + (j >> 1) * 32 + (j & 1) * 16 + kq * 4;
+            const f32x4 a = acc[hf * 4 + ii][j];
+            const float4 r = rs[ii][j];
+            *reinterpret_cast<float4*>((float*)p.out + m * p.ldo + n) =
+                make_float4(r.x + gt[j].x * (a[0] + bs[j].x), r.y + gt[j].y * (a[1] + bs[j].y),
+                            r.z + gt[j].z * (a[2] + bs[j].z), r.w + gt[j].w * (a[3] + bs[j].w));
+          }
+        }
+      }
+    }
+  } else if (MF == 16) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -277,11 +374,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
 #undef G256_EMIT
 }
 
-template <int EPI, int MF>
+template <int EPI, int MF, int SCH>
 int launch(const Params& p, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI, MF>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI, MF, SCH>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) {
       icv_set_error("gemm256: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -290,7 +387,7 @@ int launch(const Params& p, hipStream_t st) {
     attr_set = true;
   }
   const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL((gemm256_kernel<EPI, MF>), dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p);
+  hipLaunchKernelGGL((gemm256_kernel<EPI, MF, SCH>), dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p);
   return icv_check_launch("icv_gemm_bf16(256)");
 }
 
@@ -309,12 +406,24 @@ int icv_gemm256_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw,
   p.tiles_n = (int)((N + g256::BN - 1) / g256::BN);
   p.gm = icv_get_option_int("gemm256_gm", 4);
   const bool m32 = icv_get_option_int("gemm256_mfma", 16) == 32;
+  // schedule variant (A/B switch "gemm256_sched"): bit 0 = two 32-MFMA phases per K-tile, bit 1 = batched residual loads
+  const int sch = icv_get_option_int("gemm256_sched", G256_SCHED_DEFAULT) & 3;
+#define G256_CASE(E_)                                                                              \
+  case E_:                                                                                         \
+    if (m32) return g256::launch<E_, 32, 0>(p, st);                                                \
+    switch (sch) {                                                                                 \
+      case 0: return g256::launch<E_, 16, 0>(p, st);                                               \
+      case 1: return g256::launch<E_, 16, 1>(p, st);                                               \
+      case 2: return g256::launch<E_, 16, 2>(p, st);                                               \
+      default: return g256::launch<E_, 16, 3>(p, st);                                              \
+    }
   switch (epilogue) {
-    case ICV_EPI_BF16: return m32 ? g256::launch<ICV_EPI_BF16, 32>(p, st) : g256::launch<ICV_EPI_BF16, 16>(p, st);
-    case ICV_EPI_GELU_BF16: return m32 ? g256::launch<ICV_EPI_GELU_BF16, 32>(p, st) : g256::launch<ICV_EPI_GELU_BF16, 16>(p, st);
-    case ICV_EPI_RESID_F32: return m32 ? g256::launch<ICV_EPI_RESID_F32, 32>(p, st) : g256::launch<ICV_EPI_RESID_F32, 16>(p, st);
-    case ICV_EPI_F32: return m32 ? g256::launch<ICV_EPI_F32, 32>(p, st) : g256::launch<ICV_EPI_F32, 16>(p, st);
+    G256_CASE(ICV_EPI_BF16)
+    G256_CASE(ICV_EPI_GELU_BF16)
+    G256_CASE(ICV_EPI_RESID_F32)
+    G256_CASE(ICV_EPI_F32)
   }
+#undef G256_CASE
   icv_set_error("icv_gemm_bf16: unknown epilogue %d", epilogue);
   return 1;
 }

@@ -79,7 +79,8 @@ def generate_rgb_semantic_buffer(semantics_rgb: np.ndarray, instance_buffer) -> 
         lut[int(iid) & 0xffff] = (np.array(c) * 255).astype(np.uint8)
     sem = torch.from_numpy(np.ascontiguousarray(semantics_rgb, dtype=np.uint8)).to(dev)
     out = torch.empty_like(sem)
-    native.check(lib.icv_instance_overlay_u8(sem.data_ptr(), inst.data_ptr(), inst.numel(), torch.from_numpy(lut).to(dev).data_ptr(),
+    lut_d = torch.from_numpy(lut).to(dev)      # kept in a local: the launch below is asynchronous
+    native.check(lib.icv_instance_overlay_u8(sem.data_ptr(), inst.data_ptr(), inst.numel(), lut_d.data_ptr(),
                                              out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "icv_instance_overlay_u8")
     torch.cuda.synchronize(dev)
     return out.cpu().numpy()

@@ -58,15 +58,29 @@ class ContextKV:
 
 class WanDiT:
     FP8_WEIGHTS = ("wqkv", "wo", "xq_w", "xo_w", "f0_w", "f2_w")
+    # Default e4m3 set of the fp8 mode: everything but FFN2.  Measured at the real 1.3B depth (config #1, 10 steps, vs the
+    # bf16 path; tools/fp8_subset_study.py): each FFN GEMM alone costs 43.3 dB, every other projection 52-57 dB; all six
+    # 39.8 dB (under the 40 dB bar), all but FFN2 42.6 dB.  FFN2 is the one to leave in bf16: its A operand (the GELU
+    # output, [S, ffn]) would need a separate quantise pass, FFN1's comes out of the LayerNorm kernel already in e4m3.
+    FP8_DEFAULT = ("wqkv", "wo", "xq_w", "xo_w", "f0_w")
 
     def __init__(self, cfg: WanDiTConfig, state_dict: Dict[str, torch.Tensor], ops,
                  buffer_embedder_sd: Optional[Dict[str, torch.Tensor]] = None, gemm_dtype: str = "bf16",
-                 attn_dtype: str = "bf16"):
+                 attn_dtype: str = "bf16", fp8_weights: Optional[tuple] = None):
         self.cfg = cfg.validate()
         self.ops = ops
         if gemm_dtype not in ("bf16", "fp8"):
             raise ValueError(f"gemm_dtype must be 'bf16' or 'fp8', got {gemm_dtype!r}")
         self.fp8 = gemm_dtype == "fp8"
+        # which of the six per-layer projections run in e4m3 when gemm_dtype == "fp8" (default FP8_DEFAULT; ICV_FP8_WEIGHTS=
+        # "wqkv,f0_w,..." or the fp8_weights argument overrides it: e4m3 has 3 mantissa bits, so every quantised GEMM adds
+        # ~3-5 % relative noise to its output however fine the scales are - DESIGN.md §8 has the accuracy / speed table)
+        env = os.environ.get("ICV_FP8_WEIGHTS")
+        sel = fp8_weights if fp8_weights is not None else (tuple(x for x in env.split(",") if x) if env else self.FP8_DEFAULT)
+        bad = [x for x in sel if x not in self.FP8_WEIGHTS]
+        if bad:
+            raise ValueError(f"fp8_weights: unknown projection(s) {bad}; choose from {self.FP8_WEIGHTS}")
+        self.fp8_set = tuple(sel) if self.fp8 else ()
         if attn_dtype not in ("bf16", "fp8"):
             raise ValueError(f"attn_dtype must be 'bf16' or 'fp8', got {attn_dtype!r}")
         # fp8 self-attention (e4m3 Q/K/V/P on the K=64 scaled MFMA, csrc/attn8.hip), single-rank and sequence-parallel
@@ -124,7 +138,7 @@ class WanDiT:
                 f2_w=W(f"{p}.ffn.2.weight"), f2_b=V(f"{p}.ffn.2.bias"),
             )
             if self.fp8:                                  # e4m3 rows + per-output-channel scale; bf16 copy dropped
-                for nm in self.FP8_WEIGHTS:
+                for nm in self.fp8_set:
                     lw[nm] = self._quantize_weight(lw[nm])
             if cfg.has_image_input:
                 lw["xkv_img_w"] = torch.cat([W(f"{ca}.k_img.weight"), W(f"{ca}.v_img.weight")], 0).contiguous()
@@ -147,17 +161,18 @@ class WanDiT:
 
     # GEMM operands are either a bf16 tensor or an (e4m3 rows, f32 row scales) pair; these three helpers keep
     # forward_tokens identical for both GEMM dtypes.
-    def _norm(self, **kw):
-        """K3 / K8: LayerNorm(+affine)(+modulate) of the residual stream into the next GEMM's A operand."""
-        if self.fp8:
+    def _norm(self, w, **kw):
+        """K3 / K8: LayerNorm(+affine)(+modulate) of the residual stream into the A operand of the GEMM with weight
+        ``w`` (e4m3 rows + scales when that weight is quantised, bf16 otherwise)."""
+        if isinstance(w, tuple):
             self.ops.ln_modulate_fp8(self.x, self.h8, self.h8s, **kw)
             return (self.h8, self.h8s)
         self.ops.ln_modulate(self.x, self.h, **kw)
         return self.h
 
-    def _operand(self, t: torch.Tensor, q8: Optional[torch.Tensor], s8: Optional[torch.Tensor]):
-        """bf16 activation produced by attention / the GELU epilogue -> GEMM A operand."""
-        if self.fp8:
+    def _operand(self, t: torch.Tensor, q8: Optional[torch.Tensor], s8: Optional[torch.Tensor], w):
+        """bf16 activation produced by attention / the GELU epilogue -> A operand of the GEMM with weight ``w``."""
+        if isinstance(w, tuple):
             self.ops.quantize_rows(t, q8, s8)
             return (q8, s8)
         return t
@@ -451,7 +466,7 @@ class WanDiT:
             sh1, sc1, g1 = m[0:d], m[d:2 * d], m[2 * d:3 * d]
             sh2, sc2, g2 = m[3 * d:4 * d], m[4 * d:5 * d], m[5 * d:6 * d]
             # --- self-attention ---
-            h = self._norm(shift=sh1, scale=sc1, eps=eps)                                   # K3
+            h = self._norm(lw["wqkv"], shift=sh1, scale=sc1, eps=eps)                       # K3
             if plan.world > 1:
                 # K and V first, so their all-gather (K13) is already moving while Q is projected
                 self._mm(h, lw["wqkv"], lw["bqkv"], self.kv_loc, EPI_BF16, rows=slice(d, 3 * d))            # K4 (k | v rows)
@@ -467,21 +482,21 @@ class WanDiT:
                     ops.attention_fp8(q, k, v, self.att, H, self.attn8_ws)                  # K6 (e4m3)
                 else:
                     ops.attention(q, k, v, self.att, H, scale)                              # K6
-            a = self._operand(self.att, self.att8, self.att8s)
+            a = self._operand(self.att, self.att8, self.att8s, lw["wo"])
             self._mm(a, lw["wo"], lw["bo"], self.x, EPI_RESID_F32, resid=self.x, gate=g1)   # K7
             # --- cross-attention to text (no gate) ---
-            h = self._norm(weight=lw["n3w"], bias=lw["n3b"], eps=eps)                       # K8
+            h = self._norm(lw["xq_w"], weight=lw["n3w"], bias=lw["n3b"], eps=eps)           # K8
             self._mm(h, lw["xq_w"], lw["xq_b"], q, EPI_BF16)                                # K9
             ops.rmsnorm_rope(q, lw["xnq"], eps=eps)
             ops.attention(q, ctx.k[i], ctx.v[i], self.att, H, scale)
             if ctx.k_img is not None:                                                      # i2v: + softmax over CLIP tokens
                 ops.attention_add(q, ctx.k_img[i], ctx.v_img[i], self.att, H, scale)
-            a = self._operand(self.att, self.att8, self.att8s)
+            a = self._operand(self.att, self.att8, self.att8s, lw["xo_w"])
             self._mm(a, lw["xo_w"], lw["xo_b"], self.x, EPI_RESID_F32, resid=self.x)
             # --- FFN ---
-            h = self._norm(shift=sh2, scale=sc2, eps=eps)                                   # K3
+            h = self._norm(lw["f0_w"], shift=sh2, scale=sc2, eps=eps)                       # K3
             self._mm(h, lw["f0_w"], lw["f0_b"], self.ff, EPI_GELU_BF16)                     # K10
-            a = self._operand(self.ff, self.ff8, self.ff8s)
+            a = self._operand(self.ff, self.ff8, self.ff8s, lw["f2_w"])
             self._mm(a, lw["f2_w"], lw["f2_b"], self.x, EPI_RESID_F32, resid=self.x, gate=g2)
         # K11: head
         ops.ln_modulate(self.x, self.h, shift=self.hmod[0], scale=self.hmod[1], eps=eps)

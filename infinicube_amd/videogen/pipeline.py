@@ -162,7 +162,9 @@ class WanVideoPipeline:
         # projections (BASELINE.json config #5).  Anything else = bf16, the reference's setting
         # [R infinicube/inference/guidance_buffer_generation.py:762].
         self.gemm_dtype = "fp8" if torch_dtype == torch.float8_e4m3fn else "bf16"
-        self.attn_dtype = self.gemm_dtype     # the fp8 mode also runs self-attention in e4m3 (no measurable accuracy cost)
+        # the fp8 mode also runs self-attention in e4m3 (no measurable accuracy cost: 60.1 dB alone) and quantises
+        # dit.WanDiT.FP8_DEFAULT = every projection but FFN2: 42.6 dB at the real 1.3B depth (all six: 39.8 dB, under the bar)
+        self.attn_dtype = self.gemm_dtype
         # multi-GPU layout when torch.distributed is initialised (seqpar.ParallelLayout): "auto" | "sp" | "cfg+sp"
         self.parallelism = os.environ.get("ICV_PARALLELISM", "auto")
         self.sp_chunks = int(os.environ.get("ICV_SP_CHUNKS", "4"))       # K/V exchange chunks per layer (overlap depth)

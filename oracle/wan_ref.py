@@ -170,6 +170,8 @@ def _lin(sd, name, x, dtype):
 
 # ---- fp8 GEMM mode of the build (BASELINE.json config #5 "fp8 MFMA weights"; not a behaviour of the reference) ----
 FP8_MAX = 448.0   # largest finite OCP e4m3 value
+FP8_ALL = ("wqkv", "wo", "xq_w", "xo_w", "f0_w", "f2_w")
+FP8_DEFAULT = ("wqkv", "wo", "xq_w", "xo_w", "f0_w")   # the build's default e4m3 set (FFN2 stays bf16)
 
 
 def quantize_rows_fp8(x: Tensor) -> Tuple[Tensor, Tensor]:
@@ -197,10 +199,16 @@ def _lin8(sd, name, x, dtype):
 def dit_block(sd: Dict[str, Tensor], cfg, i: int, x: Tensor, ctx: Tensor, t_mod: Tensor,
               freqs: Tensor, dtype=torch.float32, kv_override=None, ctx_img: Optional[Tensor] = None,
               fp8: bool = False) -> Tensor:
-    """``fp8``: the six projections applied to token rows (q/k/v, o, cross q, cross o, ffn.0, ffn.2) take
-    e4m3 row-quantised operands; the cross-attention K/V projections of the context stay unquantised."""
+    """``fp8``: which of the six projections applied to token rows take e4m3 row-quantised operands — True = all six,
+    or a tuple of the build's names ("wqkv" = q/k/v, "wo", "xq_w" = cross q, "xo_w" = cross o, "f0_w" = ffn.0,
+    "f2_w" = ffn.2); the cross-attention K/V projections of the context always stay unquantised."""
     p = f"blocks.{i}"
-    lin = _lin8 if fp8 else _lin
+    fp8_set = FP8_ALL if fp8 is True else (tuple(fp8) if fp8 else ())
+
+    def lin(sd_, name, x_, dtype_):
+        key = {"self_attn.q": "wqkv", "self_attn.k": "wqkv", "self_attn.v": "wqkv", "self_attn.o": "wo",
+               "cross_attn.q": "xq_w", "cross_attn.o": "xo_w", "ffn.0": "f0_w", "ffn.2": "f2_w"}[name.split(".", 2)[2]]
+        return (_lin8 if key in fp8_set else _lin)(sd_, name, x_, dtype_)
     mod = sd[f"{p}.modulation"].to(dtype).reshape(6, cfg.dim) + t_mod
     sh1, sc1, g1, sh2, sc2, g2 = mod.unbind(0)
     H, eps = cfg.num_heads, cfg.eps

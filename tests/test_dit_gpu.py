@@ -155,7 +155,7 @@ def test_fp8_gemm_mode_forward_and_loop(hip_ops):
     sdr, bsdr = R.round_state_dict_to_bf16(sd), R.round_state_dict_to_bf16(bsd)
     noise, c1, c2 = syn.make_latent_noise(grid), syn.make_text_context(cfg, 1), syn.make_text_context(cfg, 2)
     bl, clip, y = syn.make_buffer_latents(cfg, grid), syn.make_clip_features(cfg), syn.make_cond_latents(cfg, grid)
-    m = WanDiT(cfg, sd, hip_ops, bsd, gemm_dtype="fp8").prepare(grid)
+    m = WanDiT(cfg, sd, hip_ops, bsd, gemm_dtype="fp8", fp8_weights=WanDiT.FP8_WEIGHTS).prepare(grid)
     ck, cu = m.encode_context(c1, clip), m.encode_context(c2, clip)
     add = m.embed_cond_latents(y, add_to=m.embed_buffers(bl))
     lat = noise.to("cuda:0")
@@ -216,7 +216,7 @@ def test_sequence_parallel_path_on_one_gpu(hip_ops, chunks, model, gemm_dtype):
 
     hip_ops.attention_fp8 = recording_attention8
     try:
-        full = WanDiT(cfg, sd, hip_ops, bsd, gemm_dtype=gemm_dtype, attn_dtype=attn_dtype).prepare(grid, graphs=False)   # ops are wrapped: no capture
+        full = WanDiT(cfg, sd, hip_ops, bsd, gemm_dtype=gemm_dtype, attn_dtype=attn_dtype, fp8_weights=WanDiT.FP8_WEIGHTS).prepare(grid, graphs=False)   # ops are wrapped: no capture
         lat = noise.to("cuda:0")
         full.forward_tokens(lat, full.encode_context(ctx, clip), 300.0, additive(full), full.head_out[0])
         torch.cuda.synchronize()
@@ -255,7 +255,7 @@ def test_sequence_parallel_path_on_one_gpu(hip_ops, chunks, model, gemm_dtype):
             def wait(self, handle):
                 pass
 
-        m = WanDiT(cfg, sd, hip_ops, bsd, gemm_dtype=gemm_dtype, attn_dtype=attn_dtype).prepare(grid, plan, kv_gather=FakeGather(), sp_chunks=chunks)
+        m = WanDiT(cfg, sd, hip_ops, bsd, gemm_dtype=gemm_dtype, attn_dtype=attn_dtype, fp8_weights=WanDiT.FP8_WEIGHTS).prepare(grid, plan, kv_gather=FakeGather(), sp_chunks=chunks)
         m.forward_tokens(lat, m.encode_context(ctx, clip), 300.0, additive(m), m.head_out[0])
         torch.cuda.synchronize()
         outs.append(m.head_out[0].clone())
@@ -360,36 +360,29 @@ def test_config1_wan_1p3b_17f_256p_10_steps(hip_ops):
     cos = float(torch.nn.functional.cosine_similarity((lat.cpu() - noise).flatten(), (ref - noise).flatten(), dim=0))
     print(f"config #1: GPU {t_gpu:.2f}s, CPU oracle {t_cpu:.1f}s, PSNR {p:.1f} dB, update cosine {cos:.5f}")
     assert p >= 40.0 and cos >= 0.999, f"config #1 parity: PSNR {p:.1f} dB, cosine {cos}"
-    # the fp8-projection mode at the same REAL depth (30 layers): what the e4m3 quantisation itself costs against
-    # the unquantised fp32 oracle (reported; its kernel-arithmetic parity is pinned by test_fp8_gemm_mode_*)
+    # The fp8 mode (what torch_dtype=float8_e4m3fn selects: e4m3 self-attention + the DEFAULT e4m3 projection set, FFN2 in
+    # bf16) at the same REAL depth must also meet the 40 dB bar against the UNQUANTISED fp32 oracle.
     del m
-    m8 = WanDiT(cfg, sd, hip_ops, bsd, gemm_dtype="fp8").prepare(grid)
-    lat8 = noise.clone().to("cuda:0")
-    m8.denoise(lat8, m8.encode_context(c1), m8.encode_context(c2), m8.embed_buffers(bl), FlowMatchScheduler(steps), 5.0)
-    torch.cuda.synchronize()
-    p8 = R.psnr(lat8.cpu(), ref)
-    cos8 = float(torch.nn.functional.cosine_similarity((lat8.cpu() - noise).flatten(), (ref - noise).flatten(), dim=0))
-    print(f"config #1, fp8 projections: PSNR vs unquantised fp32 oracle {p8:.1f} dB, update cosine {cos8:.5f}")
-    assert p8 >= 25.0 and cos8 >= 0.99, f"fp8 mode drifted further than e4m3 rounding explains: PSNR {p8:.1f} dB, cosine {cos8}"
-    # ... and with the self-attention in e4m3 as well (attn8.hip)
-    del m8
-    m9 = WanDiT(cfg, sd, hip_ops, bsd, gemm_dtype="fp8", attn_dtype="fp8").prepare(grid)
-    lat9 = noise.clone().to("cuda:0")
-    m9.denoise(lat9, m9.encode_context(c1), m9.encode_context(c2), m9.embed_buffers(bl), FlowMatchScheduler(steps), 5.0)
-    torch.cuda.synchronize()
-    p9 = R.psnr(lat9.cpu(), ref)
-    cos9 = float(torch.nn.functional.cosine_similarity((lat9.cpu() - noise).flatten(), (ref - noise).flatten(), dim=0))
-    print(f"config #1, fp8 projections + fp8 self-attention: PSNR vs unquantised fp32 oracle {p9:.1f} dB, update cosine {cos9:.5f}")
-    assert p9 >= 22.0 and cos9 >= 0.98, f"fp8 attention mode: PSNR {p9:.1f} dB, cosine {cos9}"
-    # ... and the e4m3 self-attention alone (bf16 projections): isolates what attention in fp8 costs
-    del m9
-    ma = WanDiT(cfg, sd, hip_ops, bsd, attn_dtype="fp8").prepare(grid)
-    lata = noise.clone().to("cuda:0")
-    ma.denoise(lata, ma.encode_context(c1), ma.encode_context(c2), ma.embed_buffers(bl), FlowMatchScheduler(steps), 5.0)
-    torch.cuda.synchronize()
-    pa = R.psnr(lata.cpu(), ref)
-    print(f"config #1, bf16 projections + fp8 self-attention: PSNR vs unquantised fp32 oracle {pa:.1f} dB")
-    assert pa >= 30.0
+
+    def run(**kw):
+        mm = WanDiT(cfg, sd, hip_ops, bsd, **kw).prepare(grid)
+        l8 = noise.clone().to("cuda:0")
+        mm.denoise(l8, mm.encode_context(c1), mm.encode_context(c2), mm.embed_buffers(bl), FlowMatchScheduler(steps), 5.0)
+        torch.cuda.synchronize()
+        l8 = l8.cpu()
+        return R.psnr(l8, ref), float(torch.nn.functional.cosine_similarity((l8 - noise).flatten().double(), (ref - noise).flatten().double(), dim=0))
+
+    assert WanDiT.FP8_DEFAULT == ("wqkv", "wo", "xq_w", "xo_w", "f0_w")
+    pd, cd = run(gemm_dtype="fp8", attn_dtype="fp8")
+    print(f"config #1, fp8 mode (default set {WanDiT.FP8_DEFAULT} + e4m3 self-attention): PSNR vs unquantised fp32 oracle {pd:.1f} dB, cosine {cd:.5f}")
+    assert pd >= 40.0 and cd >= 0.995, f"the default fp8 mode misses the 40 dB bar at 1.3B depth: {pd:.1f} dB, cosine {cd}"
+    # reported (and loosely bounded): every projection in e4m3, and the e4m3 self-attention alone
+    p6, c6 = run(gemm_dtype="fp8", attn_dtype="fp8", fp8_weights=WanDiT.FP8_WEIGHTS)
+    print(f"config #1, all six projections + self-attention in e4m3: {p6:.1f} dB, cosine {c6:.5f}")
+    assert p6 >= 25.0 and c6 >= 0.98
+    pa, _ = run(attn_dtype="fp8")
+    print(f"config #1, bf16 projections + fp8 self-attention: {pa:.1f} dB")
+    assert pa >= 50.0
 
 
 def test_generator_end_to_end_on_gpu(tmp_path, monkeypatch):

@@ -123,7 +123,7 @@ def _oracle_block_slice(sdr, bsdr, cfg, grid, noise, ctx, bl, clip, y, ts, sl, f
     ctx_img = R.image_embed(sdr, clip) if clip is not None else None
     freqs = R.rope_freqs_3d(cfg.head_dim, grid.T, grid.Hp, grid.Wp)
     p = "blocks.0"
-    lin = R._lin8 if fp8 else R._lin
+    lin = R._lin8 if (fp8 and "wqkv" in fp8) else R._lin
     mod = sdr[f"{p}.modulation"].reshape(6, cfg.dim) + t_mod
     h_all = R.modulate(R.layer_norm(x_all, None, None, cfg.eps), mod[0], mod[1])
     k_all = R.rope_apply(R.rms_norm(lin(sdr, f"{p}.self_attn.k", h_all, f32), sdr[f"{p}.self_attn.norm_k.weight"], cfg.eps), freqs, cfg.num_heads)
@@ -150,7 +150,7 @@ def _run_block(hip_ops, model, grid, sl, gemm_dtype="bf16", attn_dtype="bf16"):
     x_in = x_in.float().cpu()
     del m
     t0 = time.time()
-    rx_in, rx_out = _oracle_block_slice(sdr, bsdr, cfg, grid, noise, ctx, bl, clip, y, ts, sl, fp8=(gemm_dtype == "fp8"))
+    rx_in, rx_out = _oracle_block_slice(sdr, bsdr, cfg, grid, noise, ctx, bl, clip, y, ts, sl, fp8=(R.FP8_DEFAULT if gemm_dtype == "fp8" else False))
     t_cpu = time.time() - t0
     u, ur = x_out - x_in, rx_out - rx_in                       # the block's update of the residual stream
     rel_in = float((x_in - rx_in).norm() / rx_in.norm())

@@ -92,7 +92,7 @@ def test_fp8_gemm_mode_matches_fake_quant_oracle():
     sd, bsd = syn.make_dit_state_dict(cfg), syn.make_buffer_embedder_state_dict(cfg)
     noise, c1, bl = syn.make_latent_noise(GRID), syn.make_text_context(cfg, 1), syn.make_buffer_latents(cfg, GRID)
     clip, y = syn.make_clip_features(cfg), syn.make_cond_latents(cfg, GRID)
-    m = WanDiT(cfg, sd, OracleOps(), bsd, gemm_dtype="fp8").prepare(GRID)
+    m = WanDiT(cfg, sd, OracleOps(), bsd, gemm_dtype="fp8", fp8_weights=WanDiT.FP8_WEIGHTS).prepare(GRID)
     assert m.layers[0]["wqkv"][0].dtype == torch.float8_e4m3fn and m.layers[0]["wqkv"][1].shape == (3 * cfg.dim,)
     assert m.layers[0]["xkv_w"].dtype == torch.bfloat16            # context K/V projection stays bf16
     add = m.embed_cond_latents(y, add_to=m.embed_buffers(bl))
@@ -109,7 +109,7 @@ def test_fp8_gemm_mode_matches_fake_quant_oracle():
     with pytest.raises(ValueError, match="attn_dtype"):
         WanDiT(cfg, sd, OracleOps(), bsd, attn_dtype="fp4")
     # fp8 self-attention on top (host routing; the e4m3 attention oracle stands in for the kernel)
-    m2 = WanDiT(cfg, sd, OracleOps(), bsd, gemm_dtype="fp8", attn_dtype="fp8").prepare(GRID)
+    m2 = WanDiT(cfg, sd, OracleOps(), bsd, gemm_dtype="fp8", attn_dtype="fp8", fp8_weights=WanDiT.FP8_WEIGHTS).prepare(GRID)
     m2.forward_tokens(noise.clone(), m2.encode_context(c1, clip), 500.0, m2.embed_cond_latents(y, add_to=m2.embed_buffers(bl)), m2.head_out[0])
     v2 = R.unpatchify(m2.head_out[0], (GRID.T, GRID.Hp, GRID.Wp), cfg.out_dim)
     rel2 = float((v2 - ref).norm() / ref.norm())
@@ -146,7 +146,7 @@ def test_inprocess_two_shards_equal_unsharded(chunks, model, gemm_dtype):
         bt = m.embed_buffers(bl)
         return m.embed_cond_latents(ycond, add_to=bt) if ycond is not None else bt
 
-    full = WanDiT(CFG, sd, OracleOps(), bsd, gemm_dtype=gemm_dtype, attn_dtype=attn_dtype).prepare(GRID)
+    full = WanDiT(CFG, sd, OracleOps(), bsd, gemm_dtype=gemm_dtype, attn_dtype=attn_dtype, fp8_weights=WanDiT.FP8_WEIGHTS).prepare(GRID)
     full.forward_tokens(noise.clone(), full.encode_context(c1, clip), 300.0, additive(full), full.head_out[0])
     # lock-step emulation: layer-by-layer is awkward, so exploit determinism — shard r's K/V for layer i
     # equal rows [tok0, tok0+n) of the unsharded K/V; capture them from the full run via a recording ops.
@@ -162,7 +162,7 @@ def test_inprocess_two_shards_equal_unsharded(chunks, model, gemm_dtype):
             rec.setdefault("kv", []).append((k.clone(), v.clone()))
             super().attention_fp8(q, k, v, o, heads, ws)
 
-    f2 = WanDiT(CFG, sd, RecOps(), bsd, gemm_dtype=gemm_dtype, attn_dtype=attn_dtype).prepare(GRID)
+    f2 = WanDiT(CFG, sd, RecOps(), bsd, gemm_dtype=gemm_dtype, attn_dtype=attn_dtype, fp8_weights=WanDiT.FP8_WEIGHTS).prepare(GRID)
     f2.forward_tokens(noise.clone(), f2.encode_context(c1, clip), 300.0, additive(f2), f2.head_out[0])
     outs = []
     for r in range(2):
@@ -196,7 +196,7 @@ def test_inprocess_two_shards_equal_unsharded(chunks, model, gemm_dtype):
             def wait(self, handle):
                 pass
 
-        m = WanDiT(CFG, sd, OracleOps(), bsd, gemm_dtype=gemm_dtype, attn_dtype=attn_dtype)
+        m = WanDiT(CFG, sd, OracleOps(), bsd, gemm_dtype=gemm_dtype, attn_dtype=attn_dtype, fp8_weights=WanDiT.FP8_WEIGHTS)
         m.prepare(GRID, plan, kv_gather=FakeGather(), sp_chunks=chunks)   # world>1 without torch.distributed
         m.forward_tokens(noise.clone(), m.encode_context(c1, clip), 300.0, additive(m), m.head_out[0])
         outs.append(m.head_out[0].clone())
