@@ -1,6 +1,6 @@
 // Attention entry points of the C ABI (include/icvideo.h) and the kernel-family routing.
 //   7 = attn7.hip (default: LDS-DMA ring + lazy max + unit scale), 2 = attn2.hip (the previous default, register-staged
-//   128-key tile).  Families 1, 3, 4, 5, 6 are measured-slower experiments kept for A/B under experiments/; they are
+//   128-key tile).  Families 1, 3, 4, 5, 6, 9 are measured-slower (or tying) experiments kept for A/B under experiments/; they are
 //   compiled in only when the library is built with ICV_EXPERIMENTS=1 (csrc/build.sh) and otherwise report an error.
 #include "icv_common.h"
 
@@ -17,6 +17,10 @@ int icv_attn3_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, c
                        int state_out, int64_t Sq, int64_t Skv, int64_t heads, float scale, int var,
                        hipStream_t st);
 
+int icv_attn9_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                       void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml, int state_in,
+                       int state_out, int64_t Sq, int64_t Skv, int64_t heads, float scale, int var,
+                       hipStream_t st);
 int icv_attn7_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                        void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml, int state_in,
                        int state_out, int64_t Sq, int64_t Skv, int64_t heads, float scale, int var,
@@ -44,13 +48,14 @@ static int attn_route(const void* q, int64_t ldq, const void* k, int64_t ldk, co
   switch (icv_get_option_int("attn_kernel", ATTN_KERNEL_DEFAULT)) {
     case 7: return icv_attn7_dispatch(ATT_ARGS, icv_get_option_int("attn7_variant", 0), st);
 #ifdef ICV_EXPERIMENTS
+    case 9: return icv_attn9_dispatch(ATT_ARGS, icv_get_option_int("attn9_variant", 0), st);
     case 6: return icv_attn6_dispatch(ATT_ARGS, icv_get_option_int("attn6_variant", 5), st);
     case 5: return icv_attn5_dispatch(ATT_ARGS, 0, st);
     case 4: return icv_attn4_dispatch(ATT_ARGS, icv_get_option_int("attn4_variant", 4), st);
     case 3: return icv_attn3_dispatch(ATT_ARGS, icv_get_option_int("attn3_variant", 0), st);
 #else
-    case 6: case 5: case 4: case 3:
-      icv_set_error("attn_kernel 3..6 are experiments: rebuild libicvideo with ICV_EXPERIMENTS=1");
+    case 9: case 6: case 5: case 4: case 3:
+      icv_set_error("attn_kernel 3..6 and 9 are experiments: rebuild libicvideo with ICV_EXPERIMENTS=1");
       return 1;
 #endif
     default: return icv_attn2_dispatch(ATT_ARGS, icv_get_option_int("attn2_variant", 12), st);

@@ -158,3 +158,91 @@ def test_semantic_hip_matches_reference_golden():
     out = generate_rgb_semantic_buffer(sem_rgb, inst)
     assert np.array_equal(out[inst == 0], sem_rgb[inst == 0])
     assert len(np.unique(out[inst == 9].reshape(-1, 3), axis=0)) == 1
+
+
+@pytest.mark.gpu
+def test_buffer_kernel_throughput_report(capsys):
+    """Measurement, not a pass/fail bar (only sanity-bounded): HBM GB/s of the five guidance-buffer kernels at the
+    BASELINE buffer size 93 x 480 x 832, with the CPU restatement of the reference functions (oracle/buffer_ref.py)
+    timed beside them on this box's host.  The printed table is what profiles/r02/buffers.md holds."""
+    import ctypes
+    import time
+    from infinicube_amd import native
+    from infinicube_amd.utils import semantic_utils as su
+    lib = native.lib()
+    n, h, w = 93, 480, 832
+    px = n * h * w
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(0)
+    depth = torch.rand((n, h, w), generator=g) * 60 + 2
+    depth[:, :100] = 0
+    poses = torch.eye(4).repeat(n, 1, 1)
+    poses[:, 2, 3] = torch.arange(n) * 0.5
+    cam = Cam(700.0, 700.0, w / 2, h / 2)
+    d_dev = depth.to(dev)
+    cf = lambda a: (ctypes.c_float * len(a))(*[float(x) for x in a])   # noqa: E731
+    kinv = cf(torch.inverse(cam.get_intrinsics_matrix()).reshape(-1).tolist())
+    tf = poses.contiguous().to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    mask = torch.empty((px,), dtype=torch.uint8, device=dev)
+    idx = torch.arange(0, px, px // 100000, device=dev)[:100000].contiguous()
+    samp = torch.empty((idx.numel(), 3), device=dev)
+    of, ou = torch.empty((n, h, w, 3), device=dev), torch.empty((n, h, w, 3), dtype=torch.uint8, device=dev)
+    sem = torch.randint(0, 23, (px,), dtype=torch.int32, device=dev)
+    lut = torch.from_numpy(su.WAYMO_PALETTE[su.WAYMO_MAPPING]).to(dev).contiguous()
+    cf32 = torch.empty((px, 3), device=dev)
+    inst = torch.zeros((px,), dtype=torch.int32, device=dev)
+    inst[: px // 10] = 7
+    ilut = torch.zeros((65536, 3), dtype=torch.uint8, device=dev)
+    srgb = torch.randint(0, 255, (px, 3), dtype=torch.uint8, device=dev)
+    orgb = torch.empty_like(srgb)
+    du16 = torch.empty((px,), dtype=torch.uint16, device=dev)
+    mins, rngs = cf([-10.0, -5.0, 0.0]), cf([20.0, 10.0, 80.0])
+    cases = [
+        ("icv_coord_valid_mask", lambda: lib.icv_coord_valid_mask(d_dev.data_ptr(), kinv, tf.data_ptr(), n, h, w, mask.data_ptr(), st), px * (4 + 1)),
+        ("icv_coord_gather_points (100k samples)", lambda: lib.icv_coord_gather_points(d_dev.data_ptr(), kinv, tf.data_ptr(), n, h, w, idx.data_ptr(), idx.numel(), samp.data_ptr(), st), idx.numel() * (8 + 4 + 12)),
+        ("icv_coord_normalize -> f32", lambda: lib.icv_coord_normalize(d_dev.data_ptr(), kinv, tf.data_ptr(), n, h, w, mins, rngs, 1, of.data_ptr(), None, st), px * (4 + 12)),
+        ("icv_coord_normalize -> u8", lambda: lib.icv_coord_normalize(d_dev.data_ptr(), kinv, tf.data_ptr(), n, h, w, mins, rngs, 1, None, ou.data_ptr(), st), px * (4 + 3)),
+        ("icv_semantic_to_color -> f32", lambda: lib.icv_semantic_to_color(sem.data_ptr(), px, lut.data_ptr(), 23, cf32.data_ptr(), None, st), px * (4 + 12)),
+        ("icv_instance_overlay_u8", lambda: lib.icv_instance_overlay_u8(srgb.data_ptr(), inst.data_ptr(), px, ilut.data_ptr(), orgb.data_ptr(), st), px * (3 + 4 + 3)),
+        ("icv_depth_to_u16", lambda: lib.icv_depth_to_u16(d_dev.data_ptr(), px, 100.0, du16.data_ptr(), st), px * (4 + 2)),
+    ]
+    lines = ["| kernel | bytes / call (algorithmic) | us / call | GB/s | % of 8 TB/s |", "|---|---|---|---|---|"]
+    for name, fn, nbytes in cases:
+        for _ in range(3):
+            assert fn() == 0
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 20
+        gbs = nbytes / (us * 1e-6) / 1e9
+        lines.append(f"| {name} | {nbytes / 1e6:.1f} MB | {us:.1f} | {gbs:.0f} | {100 * gbs / 8000:.1f} |")
+        assert gbs > 50 or "gather" in name, f"{name}: {gbs:.0f} GB/s"
+    # the reference's CPU path (restated: oracle/buffer_ref.py), a 6-frame sample scaled to 93 frames
+    torch.manual_seed(0)
+    t0 = time.perf_counter()
+    B.coordinate_buffer_global_norm(depth[:6], cam.get_intrinsics_matrix(), poses[:6], 0.05)
+    t_coord = (time.perf_counter() - t0) * n / 6
+    semn = sem.cpu().numpy().reshape(n, h, w)
+    t0 = time.perf_counter()
+    B.semantic_to_color(semn[:6], su.WAYMO_MAPPING, su.WAYMO_PALETTE)
+    t_sem = (time.perf_counter() - t0) * n / 6
+    torch.manual_seed(0)
+    from infinicube_amd.utils.buffer_utils import generate_coordinate_buffer_from_memory_global_norm as gen
+    gen(d_dev, cam, poses, return_uint8=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gen(d_dev, cam, poses, return_uint8=True)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t0
+    lines += ["", f"whole `generate_coordinate_buffer_from_memory_global_norm` (depth resident in HBM, uint8 out, incl. host quantile of the 100k sample): {t_gen * 1e3:.1f} ms",
+              f"CPU restatement of the reference function (oracle/buffer_ref.py, torch CPU, {torch.get_num_threads()} threads; 6 frames scaled to 93): coordinate buffer {t_coord:.2f} s, semantic_to_color {t_sem:.2f} s"]
+    with capsys.disabled():
+        print("\n" + "\n".join(lines))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/buffers_throughput.md", "w") as f:
+        f.write("\n".join(lines) + "\n")

@@ -185,16 +185,7 @@ def test_layer_14b_i2v_720p(hip_ops, mode):
         assert cos >= 0.998 and rel <= 6e-2, f"14B i2v fp8 block at S=86400: rel-L2 {rel}, cosine {cos}"
 
 
-def _frames_u8(latent, vae):
-    v = vae.decode(latent.float().cpu())
-    return ((v.clamp(-1, 1) + 1.0) * 127.5).round().to(torch.uint8)
-
-
-def frame_psnr(lat_a, lat_b, vae):
-    """PSNR of the DECODED uint8 frames (peak 255), the same decoder on both arms."""
-    a, b = _frames_u8(lat_a, vae).double(), _frames_u8(lat_b, vae).double()
-    mse = float(((a - b) ** 2).mean())
-    return float("inf") if mse == 0 else 10.0 * math.log10(255.0 ** 2 / mse)
+from psnr_util import frame_psnr  # noqa: E402
 
 
 def test_config2_wan_1p3b_93f_480p(hip_ops):

@@ -24,7 +24,8 @@ def need_experiments(hip_ops):
         pytest.skip("libicvideo built without ICV_EXPERIMENTS=1")
 
 
-EXPERIMENT_KERNELS = (1, 3, 4, 5, 6)
+EXPERIMENT_KERNELS = (1, 3, 4, 5, 6, 9)
+ATTN_DEFAULT = 7   # icv_set_option("attn_kernel") value of the shipped default (tests restore it after an A/B switch)
 
 
 def rnd(shape, seed, std=1.0, dtype=torch.float32):
@@ -279,7 +280,7 @@ def test_attention_variants(hip_ops, variant, thr):
         hip_ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), o2, H, 1.0 / math.sqrt(128))
         torch.cuda.synchronize()
     finally:
-        hip_ops.lib.icv_set_option(b"attn_kernel", 7)
+        hip_ops.lib.icv_set_option(b"attn_kernel", ATTN_DEFAULT)
         hip_ops.lib.icv_set_option(b"attn_variant", 5)
         hip_ops.lib.icv_set_option(b"attn_defer_max_log2", 8)
     assert torch.equal(o, o2), "non-deterministic attention output (LDS staging race?)"
@@ -319,7 +320,7 @@ def test_attention2_variants(hip_ops, variant):
         assert torch.isfinite(o.float()).all()
         assert_bf16_close(o, ref, f"attn2 variant {variant} growing scores", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
     finally:
-        hip_ops.lib.icv_set_option(b"attn2_variant", 12); hip_ops.lib.icv_set_option(b"attn_kernel", 7)
+        hip_ops.lib.icv_set_option(b"attn2_variant", 12); hip_ops.lib.icv_set_option(b"attn_kernel", ATTN_DEFAULT)
 
 
 @pytest.mark.parametrize("variant", [0, 1, 4, 5, 6, 7])
@@ -328,7 +329,7 @@ def test_attention7_variants(hip_ops, variant):
     covered by test_attention_unit_scale[kernel 7]."""
     H = 2
     d = H * 128
-    hip_ops.lib.icv_set_option(b"attn_kernel", 7); hip_ops.lib.icv_set_option(b"attn7_variant", variant)
+    hip_ops.lib.icv_set_option(b"attn_kernel", ATTN_DEFAULT); hip_ops.lib.icv_set_option(b"attn7_variant", variant)
     try:
         for Sq, Skv in ((300, 1100), (64, 64), (257, 65), (33, 129), (513, 640), (1000, 3000), (1, 1)):
             q, k, v = (rnd((Sq, d), 191).to(torch.bfloat16), rnd((Skv, d), 192).to(torch.bfloat16), rnd((Skv, d), 193).to(torch.bfloat16))
@@ -342,13 +343,53 @@ def test_attention7_variants(hip_ops, variant):
             assert torch.equal(o, o2), "non-deterministic attention output (LDS-DMA ring race?)"
             assert_bf16_close(o, ref, f"attn7 variant {variant} Sq={Sq} Skv={Skv}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
     finally:
-        hip_ops.lib.icv_set_option(b"attn_kernel", 7); hip_ops.lib.icv_set_option(b"attn7_variant", 0)
+        hip_ops.lib.icv_set_option(b"attn_kernel", ATTN_DEFAULT); hip_ops.lib.icv_set_option(b"attn7_variant", 0)
 
 
-@pytest.mark.parametrize("kernel,unit", [(2, 1), (2, 0), (7, 1), (7, 0)])
+@pytest.mark.parametrize("variant", [0, 4])
+def test_attention9_variants(hip_ops, variant):
+    """attn9.hip (QK^T of the next 32-key block in the same basic block as the softmax of the current one) at the
+    generic scale: ragged sizes, spikes late in the sequence, scores that keep outgrowing the lazy reference, a row with
+    hugely negative scores; run-to-run determinism (LDS-DMA ring 3 tiles ahead).  Unit scale / carried state / minimum
+    sizes: the parametrised tests below."""
+    need_experiments(hip_ops)
+    H = 2
+    d = H * 128
+    hip_ops.lib.icv_set_option(b"attn_kernel", 9); hip_ops.lib.icv_set_option(b"attn9_variant", variant)
+    try:
+        for Sq, Skv in ((300, 1100), (64, 64), (257, 65), (33, 129), (513, 640), (1000, 3000), (1, 1), (40, 31), (256, 192), (70, 97)):
+            q, k, v = (rnd((Sq, d), 291).to(torch.bfloat16), rnd((Skv, d), 292).to(torch.bfloat16), rnd((Skv, d), 293).to(torch.bfloat16))
+            k[Skv - 1] = q[min(3, Sq - 1)] * 5.0
+            k[Skv // 2] = q[min(40, Sq - 1)] * 5.0
+            ref = R.attention(q.float(), k.float(), v.float(), H)
+            outs = []
+            for _ in range(3):
+                o = torch.zeros((Sq, d), dtype=torch.bfloat16, device=DEV)
+                hip_ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), o, H, 1.0 / math.sqrt(128))
+                outs.append(o)
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "non-deterministic attention output (LDS-DMA ring race?)"
+            assert_bf16_close(outs[0], ref, f"attn9 variant {variant} Sq={Sq} Skv={Skv}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
+        Sq, Skv = 130, 1500
+        q = rnd((Sq, d), 274).to(torch.bfloat16)
+        k = (rnd((Skv, d), 275) * torch.linspace(0.2, 6.0, Skv)[:, None]).to(torch.bfloat16)
+        k[:, :128] += (q[5, :128].float() * torch.linspace(0.0, 3.0, Skv)[:, None]).to(torch.bfloat16)
+        v = rnd((Skv, d), 276).to(torch.bfloat16)
+        q[7] = -8.0 * k[:, :].float().mean(0).to(torch.bfloat16)
+        ref = R.attention(q.float(), k.float(), v.float(), H)
+        o = torch.zeros((Sq, d), dtype=torch.bfloat16, device=DEV)
+        hip_ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), o, H, 1.0 / math.sqrt(128))
+        assert torch.isfinite(o.float()).all()
+        assert_bf16_close(o, ref, f"attn9 variant {variant} growing scores", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
+    finally:
+        hip_ops.lib.icv_set_option(b"attn_kernel", ATTN_DEFAULT); hip_ops.lib.icv_set_option(b"attn9_variant", 0)
+
+
+@pytest.mark.parametrize("kernel,unit", [(2, 1), (2, 0), (7, 1), (7, 0), (9, 1), (9, 0)])
 def test_attention_unit_scale(hip_ops, kernel, unit):
     """scale * log2(e) == 1 (the DiT folds the softmax scale into K and calls with scale = ln 2): the kernel then
     starts the S accumulator at -m_ref and takes exp2(S) directly.  Same answers as the generic path (unit=0)."""
+    if kernel in EXPERIMENT_KERNELS:
+        need_experiments(hip_ops)
     H = 2
     d = H * 128
     ln2, fold = math.log(2.0), (1.0 / math.sqrt(128)) * math.log2(math.e)
@@ -380,7 +421,7 @@ def test_attention_unit_scale(hip_ops, kernel, unit):
                                             first=(c == 0), last=(c == 2))
                 assert_bf16_close(o2, ref, f"unit-scale={unit} chunked Sq={Sq} Skv={Skv}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
     finally:
-        hip_ops.lib.icv_set_option(b"attn_unit_scale", 1); hip_ops.lib.icv_set_option(b"attn_kernel", 7)
+        hip_ops.lib.icv_set_option(b"attn_unit_scale", 1); hip_ops.lib.icv_set_option(b"attn_kernel", ATTN_DEFAULT)
 
 
 @pytest.mark.parametrize("variant", [0, 4])
@@ -404,7 +445,7 @@ def test_attention3_variants(hip_ops, variant):
             assert torch.equal(o, o2), "non-deterministic attention output (LDS staging race?)"
             assert_bf16_close(o, ref, f"attn3 variant {variant} Sq={Sq} Skv={Skv}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
     finally:
-        hip_ops.lib.icv_set_option(b"attn_kernel", 7)
+        hip_ops.lib.icv_set_option(b"attn_kernel", ATTN_DEFAULT)
         hip_ops.lib.icv_set_option(b"attn3_variant", 0)
 
 
@@ -430,7 +471,7 @@ def test_attention4_variants(hip_ops, variant):
             assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "non-deterministic output (DMA ring race?)"
             assert_bf16_close(outs[0], ref, f"attn4 variant {variant} Sq={Sq} Skv={Skv}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
     finally:
-        hip_ops.lib.icv_set_option(b"attn_kernel", 7)
+        hip_ops.lib.icv_set_option(b"attn_kernel", ATTN_DEFAULT)
         hip_ops.lib.icv_set_option(b"attn4_variant", 4)
 
 
@@ -454,10 +495,10 @@ def test_attention5(hip_ops):
             assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "non-deterministic output (hazard / DMA race?)"
             assert_bf16_close(outs[0], ref, f"attn5 Sq={Sq} Skv={Skv}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
     finally:
-        hip_ops.lib.icv_set_option(b"attn_kernel", 7)
+        hip_ops.lib.icv_set_option(b"attn_kernel", ATTN_DEFAULT)
 
 
-@pytest.mark.parametrize("kernel", [2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("kernel", [2, 3, 4, 5, 6, 7, 9])
 @pytest.mark.parametrize("chunks", [[700], [128, 572], [300, 100, 300], [64, 64, 64, 508]])
 def test_attention_chunked_state(hip_ops, chunks, kernel):
     """Splitting the KEY axis over several launches with carried (O, m, l) state must reproduce the
@@ -486,7 +527,7 @@ def test_attention_chunked_state(hip_ops, chunks, kernel):
                                     first=(j == 0), last=(j == len(order) - 1))
         torch.cuda.synchronize()
     finally:
-        hip_ops.lib.icv_set_option(b"attn_kernel", 7)
+        hip_ops.lib.icv_set_option(b"attn_kernel", ATTN_DEFAULT)
     assert_bf16_close(o, ref, f"chunked attention {chunks}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
 
 
@@ -596,10 +637,10 @@ def test_attention6_pingpong(hip_ops, variant):
             assert_bf16_close(o, ref, f"attn6 v{variant} Sq={Sq} Skv={Skv}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
             assert torch.equal(o, o2), "attn6 is not deterministic"
     finally:
-        hip_ops.lib.icv_set_option(b"attn_kernel", 7); hip_ops.lib.icv_set_option(b"attn6_variant", 5)
+        hip_ops.lib.icv_set_option(b"attn_kernel", ATTN_DEFAULT); hip_ops.lib.icv_set_option(b"attn6_variant", 5)
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("kernel", [1, 2, 3, 4, 5, 6, 7, 9])
 def test_attention_minimum_sizes(hip_ops, kernel):
     if kernel in EXPERIMENT_KERNELS:
         need_experiments(hip_ops)
@@ -614,7 +655,7 @@ def test_attention_minimum_sizes(hip_ops, kernel):
             assert_bf16_close(o[:Sq], ref, f"attention kernel {kernel} Sq={Sq} Skv={Skv}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
             assert bool((o[Sq:] == 9.0).all()), "wrote past the last query row"
     finally:
-        hip_ops.lib.icv_set_option(b"attn_kernel", 7)
+        hip_ops.lib.icv_set_option(b"attn_kernel", ATTN_DEFAULT)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -42,7 +42,9 @@ for name, Sq, Skv, H in cases:
     for rd in range(rounds):           # interleaved rounds: within-process A/B
         for vv in variants:
             # variant codes: <100 -> attn.hip variant; 1000+x -> attn2.hip variant x
-            if vv >= 7000:
+            if vv >= 9000:
+                ops.lib.icv_set_option(b"attn_kernel", 9); ops.lib.icv_set_option(b"attn9_variant", vv - 9000)
+            elif vv >= 7000:
                 ops.lib.icv_set_option(b"attn_kernel", 7); ops.lib.icv_set_option(b"attn7_variant", vv - 7000)
             elif vv >= 6000:
                 ops.lib.icv_set_option(b"attn_kernel", 6); ops.lib.icv_set_option(b"attn6_variant", vv - 6000)
