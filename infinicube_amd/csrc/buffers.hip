@@ -21,11 +21,9 @@ __device__ __forceinline__ float dot3(float a0, float b0, float a1, float b1, fl
   return __fadd_rn(__fadd_rn(__fmul_rn(a0, b0), __fmul_rn(a1, b1)), __fmul_rn(a2, b2));
 }
 
-__device__ __forceinline__ void point_cam0(const CoordParams& p, int64_t pix, float d, float out[3]) {
-  const int64_t hw = p.H * p.W;
-  const int n = (int)(pix / hw);
-  const int64_t r = pix - (int64_t)n * hw;
-  const float y = (float)(r / p.W), x = (float)(r % p.W);
+// One thread handles 4 consecutive pixels of a row (16-byte depth load, 16-byte stores); the grid is (x-quads, rows,
+// frames), so no 64-bit division is needed to recover (n, y, x) from a flat index.  W % 4 != 0 takes the scalar tail.
+__device__ __forceinline__ void point_cam0_xy(const CoordParams& p, int n, float x, float y, float d, float out[3]) {
   // rays = Kinv (x, y, 1).  Byte outputs must match the reference bit for bit, so every product and sum is rounded
   // separately, left to right, exactly like the reference's torch.matmul on these 3x3 / 4x4 operands (verified against
   // its CPU output: no fused multiply-add anywhere; tests/golden/make_coord_buffer_golden.py) — hence the explicit
@@ -40,13 +38,49 @@ __device__ __forceinline__ void point_cam0(const CoordParams& p, int64_t pix, fl
     out[i] = __fadd_rn(dot3(m[i * 4 + 0], cx, m[i * 4 + 1], cy, m[i * 4 + 2], cz), __fmul_rn(m[i * 4 + 3], 1.0f));
 }
 
-__global__ __launch_bounds__(256) void coord_valid_mask_kernel(CoordParams p, unsigned char* __restrict__ mask, int64_t total) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const float d = p.depth[i];
-  float pt[3];
-  point_cam0(p, i, d, pt);
-  mask[i] = (d != 0.f && pt[2] < 1e6f) ? 1 : 0;   // depth 0 = infinitely far (set to 1e7, filtered by z < 1e6)
+// flat pixel index -> point (the gather of <= 100000 sampled pixels)
+__device__ __forceinline__ void point_cam0(const CoordParams& p, int64_t pix, float d, float out[3]) {
+  const int64_t hw = p.H * p.W;
+  const int n = (int)(pix / hw);
+  const int64_t r = pix - (int64_t)n * hw;
+  point_cam0_xy(p, n, (float)(r % p.W), (float)(r / p.W), d, out);
+}
+
+// (frame, row, first x, pixel count <= 4) of this thread; false = out of range
+__device__ __forceinline__ bool quad(const CoordParams& p, int& n, int& y, int& x0, int& cnt, int64_t& base) {
+  n = blockIdx.z; y = blockIdx.y;
+  x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (x0 >= p.W) return false;
+  cnt = (int)(p.W - x0 < 4 ? p.W - x0 : 4);
+  base = ((int64_t)n * p.H + y) * p.W + x0;
+  return true;
+}
+
+__device__ __forceinline__ void load_depth4(const CoordParams& p, int64_t base, int cnt, bool vec, float d[4]) {
+  if (vec) {
+    const float4 v = *reinterpret_cast<const float4*>(p.depth + base);
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[j] = j < cnt ? p.depth[base + j] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void coord_valid_mask_kernel(CoordParams p, unsigned char* __restrict__ mask) {
+  int n, y, x0, cnt; int64_t base;
+  if (!quad(p, n, y, x0, cnt, base)) return;
+  const bool vec = cnt == 4 && (p.W & 3) == 0 && (((uintptr_t)p.depth & 15) | ((uintptr_t)mask & 3)) == 0;
+  float d[4];
+  load_depth4(p, base, cnt, vec, d);
+  unsigned char m[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float pt[3];
+    point_cam0_xy(p, n, (float)(x0 + j), (float)y, d[j], pt);
+    m[j] = (d[j] != 0.f && pt[2] < 1e6f) ? 1 : 0;   // depth 0 = infinitely far (set to 1e7, filtered by z < 1e6)
+  }
+  if (vec) *reinterpret_cast<uchar4*>(mask + base) = make_uchar4(m[0], m[1], m[2], m[3]);
+  else for (int j = 0; j < cnt; ++j) mask[base + j] = m[j];
 }
 
 __global__ __launch_bounds__(256) void coord_gather_kernel(CoordParams p, const int64_t* __restrict__ idx, int64_t n,
@@ -62,35 +96,62 @@ __global__ __launch_bounds__(256) void coord_gather_kernel(CoordParams p, const 
 __global__ __launch_bounds__(256) void coord_normalize_kernel(CoordParams p, float mn0, float mn1, float mn2, float rg0,
                                                               float rg1, float rg2, int has_valid,
                                                               float* __restrict__ out_f32,
-                                                              unsigned char* __restrict__ out_u8, int64_t total) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const float d = p.depth[i];
-  float v[3];
-  if (d == 0.f) {
-    v[0] = v[1] = v[2] = 1.0f;                      // sky
-  } else {
-    float pt[3];
-    point_cam0(p, i, d, pt);
-    const float mn[3] = {mn0, mn1, mn2}, rg[3] = {rg0, rg1, rg2};
+                                                              unsigned char* __restrict__ out_u8) {
+  int n, y, x0, cnt; int64_t base;
+  if (!quad(p, n, y, x0, cnt, base)) return;
+  const bool vec = cnt == 4 && (p.W & 3) == 0 &&
+                   (((uintptr_t)p.depth & 15) | ((uintptr_t)out_f32 & 15) | ((uintptr_t)out_u8 & 3)) == 0;
+  float d[4];
+  load_depth4(p, base, cnt, vec, d);
+  const float mn[3] = {mn0, mn1, mn2}, rg[3] = {rg0, rg1, rg2};
+  float v[12];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      if (has_valid) {
-        // (clamp((pt - min) / range * 2 - 1, -1, 1) + 1) / 2, torch's op order [R infinicube/utils/buffer_utils.py:246-252]
-        float t = __fsub_rn(__fmul_rn(__fdiv_rn(__fsub_rn(pt[c], mn[c]), rg[c]), 2.0f), 1.0f);
-        t = fminf(fmaxf(t, -1.0f), 1.0f);
-        v[c] = __fdiv_rn(__fadd_rn(t, 1.0f), 2.0f);
-      } else {
-        v[c] = __fmul_rn(pt[c], 0.5f);
+  for (int j = 0; j < 4; ++j) {
+    if (d[j] == 0.f) {
+      v[j * 3 + 0] = v[j * 3 + 1] = v[j * 3 + 2] = 1.0f;                      // sky
+    } else {
+      float pt[3];
+      point_cam0_xy(p, n, (float)(x0 + j), (float)y, d[j], pt);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (has_valid) {
+          // (clamp((pt - min) / range * 2 - 1, -1, 1) + 1) / 2, torch's op order [R infinicube/utils/buffer_utils.py:246-252]
+          float t = __fsub_rn(__fmul_rn(__fdiv_rn(__fsub_rn(pt[c], mn[c]), rg[c]), 2.0f), 1.0f);
+          t = fminf(fmaxf(t, -1.0f), 1.0f);
+          v[j * 3 + c] = __fmul_rn(__fadd_rn(t, 1.0f), 0.5f);   // == / 2.0 exactly (power of two), without the division sequence
+        } else {
+          v[j * 3 + c] = __fmul_rn(pt[c], 0.5f);
+        }
       }
     }
   }
-  if (out_f32) { out_f32[i * 3 + 0] = v[0]; out_f32[i * 3 + 1] = v[1]; out_f32[i * 3 + 2] = v[2]; }
-  if (out_u8) {   // the caller's `(buffer * 255).astype(np.uint8)`: truncation toward zero
-    out_u8[i * 3 + 0] = (unsigned char)(int)__fmul_rn(v[0], 255.0f);
-    out_u8[i * 3 + 1] = (unsigned char)(int)__fmul_rn(v[1], 255.0f);
-    out_u8[i * 3 + 2] = (unsigned char)(int)__fmul_rn(v[2], 255.0f);
+  if (out_f32) {
+    float* o = out_f32 + base * 3;
+    if (vec) {   // 12 floats = 48 contiguous bytes, 16-byte aligned (base % 4 == 0)
+      reinterpret_cast<float4*>(o)[0] = make_float4(v[0], v[1], v[2], v[3]);
+      reinterpret_cast<float4*>(o)[1] = make_float4(v[4], v[5], v[6], v[7]);
+      reinterpret_cast<float4*>(o)[2] = make_float4(v[8], v[9], v[10], v[11]);
+    } else {
+      for (int j = 0; j < cnt * 3; ++j) o[j] = v[j];
+    }
   }
+  if (out_u8) {   // the caller's `(buffer * 255).astype(np.uint8)`: truncation toward zero
+    unsigned char b[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) b[j] = (unsigned char)(int)__fmul_rn(v[j], 255.0f);
+    unsigned char* o = out_u8 + base * 3;
+    if (vec) {   // 12 bytes, 4-byte aligned
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        reinterpret_cast<unsigned*>(o)[q] = (unsigned)b[q * 4] | ((unsigned)b[q * 4 + 1] << 8) | ((unsigned)b[q * 4 + 2] << 16) | ((unsigned)b[q * 4 + 3] << 24);
+    } else {
+      for (int j = 0; j < cnt * 3; ++j) o[j] = b[j];
+    }
+  }
+}
+
+static inline dim3 quad_grid(int64_t N, int64_t H, int64_t W) {
+  return dim3((unsigned)((W + 1023) / 1024), (unsigned)H, (unsigned)N);
 }
 
 int fill(CoordParams& p, const float* depth, const float* kinv, const float* tf, int64_t N, int64_t H, int64_t W) {
@@ -106,8 +167,8 @@ extern "C" int icv_coord_valid_mask(const float* depth, const float* kinv_host9,
                                     int64_t N, int64_t H, int64_t W, unsigned char* mask, void* stream) {
   CoordParams p;
   if (int rc = fill(p, depth, kinv_host9, cam_to_cam0, N, H, W)) return rc;
-  const int64_t total = N * H * W;
-  hipLaunchKernelGGL(coord_valid_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, mask, total);
+  ICV_REQUIRE(H < 65536 && N < 65536, "icv_coord_valid_mask: H and N must be < 65536");
+  hipLaunchKernelGGL(coord_valid_mask_kernel, quad_grid(N, H, W), dim3(256), 0, (hipStream_t)stream, p, mask);
   return icv_check_launch("icv_coord_valid_mask");
 }
 
@@ -132,9 +193,9 @@ extern "C" int icv_coord_normalize(const float* depth, const float* kinv_host9, 
   const float z[3] = {0.f, 0.f, 0.f}, o[3] = {1.f, 1.f, 1.f};
   const float* mn = has_valid ? mins_host3 : z;
   const float* rg = has_valid ? ranges_host3 : o;
-  const int64_t total = N * H * W;
-  hipLaunchKernelGGL(coord_normalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p,
-                     mn[0], mn[1], mn[2], rg[0], rg[1], rg[2], has_valid, out_f32, out_u8, total);
+  ICV_REQUIRE(H < 65536 && N < 65536, "icv_coord_normalize: H and N must be < 65536");
+  hipLaunchKernelGGL(coord_normalize_kernel, quad_grid(N, H, W), dim3(256), 0, (hipStream_t)stream, p,
+                     mn[0], mn[1], mn[2], rg[0], rg[1], rg[2], has_valid, out_f32, out_u8);
   return icv_check_launch("icv_coord_normalize");
 }
 
@@ -148,16 +209,52 @@ __global__ __launch_bounds__(256) void semantic_color_kernel(const int* __restri
                                                              const float* __restrict__ lut, int n_classes,
                                                              float* __restrict__ out_f32,
                                                              unsigned char* __restrict__ out_u8) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  int c = sem[i];
-  c = c < 0 ? 0 : (c >= n_classes ? n_classes - 1 : c);
-  const float r = lut[c * 3 + 0], g = lut[c * 3 + 1], b = lut[c * 3 + 2];
-  if (out_f32) { out_f32[i * 3 + 0] = r; out_f32[i * 3 + 1] = g; out_f32[i * 3 + 2] = b; }
+  __shared__ float slut[64 * 3];        // the class -> colour table (23 x 3 for Waymo) staged once per block
+  const bool in_lds = n_classes <= 64;
+  if (in_lds) {
+    for (int t = threadIdx.x; t < n_classes * 3; t += 256) slut[t] = lut[t];
+    __syncthreads();
+  }
+  const float* tab = in_lds ? slut : lut;
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;   // 4 pixels per thread: 16-byte load, 16-byte stores
+  if (i0 >= n) return;
+  const int cnt = (int)(n - i0 < 4 ? n - i0 : 4);
+  const bool vec = cnt == 4 && (((uintptr_t)sem & 15) | ((uintptr_t)out_f32 & 15) | ((uintptr_t)out_u8 & 3)) == 0;
+  int c[4] = {0, 0, 0, 0};
+  if (vec) {
+    const int4 v = *reinterpret_cast<const int4*>(sem + i0);
+    c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+  } else {
+    for (int j = 0; j < cnt; ++j) c[j] = sem[i0 + j];
+  }
+  float v[12];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int cc = c[j] < 0 ? 0 : (c[j] >= n_classes ? n_classes - 1 : c[j]);
+    v[j * 3 + 0] = tab[cc * 3 + 0]; v[j * 3 + 1] = tab[cc * 3 + 1]; v[j * 3 + 2] = tab[cc * 3 + 2];
+  }
+  if (out_f32) {
+    float* o = out_f32 + i0 * 3;
+    if (vec) {
+      reinterpret_cast<float4*>(o)[0] = make_float4(v[0], v[1], v[2], v[3]);
+      reinterpret_cast<float4*>(o)[1] = make_float4(v[4], v[5], v[6], v[7]);
+      reinterpret_cast<float4*>(o)[2] = make_float4(v[8], v[9], v[10], v[11]);
+    } else {
+      for (int j = 0; j < cnt * 3; ++j) o[j] = v[j];
+    }
+  }
   if (out_u8) {   // the caller's (colour * 255).astype(uint8)
-    out_u8[i * 3 + 0] = (unsigned char)(int)(r * 255.0f);
-    out_u8[i * 3 + 1] = (unsigned char)(int)(g * 255.0f);
-    out_u8[i * 3 + 2] = (unsigned char)(int)(b * 255.0f);
+    unsigned char b[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) b[j] = (unsigned char)(int)__fmul_rn(v[j], 255.0f);
+    unsigned char* o = out_u8 + i0 * 3;
+    if (vec) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        reinterpret_cast<unsigned*>(o)[q] = (unsigned)b[q * 4] | ((unsigned)b[q * 4 + 1] << 8) | ((unsigned)b[q * 4 + 2] << 16) | ((unsigned)b[q * 4 + 3] << 24);
+    } else {
+      for (int j = 0; j < cnt * 3; ++j) o[j] = b[j];
+    }
   }
 }
 
@@ -165,17 +262,45 @@ __global__ __launch_bounds__(256) void instance_overlay_kernel(const unsigned ch
                                                                const int* __restrict__ inst, int64_t n,
                                                                const unsigned char* __restrict__ inst_lut,
                                                                unsigned char* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int id = inst[i] & 0xffff;
-  const unsigned char* src = id > 0 ? inst_lut + (int64_t)id * 3 : sem_rgb + i * 3;
-  out[i * 3 + 0] = src[0]; out[i * 3 + 1] = src[1]; out[i * 3 + 2] = src[2];
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;   // 4 pixels = 12 bytes of RGB in, 12 out
+  if (i0 >= n) return;
+  const int cnt = (int)(n - i0 < 4 ? n - i0 : 4);
+  const bool vec = cnt == 4 && (((uintptr_t)inst & 15) | ((uintptr_t)sem_rgb & 3) | ((uintptr_t)out & 3)) == 0;
+  unsigned char b[12];
+  int id[4] = {0, 0, 0, 0};
+  if (vec) {
+    const int4 v = *reinterpret_cast<const int4*>(inst + i0);
+    id[0] = v.x; id[1] = v.y; id[2] = v.z; id[3] = v.w;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const unsigned w = reinterpret_cast<const unsigned*>(sem_rgb + i0 * 3)[q];
+      b[q * 4] = w & 0xff; b[q * 4 + 1] = (w >> 8) & 0xff; b[q * 4 + 2] = (w >> 16) & 0xff; b[q * 4 + 3] = w >> 24;
+    }
+  } else {
+    for (int j = 0; j < cnt; ++j) {
+      id[j] = inst[i0 + j];
+      b[j * 3] = sem_rgb[(i0 + j) * 3]; b[j * 3 + 1] = sem_rgb[(i0 + j) * 3 + 1]; b[j * 3 + 2] = sem_rgb[(i0 + j) * 3 + 2];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = id[j] & 0xffff;
+    if (k > 0) { b[j * 3] = inst_lut[k * 3]; b[j * 3 + 1] = inst_lut[k * 3 + 1]; b[j * 3 + 2] = inst_lut[k * 3 + 2]; }
+  }
+  unsigned char* o = out + i0 * 3;
+  if (vec) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      reinterpret_cast<unsigned*>(o)[q] = (unsigned)b[q * 4] | ((unsigned)b[q * 4 + 1] << 8) | ((unsigned)b[q * 4 + 2] << 16) | ((unsigned)b[q * 4 + 3] << 24);
+  } else {
+    for (int j = 0; j < cnt * 3; ++j) o[j] = b[j];
+  }
 }
 
 extern "C" int icv_semantic_to_color(const int* semantics, int64_t n, const float* class_rgb_lut, int n_classes,
                                      float* out_f32, unsigned char* out_u8, void* stream) {
   ICV_REQUIRE(semantics && class_rgb_lut && n > 0 && n_classes > 0 && (out_f32 || out_u8), "icv_semantic_to_color: bad arguments");
-  hipLaunchKernelGGL(semantic_color_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(semantic_color_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream,
                      semantics, n, class_rgb_lut, n_classes, out_f32, out_u8);
   return icv_check_launch("icv_semantic_to_color");
 }
@@ -183,7 +308,7 @@ extern "C" int icv_semantic_to_color(const int* semantics, int64_t n, const floa
 extern "C" int icv_instance_overlay_u8(const unsigned char* semantics_rgb, const int* instance, int64_t n,
                                        const unsigned char* instance_rgb_lut65536, unsigned char* out, void* stream) {
   ICV_REQUIRE(semantics_rgb && instance && instance_rgb_lut65536 && out && n > 0, "icv_instance_overlay_u8: bad arguments");
-  hipLaunchKernelGGL(instance_overlay_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(instance_overlay_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream,
                      semantics_rgb, instance, n, instance_rgb_lut65536, out);
   return icv_check_launch("icv_instance_overlay_u8");
 }
