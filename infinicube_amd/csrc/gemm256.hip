@@ -410,7 +410,7 @@ int icv_gemm256_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw,
   const int sch = icv_get_option_int("gemm256_sched", G256_SCHED_DEFAULT) & 3;
 #define G256_CASE(E_)                                                                              \
   case E_:                                                                                         \
-    if (m32) return g256::launch<E_, 32, 0>(p, st);                                                \
+    if (m32) return (sch & 1) ? g256::launch<E_, 32, 1>(p, st) : g256::launch<E_, 32, 0>(p, st);   \
     switch (sch) {                                                                                 \
       case 0: return g256::launch<E_, 16, 0>(p, st);                                               \
       case 1: return g256::launch<E_, 16, 1>(p, st);                                               \

@@ -14,7 +14,8 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libicvideo.so")
+# ICV_LIB_PATH: load another build of the same ABI (e.g. csrc/build/libicvideo_experiments.so, which adds the A/B kernels)
+LIB_PATH = os.environ.get("ICV_LIB_PATH") or os.path.join(_HERE, "csrc", "libicvideo.so")
 
 EPI_BF16, EPI_GELU_BF16, EPI_RESID_F32, EPI_F32 = 0, 1, 2, 3
 ACT_NONE, ACT_SILU = 0, 1

@@ -237,3 +237,61 @@ def test_config2_wan_1p3b_93f_480p(hip_ops):
     print(f"config #2: HIP {t_hip:.1f}s, fp32 torch oracle on GPU {t_ref:.1f}s, latent PSNR {p:.1f} dB, "
           f"decoded-frame PSNR {pf:.1f} dB, update cosine {cos:.5f}")
     assert p >= 40.0 and pf >= 40.0 and cos >= 0.999, f"config #2 parity: latent {p:.1f} dB, frames {pf:.1f} dB, cosine {cos}"
+
+
+def test_config3_wan_14b_one_step_full_depth(hip_ops):
+    """BASELINE.json config #3 at FULL depth and size: Wan2.1-14B (40 layers, d = 5120), 93 f 480x832 (S = 37 440), ONE
+    denoise step = cond + uncond forward + CFG + Euler (the unit bench.py times), HIP vs oracle/wan_ref.py executed in
+    fp32 by stock PyTorch on the GPU (weights generated on the device: 28 GB bf16 for the product, the same values in
+    fp32 for the checker).  Bars: each forward's velocity cosine >= 0.999 and rel-L2 <= 2e-2 (one
+    forward); the CFG-combined velocity v_u + 5 (v_c - v_u) amplifies the difference of two nearly equal forwards five
+    times, so it is held to cosine >= 0.999 / rel-L2 <= 5e-2; latent after the step PSNR >= 40 dB."""
+    cfg, grid = preset("14b"), GRID_480P
+    sd = syn.make_dit_state_dict(cfg, seed=0, device=DEV, dtype=torch.bfloat16)
+    bsd = syn.make_buffer_embedder_state_dict(cfg, device=DEV, dtype=torch.bfloat16)
+    noise = syn.make_latent_noise(grid)
+    c1, c2, bl = syn.make_text_context(cfg, 1), syn.make_text_context(cfg, 2), syn.make_buffer_latents(cfg, grid)
+    sched = FlowMatchScheduler(50)
+    ts = float(sched.timesteps[0])
+    gshape = (grid.T, grid.Hp, grid.Wp)
+    m = WanDiT(cfg, sd, hip_ops, bsd).prepare(grid, graphs=False)
+    lat = noise.clone().to(DEV)
+    ck, cu, bt = m.encode_context(c1), m.encode_context(c2), m.embed_buffers(bl)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    m.forward_tokens(lat, ck, ts, bt, m.head_out[0])
+    m.forward_tokens(lat, cu, ts, bt, m.head_out[1])
+    vc_hip = R.unpatchify(m.head_out[0].cpu(), gshape, cfg.out_dim)
+    vu_hip = R.unpatchify(m.head_out[1].cpu(), gshape, cfg.out_dim)
+    hip_ops.unpatchify_cfg_euler(lat, m.head_out[0], m.head_out[1], 5.0, sched.dsigma(0), 0, grid.S)
+    torch.cuda.synchronize()
+    t_hip = time.time() - t0
+    lat = lat.cpu()
+    del m, ck, cu, bt
+    torch.cuda.empty_cache()
+    sdr = {k: v.float() for k, v in sd.items()}
+    bsdr = {k: v.float() for k, v in bsd.items()}
+    del sd, bsd
+    torch.cuda.empty_cache()
+    t0 = time.time()
+    buf = R.buffer_embed(bsdr, bl.to(DEV))
+    x = noise.to(DEV)
+    v_c = R.dit_forward(sdr, cfg, x, c1.to(DEV), ts, buf)
+    v_u = R.dit_forward(sdr, cfg, x, c2.to(DEV), ts, buf)
+    v = (v_u + 5.0 * (v_c - v_u)).cpu()
+    ref = noise + v * sched.dsigma(0)
+    v_c, v_u = v_c.cpu(), v_u.cpu()
+    torch.cuda.synchronize()
+    t_ref = time.time() - t0
+
+    def cmp(a, b):
+        return (float((a - b).norm() / b.norm()),
+                float(torch.nn.functional.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0)))
+
+    (rc, cc), (ru, cu_) = cmp(vc_hip, v_c), cmp(vu_hip, v_u)
+    rv, cv = cmp((lat - noise) / sched.dsigma(0), v)
+    p = R.psnr(lat, ref)
+    print(f"config #3, one step at full depth: HIP {t_hip:.1f}s, fp32 torch oracle on GPU {t_ref:.1f}s; cond forward rel-L2 {rc:.4g} cos {cc:.6f}; "
+          f"uncond forward rel-L2 {ru:.4g} cos {cu_:.6f}; CFG velocity rel-L2 {rv:.4g} cos {cv:.6f}; latent PSNR after the step {p:.1f} dB")
+    assert cc >= 0.999 and rc <= 2e-2 and cu_ >= 0.999 and ru <= 2e-2, f"config #3 forward parity: cond {rc}/{cc}, uncond {ru}/{cu_}"
+    assert cv >= 0.999 and rv <= 5e-2 and p >= 40.0, f"config #3 one-step parity: CFG velocity rel-L2 {rv}, cosine {cv}, PSNR {p:.1f} dB"
