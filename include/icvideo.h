@@ -216,6 +216,28 @@ int icv_instance_overlay_u8(const unsigned char* semantics_rgb, const int* insta
  * one rounded f32 multiply, truncation toward zero, wrap modulo 2^16.  depth f32 [n] (16-byte aligned), out u16 [n]. */
 int icv_depth_to_u16(const float* depth, int64_t n, float scale, unsigned short* out, void* stream);
 
+/* ---- voxel ray-cast of the guidance-buffer renderer ------------------------------------------
+ * Replaces the three fVDB-bound calls of `generate_infinicube_buffer_from_fvdb_grid`
+ * [R infinicube/utils/fvdb_utils.py:572-605]: `get_zdepth_map_from_voxel` (`segments_along_rays(o, d, 1, eps=1e-1)`
+ * [R infinicube/camera/base.py:520-571]) and `get_semantic_map_from_voxel` x 2 (`voxels_along_rays(o, d, 1, eps=1e-2)`
+ * [R infinicube/camera/base.py:573-619]) on a grid built by `points_to_fvdb` [R infinicube/utils/fvdb_utils.py:71-215].
+ * The voxel world is a DENSE int32 index volume in HBM (vol[z][y][x] = voxel index or -1; dims multiples of 8) plus one
+ * occupancy byte per 8^3 brick.
+ * icv_voxel_scatter: ijk i32 [M,3] (unique occupied voxels) -> vol / bricks (pre-filled with -1 / 0); vol_min3 = ijk of
+ *   cell (0,0,0) of the volume (host ints), dims3 = (Dx, Dy, Dz).
+ * icv_voxel_raycast: grid_lo3 = world coordinate of the low corner of cell (0,0,0), voxel_size3 (host floats);
+ *   rays_cam f32 [HW,3] = the camera model's normalised rays, poses f32 [N,16] camera-to-world (device);
+ *   depth_out f32 [N,HW] = z-depth of the first occupied run longer than eps_depth (0 = none);
+ *   attrK_out i32 [N,HW] = attrK[voxel] of the first occupied voxel crossed for more than eps_voxel, else backgroundK;
+ *   index_out = that voxel's index or -1.  Outputs may be NULL. */
+int icv_voxel_scatter(const int* ijk, int64_t M, const int* vol_min3, const int* dims3, int* vol,
+                      unsigned char* bricks, void* stream);
+int icv_voxel_raycast(const int* vol, const unsigned char* bricks, const int* dims3, const float* grid_lo3,
+                      const float* voxel_size3, const float* rays_cam, const float* poses, int64_t N,
+                      int64_t HW, float eps_depth, float eps_voxel, const int* attr0, const int* attr1,
+                      int background0, int background1, float* depth_out, int* attr0_out, int* attr1_out,
+                      int* index_out, void* stream);
+
 /* ---- dtype plumbing: f32 -> bf16 (round-to-nearest-even), n elements ---------------------- */
 int icv_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 

@@ -12,7 +12,7 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$root/include" -I"$here" -W
 objs=()
 pids=()
 mkdir -p "$here/build"
-srcs=(api elementwise gemm gemm256 gemm_fp8 fp8 attention attn2 attn7 attn8 buffers)
+srcs=(api elementwise gemm gemm256 gemm_fp8 fp8 attention attn2 attn7 attn8 buffers voxels)
 tag=""
 if [[ "${ICV_EXPERIMENTS:-0}" == "1" ]]; then
   srcs+=(experiments/attn1 experiments/attn3 experiments/attn4 experiments/attn5 experiments/attn6 experiments/attn9 experiments/gemm256w)
@@ -24,7 +24,7 @@ for src in "${srcs[@]}"; do
   if [[ ! -f "$obj" || "$here/$src.hip" -nt "$obj" || "$here/icv_common.h" -nt "$obj" || "$here/attn_common.h" -nt "$obj" || "$root/include/icvideo.h" -nt "$obj" ]]; then
     extra=()
     # buffers.hip produces BYTE outputs that must equal the reference's: no fused multiply-add contraction there
-    [[ "$src" == buffers ]] && extra=(-ffp-contract=off)
+    [[ "$src" == buffers || "$src" == voxels ]] && extra=(-ffp-contract=off)
     "$HIPCC" "${FLAGS[@]}" "${extra[@]}" "$@" -c "$here/$src.hip" -o "$obj" &
     pids+=($!)
   fi

@@ -49,6 +49,9 @@ SIGNATURES = {
     "icv_cast_f32_to_bf16": (c_int, [_P, _P, _I, _P]),
     "icv_semantic_to_color": (c_int, [_P, _I, _P, c_int, _P, _P, _P]),
     "icv_instance_overlay_u8": (c_int, [_P, _P, _I, _P, _P, _P]),
+    "icv_voxel_scatter": (c_int, [_P, _I, ctypes.POINTER(c_int), ctypes.POINTER(c_int), _P, _P, _P]),
+    "icv_voxel_raycast": (c_int, [_P, _P, ctypes.POINTER(c_int), ctypes.POINTER(c_float), ctypes.POINTER(c_float), _P, _P, _I, _I,
+                                  _F, _F, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "icv_depth_to_u16": (c_int, [_P, _I, _F, _P, _P]),
     "icv_coord_valid_mask": (c_int, [_P, ctypes.POINTER(c_float), _P, _I, _I, _I, _P, _P]),
     "icv_coord_gather_points": (c_int, [_P, ctypes.POINTER(c_float), _P, _I, _I, _I, _P, _I, _P, _P]),

@@ -67,7 +67,7 @@ class WanVideoGenerator:
         self._pool = None
         world = multigpu.requested_world()
         if world > 1:
-            self._pool = multigpu.WorkerPool(world, dict(
+            self._pool = multigpu.pool_for(world, dict(
                 checkpoint_path=checkpoint_path, device=device, torch_dtype=torch_dtype, buffer_channels=buffer_channels,
                 enable_vram_management=enable_vram_management, use_wan_1pt3b=use_wan_1pt3b))
 

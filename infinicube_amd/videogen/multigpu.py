@@ -34,6 +34,22 @@ import torch
 _PIPE_SETTINGS = ("num_inference_steps", "cfg_scale", "sigma_shift", "parallelism", "sp_chunks", "kv_exchange")
 
 
+_ACTIVE_POOL = None   # the one WorkerPool of this process (the reference's caller keeps ONE generator per process)
+
+
+def pool_for(world: int, ctor_kwargs: dict) -> "WorkerPool":
+    """The process-wide pool: created on first use, reused by a later generator built with the same arguments; a
+    generator with DIFFERENT arguments cannot share the workers (they hold the first one's weights) and is refused."""
+    global _ACTIVE_POOL
+    if _ACTIVE_POOL is not None and not _ACTIVE_POOL._closed:
+        if _ACTIVE_POOL.ctor_kwargs == ctor_kwargs and _ACTIVE_POOL.world == world:
+            return _ACTIVE_POOL
+        raise RuntimeError("ICV_WORLD: this process already drives a worker pool built for another WanVideoGenerator "
+                           f"({_ACTIVE_POOL.ctor_kwargs}); close it (generator._pool.close()) before building a different one")
+    _ACTIVE_POOL = WorkerPool(world, ctor_kwargs)
+    return _ACTIVE_POOL
+
+
 def requested_world() -> int:
     """ICV_WORLD = N | auto (= every visible GPU).  1 inside a worker, when unset, or when the process already is a
     rank of somebody else's job (torch.distributed initialised / launched by torch.distributed.run)."""
@@ -41,8 +57,8 @@ def requested_world() -> int:
     if not v or os.environ.get("ICV_WORKER_RANK") is not None:
         return 1
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
-        return 1
+    if dist.is_available() and dist.is_initialized() and (_ACTIVE_POOL is None or _ACTIVE_POOL._closed):
+        return 1          # somebody else's process group (e.g. torch.distributed.run): this process is already one rank of it
     if v == "auto":
         return max(1, torch.cuda.device_count())
     n = int(v)
@@ -67,7 +83,8 @@ class WorkerPool:
 
     def __init__(self, world: int, ctor_kwargs: dict, backend: Optional[str] = None):
         import torch.distributed as dist
-        self.world, self.dist = world, dist
+        self.world, self.dist, self.ctor_kwargs = world, dist, dict(ctor_kwargs)
+        self._closed = True
         self.backend = backend or os.environ.get("ICV_DIST_BACKEND", "nccl")
         self.timeout_s = float(os.environ.get("ICV_WORLD_TIMEOUT_S", "3600"))
         port = _free_port()
