@@ -120,6 +120,19 @@ def test_hip_raycast_full_size_properties_and_rate():
     assert depth.shape == (93, 480, 832) and sem.dtype == torch.int32
     assert bool(((depth == 0) == (sem == 0)).float().mean() > 0.99)         # sky <-> no depth (up to the eps difference)
     assert float(depth.max()) < 80 and float(depth[depth > 0].min()) > 0.2
-    up = sem[:, :40]                                                          # the top rows look above the 5 m walls: sky
-    assert float((up == 0).float().mean()) > 0.5
+    assert 0.02 < float((sem == 0).float().mean()) < 0.9                      # the canyon has open sky and solid walls / ground
+    assert {14, 18} <= set(torch.unique(sem).tolist())                       # BUILDING and ROAD both visible
+    # 4000 sampled rays of frame 40 against the oracle's cell walk on the same voxel world: bit for bit
+    from infinicube_amd.utils.voxel_render import points_to_voxels
+    ijk, vattrs = points_to_voxels(torch.from_numpy(p), {"semantics": torch.from_numpy(s)})
+    vol, vmin, dims = V.dense_volume(ijk.numpy())
+    g = np.random.default_rng(0)
+    pix = np.sort(g.choice(480 * 832, 4000, replace=False))
+    d_o, h_o = V.raycast_dda(vol, vmin, (0.2, 0.2, 0.2), cam.rays.reshape(-1, 3)[pix], poses[40:41].numpy())
+    assert np.array_equal(depth[40].reshape(-1)[torch.from_numpy(pix).cuda()].cpu().numpy(), d_o[0])
+    sa = vattrs["semantics"].numpy()
+    assert np.array_equal(sem[40].reshape(-1)[torch.from_numpy(pix).cuda()].cpu().numpy(), np.where(h_o[0] >= 0, sa[np.maximum(h_o[0], 0)], 0))
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    open("gpurun_out/voxel_raycast.txt", "w").write(f"{93 * 480 * 832 / dt / 1e6:.1f} M rays/s, {dt * 1e3:.1f} ms for 93 x 480 x 832 rays incl. voxelisation of {len(p)} points\n")
     print(f"\\nvoxel ray-cast: {93 * 480 * 832 / dt / 1e6:.1f} M rays/s incl. voxelisation of {len(p)} points ({dt * 1e3:.1f} ms for 93 x 480 x 832)")
