@@ -153,11 +153,21 @@ class PinholeStandIn:
     """The one method of the reference's camera model that the coordinate-buffer function calls
     (``get_intrinsics_matrix()`` [R infinicube/utils/buffer_utils.py:212])."""
 
-    def __init__(self, fx, fy, cx, cy):
+    def __init__(self, fx, fy, cx, cy, w: int = 0, h: int = 0):
         self.k = torch.tensor([[fx, 0.0, cx], [0.0, fy, cy], [0.0, 0.0, 1.0]], dtype=torch.float32)
+        self.w, self.h = w, h
 
     def get_intrinsics_matrix(self):
         return self.k
+
+    def get_rays(self, height: int = None, width: int = None):
+        """[H, W, 3] normalised camera rays (OpenCV axes), K^-1 (u, v, 1) / |.| like the reference's
+        PinholeCamera._get_rays_impl [R infinicube/camera/pinhole.py:110-140]."""
+        h, w = height or self.h, width or self.w
+        v, u = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+        uv1 = torch.stack([u, v, torch.ones_like(u)], -1).reshape(-1, 3)
+        r = (torch.inverse(self.k) @ uv1.T).T.reshape(h, w, 3)
+        return r / r.norm(dim=-1, keepdim=True)
 
 
 def make_scene_maps(grid: TokenGrid, device="cpu"):
@@ -203,3 +213,44 @@ def make_scene_maps(grid: TokenGrid, device="cpu"):
         poses[i, 2, 3] = 0.35 * i                                      # 3.5 m/s at 10 fps, straight ahead
         poses[i, 0, 3] = 0.4 * float(torch.sin(torch.tensor(i / 15.0)))
     return depth, sem, inst, cam, poses
+
+
+def make_voxel_world(grid: TokenGrid, seed: int = 0, density: float = 150.0):
+    """A synthetic VOXEL WORLD in the form stage 1 hands to stage 2 (a point cloud with Waymo class indices, z-up,
+    x-front [R infinicube/utils/fvdb_utils.py:87]) plus a camera and a forward-driving trajectory: a 120 m street (road,
+    sidewalks, building walls 9 m either side, poles) and two vehicles with instance ids.  `density` = points per m^2.
+    Returns (points f32 [P,3], semantic i32 [P], instance i32 [P], camera with get_rays()/get_intrinsics_matrix(),
+    poses f32 [N,4,4] camera-to-world)."""
+    n, h, w = grid.num_frames, grid.height, grid.width
+    g = torch.Generator().manual_seed(seed)
+
+    def plane(cnt, lo, hi, fixed_axis, fixed_val):
+        pts = torch.rand((cnt, 3), generator=g) * (torch.tensor(hi) - torch.tensor(lo)) + torch.tensor(lo)
+        pts[:, fixed_axis] = fixed_val + 0.02 * torch.randn(cnt, generator=g)
+        return pts
+
+    L = 120.0
+    parts, sems, insts = [], [], []
+
+    def add(pts, sem, inst=0):
+        parts.append(pts); sems.append(torch.full((len(pts),), sem, dtype=torch.int32)); insts.append(torch.full((len(pts),), inst, dtype=torch.int32))
+
+    add(plane(int(density * L * 12), [-5.0, -6.0, 0.0], [L, 6.0, 0.0], 2, 0.0), 18)                 # ROAD
+    add(plane(int(density * L * 3), [-5.0, 6.0, 0.0], [L, 9.0, 0.0], 2, 0.12), 22)                  # SIDEWALK (left)
+    add(plane(int(density * L * 3), [-5.0, -9.0, 0.0], [L, -6.0, 0.0], 2, 0.12), 22)                # SIDEWALK (right)
+    add(plane(int(density * L * 12), [-5.0, 9.0, 0.0], [L, 9.0, 12.0], 1, 9.0), 14)                 # BUILDING (left wall)
+    add(plane(int(density * L * 12), [-5.0, -9.0, 0.0], [L, -9.0, 12.0], 1, -9.0), 14)              # BUILDING (right wall)
+    for x in range(5, int(L), 15):                                                                  # POLE
+        pole = torch.rand((400, 3), generator=g) * torch.tensor([0.2, 0.2, 5.0]) + torch.tensor([float(x), 6.3, 0.0])
+        add(pole, 10)
+    for j, (x0, y0, sem) in enumerate(((35.0, -2.5, 1), (22.0, 3.0, 2))):                           # CAR, TRUCK
+        box = torch.rand((6000, 3), generator=g) * torch.tensor([4.2, 1.9, 1.6]) + torch.tensor([x0, y0 - 0.95, 0.0])
+        add(box, sem, j + 1)
+    pts, sem, inst = torch.cat(parts), torch.cat(sems), torch.cat(insts)
+    cam = PinholeStandIn(0.9 * w, 0.9 * w, w / 2.0, h * 0.55, w, h)
+    # camera (x right, y down, z front) -> world (x front, y left, z up); 3.5 m/s at 10 fps, a gentle lateral sway
+    base = torch.tensor([[0.0, 0.0, 1.0, 0.0], [-1.0, 0.0, 0.0, 0.0], [0.0, -1.0, 0.0, 1.6], [0.0, 0.0, 0.0, 1.0]])
+    poses = base.repeat(n, 1, 1)
+    poses[:, 0, 3] = 0.35 * torch.arange(n)
+    poses[:, 1, 3] = 0.4 * torch.sin(torch.arange(n) / 15.0)
+    return pts, sem, inst, cam, poses

@@ -189,9 +189,9 @@ from psnr_util import frame_psnr  # noqa: E402
 
 
 def test_config2_wan_1p3b_93f_480p(hip_ops):
-    """BASELINE.json config #2: Wan2.1-1.3B t2v, 93 frames 480x832 (S = 37 440), guidance buffers rendered from a
-    synthetic scene through the product's own buffer kernels (depth -> coordinate buffer, class / instance maps ->
-    colour buffer, uint8), stand-in VAE encode, 10 flow-match steps with CFG.  HIP loop vs oracle/wan_ref.py run in
+    """BASELINE.json config #2: Wan2.1-1.3B t2v, 93 frames 480x832 (S = 37 440), "real voxel guidance buffers": a synthetic voxel world
+    (point cloud with Waymo classes) ray-cast by the product's voxel renderer into depth / class / instance maps, turned
+    into the coordinate and colour buffers by the product's buffer kernels (uint8), stand-in VAE encode, 10 flow-match steps with CFG.  HIP loop vs oracle/wan_ref.py run in
     fp32 on the GPU by stock PyTorch.  Bars: final-latent PSNR >= 40 dB, decoded-frame PSNR (peak 255) >= 40 dB."""
     from infinicube_amd.utils.buffer_utils import generate_coordinate_buffer_from_memory_global_norm
     from infinicube_amd.utils.semantic_utils import generate_rgb_semantic_buffer, semantic_to_color
@@ -199,8 +199,12 @@ def test_config2_wan_1p3b_93f_480p(hip_ops):
     from infinicube_amd.videogen.standins import PoolVAE
     from PIL import Image
     cfg, grid = preset("1.3b"), GRID_480P
+    from infinicube_amd.utils.voxel_render import render_voxel_buffers
     torch.manual_seed(0); np.random.seed(0)
-    depth, sem, inst, cam, poses = syn.make_scene_maps(grid, DEV)
+    # stage 2's own flow on the GPU: voxel world -> ray-cast depth / class / instance maps -> the two guidance buffers
+    pts, psem, pinst, cam, poses = syn.make_voxel_world(grid)
+    depth, sem, inst = render_voxel_buffers(cam, poses, pts, psem, pinst)
+    assert depth.shape == (93, 480, 832) and 0.02 < float((depth == 0).float().mean()) < 0.6
     coord_u8 = generate_coordinate_buffer_from_memory_global_norm(depth, cam, poses, return_uint8=True).cpu().numpy()
     sem_rgb = (semantic_to_color(sem) * 255).astype(np.uint8)
     sem_u8 = generate_rgb_semantic_buffer(sem_rgb, inst.cpu().numpy().astype(np.uint16))
