@@ -152,7 +152,12 @@ def load_umt5_encoder(pattern, device, torch_dtype=torch.bfloat16, tokenizer_con
     if not files:
         raise FileNotFoundError(f"UMT5 encoder checkpoint not found: {pattern!r} (skip_download=True: nothing is fetched)")
     sd = torch.load(files[0], map_location="cpu", weights_only=True)
-    model = UMT5Encoder()
+    # architecture read off the tensors (umt5-xxl for the real file); a naming mismatch still fails in the strict load
+    vocab, dim = (int(x) for x in sd["token_embedding.weight"].shape)
+    buckets, heads = (int(x) for x in sd["blocks.0.pos_embedding.embedding.weight"].shape)
+    layers = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
+    model = UMT5Encoder(vocab_size=vocab, dim=dim, dim_attn=int(sd["blocks.0.attn.q.weight"].shape[0]),
+                        dim_ffn=int(sd["blocks.0.ffn.fc1.weight"].shape[0]), num_heads=heads, num_layers=layers, num_buckets=buckets)
     model.load_state_dict(sd, strict=True)
     model = model.to(device=device, dtype=torch_dtype).eval()
     tok_dir = tokenizer_config.resolve() if tokenizer_config is not None else os.path.join(

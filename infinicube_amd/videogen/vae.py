@@ -311,6 +311,9 @@ def load_wan_vae(pattern, device, dtype=torch.bfloat16) -> WanVAE:
     sd = torch.load(files[0], map_location="cpu", weights_only=True)
     if all(k.startswith("model.") for k in sd):
         sd = {k[len("model."):]: v for k, v in sd.items()}
-    net = WanVAENet()
+    # architecture read off the tensors (dim from the first conv, z_dim from conv2; the multipliers / block counts of the
+    # public Wan2.1 VAE): a mismatch still fails loudly in the strict load below
+    dim, z_dim = int(sd["encoder.conv1.weight"].shape[0]), int(sd["conv2.weight"].shape[0])
+    net = WanVAENet(dim=dim, z_dim=z_dim)
     net.load_state_dict(sd, strict=True)
     return WanVAE(net, device, dtype)
