@@ -117,6 +117,10 @@ def main():
     ap.add_argument("--kv-exchange", default=os.environ.get("ICV_KV_EXCHANGE", "allgather"), choices=["allgather", "p2p"],
                     help="N>1: K|V rows travel by all_gather_into_tensor (RCCL's schedule) or by grouped send/recv to every "
                          "peer (the direct, fully-connected schedule; seqpar.KVGather)")
+    ap.add_argument("--share-stem", action="store_true",
+                    help="let the uncond forward reuse the context-free stem (patch embed + layer 0's self-attention block) of the "
+                         "cond forward, as the product pipeline does (bit-identical result, 1/80 less attention/QKV/O work). OFF by "
+                         "default: the metric's step is two FULL forwards")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -157,6 +161,7 @@ def main():
     # graphs off: the bench times individual attention launches with events (at the metric's size the loop is GPU-bound
     # and "auto" would not capture anyway)
     model.prepare(grid, plan, sp_chunks=args.sp_chunks, group=layout.sp_group, graphs=False, kv_exchange=args.kv_exchange)
+    model.share_stem = bool(args.share_stem)
     clip = syn.make_clip_features(cfg) if cfg.has_image_input else None
     ctx_c = model.encode_context(syn.make_text_context(cfg, 1), clip)
     ctx_u = model.encode_context(syn.make_text_context(cfg, 2), clip)
@@ -301,6 +306,7 @@ def main():
                     f"cfg2 x sp{layout.sp_world} (cond / uncond forwards on two groups of {layout.sp_world} ranks; token-sequence shards and "
                     f"K/V all-gather in {args.sp_chunks} chunks inside a group; one velocity swap per step between the groups)"),
                 "wallclock_50_steps_s": 50.0 * elapsed / args.steps,
+                "cfg_stem_shared": bool(args.share_stem),
                 "c_abi_calls_per_forward": abi_calls / (args.steps * (1 if layout.mode == "cfg+sp" else 2)),
                 "host_enqueue_ms_per_step": 1e3 * t_enqueued / args.steps,
                 "algorithmic_pflop_per_step": f_step / 1e15,

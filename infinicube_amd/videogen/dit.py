@@ -239,6 +239,7 @@ class WanDiT:
         self.rope = RopeTable.build(grid.T, grid.Hp, grid.Wp, ops.device, cfg.head_dim)
         a = ops.alloc
         self.x = a((n, d), F32)
+        self.x_stem = a((n, d), F32)       # residual stream after layer 0's self-attention block, shared by the CFG branches
         self.h = a((n, d), BF16)
         self.qkv = a((3, n, d), BF16)
         self.att = a((n, d), BF16)
@@ -274,6 +275,8 @@ class WanDiT:
         # Off by default: measured -5 % at 14B / 480p and neutral at 1.3B — two chip-filling kernels at once break the
         # XCD-local K/V and weight reuse of each other more than they fill each other's tail waves.
         self.dual_stream = os.environ.get("ICV_DUAL_STREAM", "0") == "1" and self.plan.world == 1 and self._is_gpu()
+        # ICV_SHARE_STEM=0 switches off the sharing of the context-free stem between the two CFG forwards (A/B, tests)
+        self.share_stem = os.environ.get("ICV_SHARE_STEM", "1") == "1"
         self._twin = None
         if self.plan.world > 1:
             self.kv_loc = a((n, 2 * d), BF16)                      # local k | v rows (one exchange moves both)
@@ -419,9 +422,14 @@ class WanDiT:
 
     def forward_tokens(self, latent: torch.Tensor, ctx: ContextKV, timestep: float,
                        buf_tokens: Optional[torch.Tensor], head_out: torch.Tensor,
-                       num_layers: Optional[int] = None):
+                       num_layers: Optional[int] = None, stem: Optional[str] = None):
         """One DiT forward on this rank's token shard: latent f32 [C,T,H8,W8] (full, replicated) ->
-        head_out f32 [n, out_dim*4] (velocity in token space)."""
+        head_out f32 [n, out_dim*4] (velocity in token space).
+        ``stem``: the patch embedding and layer 0's self-attention block (LN/modulate, QKV, RoPE, attention, O-projection
+        + gated residual) see nothing of the text context, so the cond and uncond forwards of one step compute
+        bit-identical values there.  "save" keeps the residual stream after that block in ``self.x_stem``; "load" starts
+        from it instead of recomputing (denoise() does this for the second CFG forward: 1/80 of a step's self-attention,
+        QKV and O work, same numbers)."""
         cfg, ops, plan = self.cfg, self.ops, self.plan
         d, H, n, eps = cfg.dim, cfg.num_heads, plan.n_tok, cfg.eps
         scale = self.attn_scale          # = ln 2: K already carries (1/sqrt(hd)) * log2(e)
@@ -430,34 +438,41 @@ class WanDiT:
         if cfg.has_image_input != (ctx.k_img is not None):
             raise ValueError("context was encoded without/with CLIP features but the DiT is/isn't i2v")
         self._time_state(timestep)
+        if stem not in (None, "save", "load"):
+            raise ValueError(f"stem must be None, 'save' or 'load', got {stem!r}")
+        if stem is not None and (num_layers == 0 or cfg.num_layers == 0):
+            stem = None
         if self._graphs_on:
-            key = (id(ctx), latent.data_ptr(), 0 if buf_tokens is None else buf_tokens.data_ptr(), head_out.data_ptr(), num_layers)
+            key = (id(ctx), latent.data_ptr(), 0 if buf_tokens is None else buf_tokens.data_ptr(), head_out.data_ptr(), num_layers, stem)
             entry = self._graphs.get(key)
             if entry is None:
                 # first call with these buffers: run eagerly (that IS this call's result; it also lets every kernel do
                 # its one-time launch-attribute set-up), then record the same launch sequence for the later calls
-                self._forward_body(latent, ctx, buf_tokens, head_out, num_layers)
+                self._forward_body(latent, ctx, buf_tokens, head_out, num_layers, stem)
                 torch.cuda.synchronize(ops.device)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    self._forward_body(latent, ctx, buf_tokens, head_out, num_layers)
+                    self._forward_body(latent, ctx, buf_tokens, head_out, num_layers, stem)
                 self._graphs[key] = (g, ctx, latent, buf_tokens, head_out)   # keep the captured buffers alive
             else:
                 entry[0].replay()
             return
-        self._forward_body(latent, ctx, buf_tokens, head_out, num_layers)
+        self._forward_body(latent, ctx, buf_tokens, head_out, num_layers, stem)
 
-    def _forward_body(self, latent, ctx, buf_tokens, head_out, num_layers):
+    def _forward_body(self, latent, ctx, buf_tokens, head_out, num_layers, stem=None):
         """The launch sequence of one forward after the time state: patch embed, L blocks, head."""
         cfg, ops, plan = self.cfg, self.ops, self.plan
         d, H, n, eps = cfg.dim, cfg.num_heads, plan.n_tok, cfg.eps
         scale = self.attn_scale
-        # K1: patch embed (+ cached guidance-buffer tokens fused into the GEMM epilogue)
-        ops.patchify(latent, self.patches, plan.tok0, n)
-        if buf_tokens is not None:
-            ops.gemm(self.patches, self.patch_w, self.patch_b, self.x, EPI_RESID_F32, resid=buf_tokens)
+        if stem == "load":
+            self.x.copy_(self.x_stem)          # the residual stream after layer 0's self-attention block (see forward_tokens)
         else:
-            ops.gemm(self.patches, self.patch_w, self.patch_b, self.x, EPI_F32)
+            # K1: patch embed (+ cached guidance-buffer tokens fused into the GEMM epilogue)
+            ops.patchify(latent, self.patches, plan.tok0, n)
+            if buf_tokens is not None:
+                ops.gemm(self.patches, self.patch_w, self.patch_b, self.x, EPI_RESID_F32, resid=buf_tokens)
+            else:
+                ops.gemm(self.patches, self.patch_w, self.patch_b, self.x, EPI_F32)
         q, k, v = self.qkv[0], self.qkv[1], self.qkv[2]
         L = cfg.num_layers if num_layers is None else num_layers
         for i in range(L):
@@ -466,8 +481,10 @@ class WanDiT:
             sh1, sc1, g1 = m[0:d], m[d:2 * d], m[2 * d:3 * d]
             sh2, sc2, g2 = m[3 * d:4 * d], m[4 * d:5 * d], m[5 * d:6 * d]
             # --- self-attention ---
-            h = self._norm(lw["wqkv"], shift=sh1, scale=sc1, eps=eps)                       # K3
-            if plan.world > 1:
+            if i == 0 and stem == "load":
+                pass                                                                        # taken from the cond forward
+            elif plan.world > 1:
+                h = self._norm(lw["wqkv"], shift=sh1, scale=sc1, eps=eps)                   # K3
                 # K and V first, so their all-gather (K13) is already moving while Q is projected
                 self._mm(h, lw["wqkv"], lw["bqkv"], self.kv_loc, EPI_BF16, rows=slice(d, 3 * d))            # K4 (k | v rows)
                 ops.rmsnorm_rope(self.kv_loc[:, :d], lw["nk"], eps=eps, rope=self.rope, tok0=plan.tok0)      # K5 (k)
@@ -476,14 +493,18 @@ class WanDiT:
                 ops.rmsnorm_rope(q, lw["nq"], eps=eps, rope=self.rope, tok0=plan.tok0)               # K5 (q)
                 self._sp_attention(q, handles, bufs, H, scale)                                       # K6
             else:
+                h = self._norm(lw["wqkv"], shift=sh1, scale=sc1, eps=eps)                   # K3
                 self._mm(h, lw["wqkv"], lw["bqkv"], self.qkv, EPI_BF16, nsplit=d)           # K4
                 ops.rmsnorm_rope(q, lw["nq"], k, lw["nk"], eps=eps, rope=self.rope, tok0=plan.tok0)  # K5
                 if self.attn8_ws is not None:
                     ops.attention_fp8(q, k, v, self.att, H, self.attn8_ws)                  # K6 (e4m3)
                 else:
                     ops.attention(q, k, v, self.att, H, scale)                              # K6
-            a = self._operand(self.att, self.att8, self.att8s, lw["wo"])
-            self._mm(a, lw["wo"], lw["bo"], self.x, EPI_RESID_F32, resid=self.x, gate=g1)   # K7
+            if not (i == 0 and stem == "load"):
+                a = self._operand(self.att, self.att8, self.att8s, lw["wo"])
+                self._mm(a, lw["wo"], lw["bo"], self.x, EPI_RESID_F32, resid=self.x, gate=g1)   # K7
+                if i == 0 and stem == "save":
+                    self.x_stem.copy_(self.x)
             # --- cross-attention to text (no gate) ---
             h = self._norm(lw["xq_w"], weight=lw["n3w"], bias=lw["n3b"], eps=eps)           # K8
             self._mm(h, lw["xq_w"], lw["xq_b"], q, EPI_BF16)                                # K9
@@ -552,9 +573,10 @@ class WanDiT:
                 self.forward_tokens(latent, ctx_cond, ts, buf_tokens, self.head_out[0])
                 main.wait_stream(side)
             else:
-                self.forward_tokens(latent, ctx_cond, ts, buf_tokens, self.head_out[0])
+                share = use_cfg and self.share_stem
+                self.forward_tokens(latent, ctx_cond, ts, buf_tokens, self.head_out[0], stem="save" if share else None)
                 if use_cfg:
-                    self.forward_tokens(latent, ctx_uncond, ts, buf_tokens, self.head_out[1])
+                    self.forward_tokens(latent, ctx_uncond, ts, buf_tokens, self.head_out[1], stem="load" if share else None)
             ops.unpatchify_cfg_euler(latent, self.head_out[0], self.head_out[1] if use_cfg else None,
                                      cfg_scale, scheduler.dsigma(i), plan.tok0, plan.n_tok, round_bf16=round_bf16)
             if on_step is not None:

@@ -71,6 +71,12 @@ def test_denoise_loop_psnr(hip_ops):
     from psnr_util import frame_psnr
     pf = frame_psnr(lat.cpu(), ref)
     assert pf >= 40.0, f"decoded-frame PSNR (peak 255) {pf:.1f} dB < 40 dB"
+    # the context-free stem shared between the two CFG forwards (product default) vs two full forwards: bit-identical
+    m2 = WanDiT(cfg, sd, hip_ops, bsd).prepare(grid)
+    m2.share_stem = False
+    lat_ns = noise.clone().to("cuda:0")
+    m2.denoise(lat_ns, m2.encode_context(c1), m2.encode_context(c2), m2.embed_buffers(bl), FlowMatchScheduler(steps), 5.0)
+    assert m.share_stem and torch.equal(lat_ns, lat), "sharing the stem between the CFG forwards changed the result"
     # determinism: same seed/buffers/prompt => bit-identical latents
     lat2 = noise.clone().to("cuda:0")
     m.denoise(lat2, m.encode_context(c1), m.encode_context(c2), m.embed_buffers(bl), FlowMatchScheduler(steps), 5.0)

@@ -116,6 +116,23 @@ def test_fp8_gemm_mode_matches_fake_quant_oracle():
     assert 1e-3 < rel2 < 0.25, f"fp8 GEMMs + fp8 attention vs unquantised oracle rel-L2 {rel2}"
 
 
+def test_cfg_forwards_share_the_context_free_stem_bit_identically():
+    """The patch embedding and layer 0's self-attention block do not see the text context: the uncond forward may start
+    from the cond forward's residual stream after that block.  Same latents bit for bit, with and without sharing."""
+    sd, bsd, noise, c1, c2, bl = _inputs()
+    outs = []
+    for share in (True, False):
+        m = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID)
+        m.share_stem = share
+        lat = noise.clone()
+        m.denoise(lat, m.encode_context(c1), m.encode_context(c2), m.embed_buffers(bl), FlowMatchScheduler(3), 5.0)
+        outs.append(lat)
+    assert torch.equal(outs[0], outs[1])
+    m = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID)
+    with pytest.raises(ValueError, match="stem"):
+        m.forward_tokens(noise.clone(), m.encode_context(c1), 500.0, m.embed_buffers(bl), m.head_out[0], stem="reuse")
+
+
 def test_loop_matches_oracle_and_time_cache():
     sd, bsd, noise, c1, c2, bl = _inputs()
     m = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID)
