@@ -177,8 +177,23 @@ class WorkerPool:
 
 
 # -- worker side ---------------------------------------------------------------------------------------
+def _exit_when_parent_dies(parent_pid: int) -> None:
+    """A worker blocked in a collective would outlive a crashed caller and keep its GPU: poll the parent and leave."""
+    import threading
+
+    def watch():
+        while True:
+            time.sleep(5.0)
+            if os.getppid() != parent_pid:
+                print("[worker] parent process is gone: exiting", flush=True)
+                os._exit(3)
+
+    threading.Thread(target=watch, daemon=True).start()
+
+
 def worker_main() -> int:
     import torch.distributed as dist
+    _exit_when_parent_dies(os.getppid())
     with open(os.environ["ICV_WORKER_SPEC"], "rb") as f:
         spec = pickle.load(f)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
