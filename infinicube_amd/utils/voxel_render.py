@@ -128,6 +128,11 @@ def render_voxel_buffers(camera_model, camera_poses_in_world: torch.Tensor, scen
     single = camera_poses_in_world.dim() == 2
     poses = camera_poses_in_world[None] if single else camera_poses_in_world
     dev = torch.device(device)
+    if scene_points.numel() == 0:        # an empty world: every ray misses (depth 0, UNDEFINED, no instance)
+        h, w = camera_model.get_rays().shape[:2]
+        z = torch.zeros((poses.shape[0], h, w), dtype=torch.int32, device=dev)
+        out = (z.to(torch.float32), z, z.clone())
+        return tuple(o[0] for o in out) if single else out
     attrs = {"semantics": scene_semantic}
     if scene_instance is not None:
         attrs["instance"] = scene_instance

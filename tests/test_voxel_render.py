@@ -80,6 +80,32 @@ def test_oracle_walk_agrees_with_bruteforce():
 
 
 @pytest.mark.gpu
+def test_hip_raycast_edge_cases():
+    """An empty world, a camera inside an occupied voxel, rays parallel to an axis, a world far off the view."""
+    from infinicube_amd.utils.voxel_render import render_voxel_buffers
+    cam = Cam(16, 12, 10.0)
+    pose = torch.from_numpy(_poses(1)[0])
+    d, s, i = render_voxel_buffers(cam, pose, torch.zeros((0, 3)), torch.zeros((0,), dtype=torch.int32))
+    assert d.shape == (12, 16) and float(d.abs().max()) == 0 and int(s.abs().max()) == 0
+    # a solid 2 m cube around the camera: every ray starts inside occupied space -> the run starts at t = 0 (depth 0 * z = 0),
+    # the semantic map still reports the voxel the ray starts in
+    g = np.random.default_rng(0)
+    cube = torch.from_numpy((g.uniform(-1, 1, (200000, 3)) + np.array([1.0, 0.0, 1.6])).astype(np.float32))
+    d, s, i = render_voxel_buffers(cam, pose, cube, torch.full((len(cube),), 14, dtype=torch.int32))
+    assert float(d.abs().max()) == 0 and bool((s == 14).all())
+    # axis-parallel rays (identity rotation, rays along +z of a z-front camera placed in world axes) hit a slab exactly
+    eye = torch.eye(4)
+    one = Cam(1, 1, 1.0)
+    one.rays = np.array([[[0.0, 0.0, 1.0]]], np.float32)
+    slab = torch.from_numpy(np.stack(np.meshgrid(np.arange(-1, 1, 0.05), np.arange(-1, 1, 0.05), [5.05]), -1).reshape(-1, 3).astype(np.float32))
+    d, s, i = render_voxel_buffers(one, eye, slab, torch.full((len(slab),), 18, dtype=torch.int32))
+    assert abs(float(d[0, 0]) - 5.0) < 1e-5 and int(s[0, 0]) == 18           # the voxel [5.0, 5.2) starts at z = 5.0
+    far = slab + torch.tensor([500.0, 0.0, 0.0])
+    d, s, i = render_voxel_buffers(one, eye, far, torch.full((len(far),), 18, dtype=torch.int32))
+    assert float(d[0, 0]) == 0 and int(s[0, 0]) == 0
+
+
+@pytest.mark.gpu
 def test_hip_raycast_bit_exact_vs_oracle():
     from infinicube_amd.utils.voxel_render import VoxelVolume, points_to_voxels
     p, s, i = _scene(2)
