@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--kv-exchange", default=os.environ.get("ICV_KV_EXCHANGE", "allgather"), choices=["allgather", "p2p"],
                     help="N>1: K|V rows travel by all_gather_into_tensor (RCCL's schedule) or by grouped send/recv to every "
                          "peer (the direct, fully-connected schedule; seqpar.KVGather)")
+    ap.add_argument("--native-forward", action="store_true",
+                    help="drive each forward with ONE icv_dit_forward call (bf16, single GPU) instead of the per-op entry points; bit-identical")
     ap.add_argument("--share-stem", action="store_true",
                     help="let the uncond forward reuse the context-free stem (patch embed + layer 0's self-attention block) of the "
                          "cond forward, as the product pipeline does (bit-identical result, 1/80 less attention/QKV/O work). OFF by "
@@ -162,6 +164,10 @@ def main():
     # and "auto" would not capture anyway)
     model.prepare(grid, plan, sp_chunks=args.sp_chunks, group=layout.sp_group, graphs=False, kv_exchange=args.kv_exchange)
     model.share_stem = bool(args.share_stem)
+    if args.native_forward:   # one icv_dit_forward call per forward instead of ~530 per-op calls (bit-identical)
+        model.native_forward = True
+        if not model._native_eligible():
+            raise SystemExit("--native-forward covers the bf16 single-GPU path only")
     clip = syn.make_clip_features(cfg) if cfg.has_image_input else None
     ctx_c = model.encode_context(syn.make_text_context(cfg, 1), clip)
     ctx_u = model.encode_context(syn.make_text_context(cfg, 2), clip)
@@ -232,6 +238,10 @@ def main():
     run_steps(0, args.warmup)
     sync()
     record["on"] = True
+    if args.native_forward:
+        model.native_profile(True)
+        if model._twin is not None:      # dual-stream CFG: the second forward runs on a twin engine with its own context
+            model._twin[0].native_profile(True)
     if model.kv_gather is not None:
         model.kv_gather.timing = []          # (event before, event after) each wait on a K|V chunk: exposed transfer time
         model.kv_gather.n_collectives = 0
@@ -268,6 +278,12 @@ def main():
         attn_ms = sum(a.elapsed_time(b) for a, b, _ in chunk_events) / len(chunk_events)
         attn_flops = 4.0 * plan.n_tok * (sum(kk for _, _, kk in chunk_events) / len(chunk_events)) * cfg.dim
         attn_events = chunk_events
+    elif args.native_forward:   # events recorded by the C driver around its own self-attention launches
+        reads = [model.native_profile_read()] + ([model._twin[0].native_profile_read()] if model._twin is not None else [])
+        n_timed = sum(n for _, n in reads)
+        attn_ms = sum(ms for ms, _ in reads) / max(n_timed, 1)
+        attn_events = [None] * n_timed
+        attn_flops = 4.0 * plan.n_tok * grid.S * cfg.dim
     else:
         attn_ms = sum(a.elapsed_time(b) for a, b in attn_events) / max(len(attn_events), 1)
         attn_flops = 4.0 * plan.n_tok * grid.S * cfg.dim        # per launch on this rank (4 S^2 d)
@@ -309,6 +325,7 @@ def main():
                 "cfg_stem_shared": bool(args.share_stem),
                 "c_abi_calls_per_forward": abi_calls / (args.steps * (1 if layout.mode == "cfg+sp" else 2)),
                 "host_enqueue_ms_per_step": 1e3 * t_enqueued / args.steps,
+                "forward_driver": "icv_dit_forward (C)" if args.native_forward else "per-op C entry points driven from videogen/dit.py",
                 "algorithmic_pflop_per_step": f_step / 1e15,
                 "model_tflops_all_gpus": f_step * args.steps / elapsed / 1e12,
                 "frac_of_bf16_mfma_peak": f_step * args.steps / elapsed / 1e12 / (PEAK_BF16_TFLOPS * world),

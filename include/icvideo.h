@@ -240,6 +240,45 @@ int icv_voxel_raycast(const int* vol, const unsigned char* bricks, const int* di
                       int background0, int background1, float* depth_out, int* attr0_out, int* attr1_out,
                       int* index_out, void* stream);
 
+/* ---- context-style driver: the whole DiT forward of a token shard in ONE call (SURVEY §8b B-native) ----------------
+ * Replaces one `WanModel.forward` of the diffsynth fork reached from `self.pipe(...)`
+ * [R infinicube/videogen/inference.py:216-226] for a host that does not drive the per-op entry points itself; it calls
+ * exactly those launchers in the order infinicube_amd/videogen/dit.py does (bit-identical results).  bf16 single-rank
+ * path (t2v and i2v).  Every tensor is BORROWED: `icv_dit_bind` records a device pointer, nothing is copied or owned.
+ *   per-layer names (layer >= 0): wqkv [3d,d] bf16, bqkv f32 [3d], nq / nk f32 [d] (nk carries the folded softmax scale),
+ *     wo, bo, n3w, n3b, xq_w, xq_b, xnq, xo_w, xo_b, f0_w [ffn,d], f0_b, f2_w [d,ffn], f2_b;
+ *   global names (layer = -1): patch_w bf16 [d,k_patch], patch_b, head_w bf16 [out_cols,d], head_b, rope (f32 table of
+ *     ops.RopeTable), workspace x f32 [n,d], x_stem f32 [n,d] (optional), h bf16 [n,d], qkv bf16 [3,n,d], att bf16 [n,d],
+ *     ff bf16 [n,ffn], patches bf16 [n,k_patch].
+ * icv_dit_forward: latent f32 [C,T,H8,W8]; mod f32 [layers,6d] and hmod f32 [2,d] = this step's modulation tables;
+ *   ctx_k / ctx_v bf16 [ctx_len, d] of layer 0, layer i at + i * ctx_layer_stride elements (text K/V cache); img_k / img_v
+ *   likewise with img_len / img_layer_stride, or NULL; buf_tokens f32
+ *   [n,d] or NULL; head_out f32 [n,out_cols]; num_layers < 0 = all; stem 0 | 1 = save x after layer 0's self-attention
+ *   block into x_stem | 2 = start from x_stem (the context-free stem shared by the two CFG forwards). */
+typedef struct icv_dit icv_dit;
+typedef struct {
+  int64_t dim, ffn_dim, heads, layers;
+  int64_t n_tok, tok0;       /* this shard's tokens [tok0, tok0 + n_tok) of the (T, Hp, Wp) grid */
+  int64_t T, Hp, Wp;
+  int64_t k_patch, out_cols; /* padded patch-GEMM K (multiple of 64); head columns = out_dim * 4 */
+  float eps;
+} icv_dit_config;
+int icv_dit_create(const icv_dit_config* cfg, icv_dit** out);
+void icv_dit_destroy(icv_dit* ctx);
+int icv_dit_bind(icv_dit* ctx, const char* name, int64_t layer, const void* device_ptr);
+int icv_dit_forward(icv_dit* ctx, const float* latent, int64_t C, int64_t H8, int64_t W8, const float* mod,
+                    const float* hmod, const void* ctx_k, const void* ctx_v, int64_t ctx_len,
+                    int64_t ctx_layer_stride, const void* img_k, const void* img_v, int64_t img_len,
+                    int64_t img_layer_stride, const float* buf_tokens, float* head_out, int64_t num_layers, int stem,
+                    float attn_scale, void* stream);
+
+/* Per-launch timing of the dominant kernel (self-attention, K6) inside icv_dit_forward: with profiling enabled every
+ * forward records a HIP event pair around that launch ON THE LAUNCH STREAM; icv_dit_profile_read waits for the recorded
+ * events, returns their summed duration and count, and resets the list.  bench.py's roofline figure uses it.  Leave it
+ * off under graph capture. */
+int icv_dit_profile(icv_dit* ctx, int enable);
+int icv_dit_profile_read(icv_dit* ctx, double* total_ms, int64_t* launches);
+
 /* ---- dtype plumbing: f32 -> bf16 (round-to-nearest-even), n elements ---------------------- */
 int icv_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 

@@ -59,6 +59,20 @@ SIGNATURES = {
                                     ctypes.POINTER(c_float), c_int, _P, _P, _P]),
 }
 
+class DitConfig(ctypes.Structure):
+    """icv_dit_config of include/icvideo.h."""
+    _fields_ = [(n, c_int64) for n in ("dim", "ffn_dim", "heads", "layers", "n_tok", "tok0", "T", "Hp", "Wp", "k_patch", "out_cols")] + [("eps", c_float)]
+
+
+SIGNATURES.update({
+    "icv_dit_create": (c_int, [ctypes.POINTER(DitConfig), ctypes.POINTER(c_void_p)]),
+    "icv_dit_destroy": (None, [c_void_p]),
+    "icv_dit_bind": (c_int, [c_void_p, c_char_p, _I, _P]),
+    "icv_dit_forward": (c_int, [c_void_p, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P, _P, _I, c_int, _F, _P]),
+    "icv_dit_profile": (c_int, [c_void_p, c_int]),
+    "icv_dit_profile_read": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
+})
+
 _lib: Optional[ctypes.CDLL] = None
 
 

@@ -275,6 +275,13 @@ class WanDiT:
         # Off by default: measured -5 % at 14B / 480p and neutral at 1.3B — two chip-filling kernels at once break the
         # XCD-local K/V and weight reuse of each other more than they fill each other's tail waves.
         self.dual_stream = os.environ.get("ICV_DUAL_STREAM", "0") == "1" and self.plan.world == 1 and self._is_gpu()
+        # ICV_NATIVE_FORWARD=1 / self.native_forward = True: one C call (icv_dit_forward) enqueues the whole forward instead of
+        # ~13 C-ABI calls per layer from Python — the same launchers in the same order, so bit-identical; available on the
+        # bf16 single-rank path.  Off by default: host issue time is 0.3 % of a 14B step either way.
+        self.native_forward = os.environ.get("ICV_NATIVE_FORWARD", "0") == "1"
+        if getattr(self, "_native", None) is not None:      # a new workspace: the old context points at freed buffers
+            self.ops.lib.icv_dit_destroy(self._native)
+        self._native = None
         # ICV_SHARE_STEM=0 switches off the sharing of the context-free stem between the two CFG forwards (A/B, tests)
         self.share_stem = os.environ.get("ICV_SHARE_STEM", "1") == "1"
         self._twin = None
@@ -288,6 +295,56 @@ class WanDiT:
         else:
             self.kv_loc, self.kv_full, self.kv_gather = None, None, None
         return self
+
+    def _native_ctx(self):
+        """icv_dit context bound to this engine's weights and workspace (built lazily, once per prepare())."""
+        if self._native is not None:
+            return self._native
+        import ctypes
+        from .. import native
+        lib, cfg, plan, g = self.ops.lib, self.cfg, self.plan, self.grid
+        c = native.DitConfig(dim=cfg.dim, ffn_dim=cfg.ffn_dim, heads=cfg.num_heads, layers=cfg.num_layers, n_tok=plan.n_tok,
+                             tok0=plan.tok0, T=g.T, Hp=g.Hp, Wp=g.Wp, k_patch=self.k_patch, out_cols=cfg.out_dim * cfg.patch_elems,
+                             eps=cfg.eps)
+        h = ctypes.c_void_p()
+        native.check(lib.icv_dit_create(ctypes.byref(c), ctypes.byref(h)), "icv_dit_create")
+
+        def bind(name, t, layer=-1):
+            native.check(lib.icv_dit_bind(h, name.encode(), layer, t.data_ptr()), f"icv_dit_bind({name})")
+
+        for name in ("patch_w", "patch_b", "head_w", "head_b", "x", "x_stem", "h", "qkv", "att", "ff", "patches"):
+            bind(name, getattr(self, name))
+        bind("rope", self.rope.table)
+        for i, lw in enumerate(self.layers):
+            for name in ("wqkv", "bqkv", "nq", "nk", "wo", "bo", "n3w", "n3b", "xq_w", "xq_b", "xnq", "xo_w", "xo_b", "f0_w", "f0_b", "f2_w", "f2_b"):
+                bind(name, lw[name], i)
+        self._native = h
+        return h
+
+    def _native_eligible(self) -> bool:
+        return (self.native_forward and self.plan.world == 1 and not self.fp8 and not self.attn_fp8 and self._is_gpu()
+                and hasattr(self.ops, "lib"))
+
+    def native_profile(self, enable: bool):
+        """Time every self-attention launch of the native forward with HIP events on the launch stream (bench.py)."""
+        from .. import native
+        native.check(self.ops.lib.icv_dit_profile(self._native_ctx(), int(bool(enable))), "icv_dit_profile")
+
+    def native_profile_read(self):
+        """(summed ms, launches) of the self-attention launches recorded since the last read; waits for them."""
+        import ctypes
+        from .. import native
+        ms, n = ctypes.c_double(), ctypes.c_int64()
+        native.check(self.ops.lib.icv_dit_profile_read(self._native_ctx(), ctypes.byref(ms), ctypes.byref(n)), "icv_dit_profile_read")
+        return ms.value, n.value
+
+    def __del__(self):
+        h = getattr(self, "_native", None)
+        if h is not None:
+            try:
+                self.ops.lib.icv_dit_destroy(h)
+            except Exception:  # pragma: no cover - interpreter shutdown
+                pass
 
     def _is_gpu(self) -> bool:
         dev = getattr(self.ops, "device", None)
@@ -464,6 +521,16 @@ class WanDiT:
         cfg, ops, plan = self.cfg, self.ops, self.plan
         d, H, n, eps = cfg.dim, cfg.num_heads, plan.n_tok, cfg.eps
         scale = self.attn_scale
+        if self._native_eligible():
+            from .. import native
+            C, _, H8, W8 = latent.shape
+            ki, vi = (ctx.k_img, ctx.v_img) if ctx.k_img is not None else (None, None)
+            native.check(ops.lib.icv_dit_forward(
+                self._native_ctx(), latent.data_ptr(), C, H8, W8, self.mod.data_ptr(), self.hmod.data_ptr(), ctx.k.data_ptr(),
+                ctx.v.data_ptr(), ctx.k.shape[1], ctx.k.stride(0), native.ptr(ki), native.ptr(vi), ki.shape[1] if ki is not None else 0,
+                ki.stride(0) if ki is not None else 0, native.ptr(buf_tokens), head_out.data_ptr(),
+                -1 if num_layers is None else num_layers, {None: 0, "save": 1, "load": 2}[stem], scale, ops._stream()), "icv_dit_forward")
+            return
         if stem == "load":
             self.x.copy_(self.x_stem)          # the residual stream after layer 0's self-attention block (see forward_tokens)
         else:
@@ -530,6 +597,7 @@ class WanDiT:
             import copy
             twin = copy.copy(self)                      # shallow: weights / caches by reference
             twin._twin = None
+            twin._native = None                         # its own workspace -> its own native context, if any
             twin.dual_stream = False
             twin.prepare(self.grid, self.plan, graphs=False)
             self._twin = (twin, torch.cuda.Stream(device=self.ops.device))

@@ -431,3 +431,50 @@ def test_generator_end_to_end_on_gpu(tmp_path, monkeypatch):
     a1, a2, a3 = (np.stack([np.asarray(x) for x in f]) for f in (f1, f2, f3))
     assert np.array_equal(a1, a2), "same seed + buffers + prompt must reproduce the same frames"
     assert not np.array_equal(a1, a3), "guidance buffers must condition the output"
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny-i2v"])
+def test_native_forward_matches_python_driver(hip_ops, name):
+    """icv_dit_create / icv_dit_bind / icv_dit_forward (the whole forward enqueued by ONE C call) against the per-op
+    driver in dit.py: the same launchers in the same order, so the velocity tokens and a whole CFG denoise loop are
+    bit-identical, with and without the shared stem; binding errors are reported through the ABI."""
+    import ctypes
+    from infinicube_amd import native
+    cfg, grid = preset(name), TokenGrid(9, 64, 96)
+    sd, bsd = syn.make_dit_state_dict(cfg), syn.make_buffer_embedder_state_dict(cfg)
+    noise, c1, c2 = syn.make_latent_noise(grid), syn.make_text_context(cfg, 1), syn.make_text_context(cfg, 2)
+    bl = syn.make_buffer_latents(cfg, grid)
+    clip = syn.make_clip_features(cfg) if cfg.has_image_input else None
+    y = syn.make_cond_latents(cfg, grid) if cfg.has_image_input else None
+    outs = {}
+    for native_on in (False, True):
+        m = WanDiT(cfg, sd, hip_ops, bsd).prepare(grid, graphs=False)
+        m.native_forward = native_on
+        assert m._native_eligible() == native_on
+        ck, cu = m.encode_context(c1, clip), m.encode_context(c2, clip)
+        add = m.embed_buffers(bl)
+        if y is not None:
+            add = m.embed_cond_latents(y, add_to=add)
+        lat = noise.clone().to("cuda:0")
+        m.forward_tokens(lat, ck, 731.0, add, m.head_out[0])
+        m.forward_tokens(lat, ck, 731.0, add, m.head_out[1], num_layers=1)
+        one = m.head_out.clone()
+        m.denoise(lat, ck, cu, add, FlowMatchScheduler(3), 5.0)          # stem shared between the CFG forwards
+        torch.cuda.synchronize()
+        outs[native_on] = (one.cpu(), lat.cpu())
+        if native_on:
+            h = m._native_ctx()
+            m.native_profile(True)                   # event pairs around the self-attention launches, read back as (ms, count)
+            m.forward_tokens(lat, ck, 500.0, add, m.head_out[0])
+            ms, n = m.native_profile_read()
+            assert n == cfg.num_layers and 0.0 < ms < 1e3
+            assert m.native_profile_read() == (0.0, 0)
+            m.native_profile(False)
+            assert hip_ops.lib.icv_dit_bind(h, b"no_such_tensor", -1, lat.data_ptr()) != 0
+            assert b"unknown tensor" in hip_ops.lib.icv_last_error()
+            assert hip_ops.lib.icv_dit_bind(h, b"wqkv", cfg.num_layers, lat.data_ptr()) != 0
+    assert torch.equal(outs[True][0], outs[False][0]), "icv_dit_forward differs from the per-op driver (one forward)"
+    assert torch.equal(outs[True][1], outs[False][1]), "icv_dit_forward differs from the per-op driver (CFG loop, shared stem)"
+    bad = native.DitConfig(dim=100, ffn_dim=64, heads=1, layers=1, n_tok=4, tok0=0, T=1, Hp=2, Wp=2, k_patch=64, out_cols=64, eps=1e-6)
+    hh = ctypes.c_void_p()
+    assert hip_ops.lib.icv_dit_create(ctypes.byref(bad), ctypes.byref(hh)) != 0
