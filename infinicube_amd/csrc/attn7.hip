@@ -56,6 +56,8 @@ __device__ __forceinline__ void dma16s(const void* base, unsigned off, unsigned 
 
 // VAR bit flags: 1 = stagger wave groups, 2 = issue all 16 K-fragment reads ahead of the QK^T MFMAs,
 //                4 = s_setprio(1) around MFMA clusters, 16 = unit scale
+// (tried and dropped: row sums with v_pk_add_f32 — 8 fewer VALU issues per 32-key block, 1142.6 vs 1149.5 TF/s, noise:
+//  the kernel is power-limited, profiles/r02/power_limit_probes.md)
 template <int VAR>
 __global__ __launch_bounds__(512) void attn7_kernel(Params p) {
   constexpr bool STAGGER = VAR & 1, KPREFETCH = VAR & 2, SETPRIO = VAR & 4, UNIT = VAR & 16;   // 16: unit scale (set by the dispatcher)
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(512) void attn7_kernel(Params p) {
     const int64_t key0 = (int64_t)t * KVB;
 
     // DMA of tile t+ahead first (longest possible flight), counted wait at the end of the interval
-    A7_DMA_TILE(t + ahead);
+    if (!(p.ablate & 1)) A7_DMA_TILE(t + ahead);
 
     f32x16 st[2];
     const bool no_ref = UNIT && m_run < -1.0e29f;
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(512) void attn7_kernel(Params p) {
     l_run += psum;
 
     A7_VMCNT4();    // this wave's share of tile t+ahead-1 has landed (tile t+ahead may still be in flight)
-    A7_BARRIER();   // ... and is published to the block
+    if (!(p.ablate & 2)) A7_BARRIER();   // ... and is published to the block
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail DMAs before the LDS is released
   if (grp == 0 && STAGGER) A7_BARRIER();             // re-balance the stagger
@@ -314,6 +316,7 @@ int icv_attn7_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, c
   att7::Params p;
   attc::fill_params(p, q, ldq, k, ldk, v, ldv, o, ldo, acc, ldacc, ml, state_in, state_out, Sq, Skv, heads, scale, att7::QB);
   if (p.sc == 1.0f && icv_get_option_int("attn_unit_scale", 1)) var |= 16;
+  p.ablate = icv_get_option_int("attn7_ablate", 0);   // timing experiments only (tools/attn_bench.py)
   switch (var) {
     case 0: return att7::launch<0>(p, st);
     case 1: return att7::launch<1>(p, st);

@@ -24,6 +24,7 @@ struct Params {
   int state_in, state_out;   // state_out: 0 = normalise + store bf16, 1 = write the carried state, 2 = normalise + ADD into bf16 o
   float sc;   // scale * log2(e)
   float thr;  // defer-max threshold, log2 units
+  int ablate; // timing ablations (attn7: 1 = no K/V DMA after the prologue, 2 = no per-tile barrier); results are then WRONG
 };
 
 inline void fill_params(Params& p, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
@@ -37,6 +38,7 @@ inline void fill_params(Params& p, const void* q, int64_t ldq, const void* k, in
   p.sc = scale * 1.4426950408889634f;
   if (fabsf(p.sc - 1.0f) < 1e-6f) p.sc = 1.0f;   // "unit scale": the caller folded scale * log2(e) into K (scale = ln 2)
   p.thr = (float)icv_get_option_int("attn_defer_max_log2", 8);
+  p.ablate = 0;
 }
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;

@@ -26,6 +26,8 @@ if os.environ.get("ATTN_ACC"):
         print(f"thr={thr}: max|err| {e.abs().max():.3e}  rms err {e.pow(2).mean().sqrt():.3e}  (rms ref {ref.pow(2).mean().sqrt():.3e})")
     ops.lib.icv_set_option(b"attn_defer_max_log2", int(os.environ.get("ATTN_THR", "8")))
 variants = [int(x) for x in os.environ.get("ATTN_VARIANTS", "5").split(",")]
+if os.environ.get("ATTN_ABLATE"):
+    ops.lib.icv_set_option(b"attn7_ablate", int(os.environ["ATTN_ABLATE"]))
 rounds = int(os.environ.get("ATTN_ROUNDS", "3"))
 SCALE = math.log(2.0) if os.environ.get("ATTN_UNIT") else 128 ** -0.5   # ATTN_UNIT=1: the DiT's unit-scale call (K carries the scale)
 for name, Sq, Skv, H in cases:
