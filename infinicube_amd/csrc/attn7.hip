@@ -55,12 +55,14 @@ __device__ __forceinline__ void dma16s(const void* base, unsigned off, unsigned 
 }
 
 // VAR bit flags: 1 = stagger wave groups, 2 = issue all 16 K-fragment reads ahead of the QK^T MFMAs,
-//                4 = s_setprio(1) around MFMA clusters, 16 = unit scale
+//                4 = s_setprio(1) around MFMA clusters, 8 = K/V DMA three tiles ahead instead of two (not with 1),
+//                16 = unit scale
 // (tried and dropped: row sums with v_pk_add_f32 — 8 fewer VALU issues per 32-key block, 1142.6 vs 1149.5 TF/s, noise:
 //  the kernel is power-limited, profiles/r02/power_limit_probes.md)
 template <int VAR>
 __global__ __launch_bounds__(512) void attn7_kernel(Params p) {
-  constexpr bool STAGGER = VAR & 1, KPREFETCH = VAR & 2, SETPRIO = VAR & 4, UNIT = VAR & 16;   // 16: unit scale (set by the dispatcher)
+  constexpr bool STAGGER = VAR & 1, KPREFETCH = VAR & 2, SETPRIO = VAR & 4, DEEP = VAR & 8, UNIT = VAR & 16;
+  static_assert(!(STAGGER && DEEP), "the staggered group already runs its DMA three tiles ahead");   // 16: unit scale (set by the dispatcher)
   const float p_lim = __builtin_amdgcn_exp2f(p.thr);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -131,7 +133,12 @@ __global__ __launch_bounds__(512) void attn7_kernel(Params p) {
       dma16(vh + r1_ * p.ldv + vcol1, l0_ + TILE_BYTES + 1024);                                      \
     }                                                                                                \
   }
-#define A7_VMCNT4() asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
+// counted wait: the youngest tile (4 DMA instructions per wave) - DEEP: the two youngest - may still be in flight
+#define A7_VMCNT4()                                              \
+  do {                                                           \
+    if (DEEP) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   \
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        \
+  } while (0)
 #define A7_BARRIER()                                          \
   do {                                                        \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        \
@@ -145,6 +152,7 @@ __global__ __launch_bounds__(512) void attn7_kernel(Params p) {
   // ---- prologue: tiles 0 and 1 in flight; tile 0 landed + published ----
   A7_DMA_TILE(0);
   A7_DMA_TILE(1);
+  if (DEEP) A7_DMA_TILE(2);
   A7_VMCNT4();
   A7_BARRIER();
   if (grp == 1) {   // group 1's idle interval I_0: it still owes its DMA duties (issue tile 2, retire tile 1)
@@ -159,7 +167,7 @@ __global__ __launch_bounds__(512) void attn7_kernel(Params p) {
   const int v_key_lo = 4 * hi + (t16 >> 2);
   const int v_byte_lo = (g & 1) * 32 + (t16 & 3) * 8;
   const int v_sw = (t16 >> 2) << 6;
-  const int ahead = 2 + grp;   // group 1 runs one tile behind, so its DMA duties are one tile further ahead
+  const int ahead = 2 + grp + (DEEP ? 1 : 0);   // group 1 runs one tile behind, so its DMA duties are one tile further ahead
 
   for (int t = 0; t < nt; ++t) {
     const char* ks = smem + (t & (NSTAGE - 1)) * STAGE_BYTES;
@@ -324,6 +332,8 @@ int icv_attn7_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, c
     case 5: return att7::launch<5>(p, st);
     case 6: return att7::launch<6>(p, st);
     case 7: return att7::launch<7>(p, st);
+    case 8: return att7::launch<8>(p, st);
+    case 24: return att7::launch<24>(p, st);
     case 16: return att7::launch<16>(p, st);
     case 17: return att7::launch<17>(p, st);
     case 20: return att7::launch<20>(p, st);
