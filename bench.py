@@ -291,13 +291,14 @@ def main():
     f_step = 2.0 * dit_forward_flops(cfg, grid.S)
     attn_peak = PEAK_BF16_TFLOPS if args.attn_dtype == "bf16" else PEAK_FP8_TFLOPS   # the dominant kernel's own MFMA peak
 
-    traffic = None
+    traffic, traffic_source = None, None
     try:   # HBM bytes per self-attention launch, measured offline with rocprofv3 PMC passes (see profiles/)
         tj = json.load(open(os.path.join(ROOT, "profiles", "attn_traffic.json")))
         if world == 1 and args.model in tj and (args.frames, args.height, args.width) == (93, 480, 832):
             traffic = tj[args.model]["hbm_bytes_per_launch"]
+            traffic_source = tj[args.model].get("source")
     except Exception:
-        traffic = None
+        traffic, traffic_source = None, None
     if rank == 0:
         out = {
             "metric": "denoise steps/sec, 93-frame 480p Wan2.1 buffer-conditioned DiT loop",
@@ -334,7 +335,7 @@ def main():
                 "kernel": "att7::attn7_kernel (self-attention, K6)" if args.attn_dtype == "bf16" else
                           "att8::attn8_kernel + its quantise pre-pass (e4m3 self-attention, K6)",
                 "bound": "mfma", "achieved": attn_tflops, "peak": attn_peak, "unit": "TFLOP/s",
-                "frac": attn_tflops / attn_peak, "traffic": traffic,
+                "frac": attn_tflops / attn_peak, "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_ms": attn_ms, "launches_timed": len(attn_events),
                 "algorithmic_flop_per_launch": attn_flops,
             },
