@@ -114,9 +114,9 @@ def main():
     ap.add_argument("--parallelism", default=os.environ.get("ICV_PARALLELISM", "auto"), choices=["auto", "sp", "cfg+sp"],
                     help="N>1: 'sp' = token shards over all N ranks, both CFG forwards on every rank; 'cfg+sp' = cond / "
                          "uncond forwards on two groups of N/2 ranks, token shards inside a group (auto when N is even)")
-    ap.add_argument("--kv-exchange", default=os.environ.get("ICV_KV_EXCHANGE", "allgather"), choices=["allgather", "p2p"],
+    ap.add_argument("--kv-exchange", default=os.environ.get("ICV_KV_EXCHANGE", "allgather"), choices=["allgather", "p2p", "native"],
                     help="N>1: K|V rows travel by all_gather_into_tensor (RCCL's schedule) or by grouped send/recv to every "
-                         "peer (the direct, fully-connected schedule; seqpar.KVGather)")
+                         "peer (the direct, fully-connected schedule), or by libicvideo's own RCCL communicator (icv_allgather_kv; seqpar.KVGather)")
     ap.add_argument("--native-forward", action="store_true",
                     help="drive each forward with ONE icv_dit_forward call (bf16, single GPU) instead of the per-op entry points; bit-identical")
     ap.add_argument("--share-stem", action="store_true",

@@ -279,6 +279,19 @@ int icv_dit_forward(icv_dit* ctx, const float* latent, int64_t C, int64_t H8, in
 int icv_dit_profile(icv_dit* ctx, int enable);
 int icv_dit_profile_read(icv_dit* ctx, double* total_ms, int64_t* launches);
 
+/* ---- K13: the sequence-parallel K|V exchange as a C entry point ---------------------------------
+ * Replaces: the fork's sequence-parallel attention gather (north_star "per-layer K/V all-gather"; upstream xDiT/USP
+ * all-gather of K and V inside `flash_attention`), for hosts that do not use torch.distributed (which
+ * infinicube_amd/videogen/seqpar.py does by default).  RCCL is dlopen'ed at first use.  rank 0 of the group makes the id,
+ * the host ships its ICV_COMM_ID_BYTES to the other ranks, every rank creates its communicator on its CURRENT device.
+ * icv_allgather_kv: rows [m, row_bytes] of every rank -> out [world * m, row_bytes], rank-major, enqueued on `stream`. */
+#define ICV_COMM_ID_BYTES 128
+typedef struct icv_comm icv_comm;
+int icv_comm_unique_id(char* id);
+int icv_comm_create(const char* id, int rank, int world, icv_comm** out);
+void icv_comm_destroy(icv_comm* comm);
+int icv_allgather_kv(icv_comm* comm, const void* rows, void* out, int64_t m, int64_t row_bytes, void* stream);
+
 /* ---- dtype plumbing: f32 -> bf16 (round-to-nearest-even), n elements ---------------------- */
 int icv_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 

@@ -12,7 +12,7 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$root/include" -I"$here" -W
 objs=()
 pids=()
 mkdir -p "$here/build"
-srcs=(api elementwise gemm gemm256 gemm_fp8 fp8 attention attn2 attn7 attn8 buffers voxels dit_forward)
+srcs=(api elementwise gemm gemm256 gemm_fp8 fp8 attention attn2 attn7 attn8 buffers voxels dit_forward comm)
 tag=""
 if [[ "${ICV_EXPERIMENTS:-0}" == "1" ]]; then
   srcs+=(experiments/attn1 experiments/attn3 experiments/attn4 experiments/attn5 experiments/attn6 experiments/attn9 experiments/gemm256w)
@@ -31,6 +31,6 @@ for src in "${srcs[@]}"; do
   objs+=("$obj")
 done
 for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$out"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -ldl -o "$out"
 python3 -c "import ctypes,sys; ctypes.CDLL(sys.argv[1])" "$out"   # unresolved symbols fail here, not on the GPU box
 echo "built $out"

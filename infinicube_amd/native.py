@@ -69,9 +69,15 @@ SIGNATURES.update({
     "icv_dit_destroy": (None, [c_void_p]),
     "icv_dit_bind": (c_int, [c_void_p, c_char_p, _I, _P]),
     "icv_dit_forward": (c_int, [c_void_p, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P, _P, _I, c_int, _F, _P]),
+    "icv_comm_unique_id": (c_int, [c_char_p]),
+    "icv_comm_create": (c_int, [c_char_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "icv_comm_destroy": (None, [c_void_p]),
+    "icv_allgather_kv": (c_int, [c_void_p, _P, _P, _I, _I, _P]),
     "icv_dit_profile": (c_int, [c_void_p, c_int]),
     "icv_dit_profile_read": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
 })
+
+COMM_ID_BYTES = 128   # ICV_COMM_ID_BYTES
 
 _lib: Optional[ctypes.CDLL] = None
 

@@ -113,9 +113,12 @@ class KVGather:
       * ``"allgather"``: ``all_gather_into_tensor`` — RCCL picks the schedule (a ring costs (world-1) hops);
       * ``"p2p"``: one grouped ``isend``/``irecv`` pair per peer (``batch_isend_irecv`` = ncclGroupStart/End around
         ncclSend/ncclRecv) — the fully-connected schedule xGMI is built for: each of the 7 links of a GPU carries exactly
-        one peer's shard, once (0.63 ms instead of 4.4 ms per 14B layer at world 8 if RCCL rings)."""
+        one peer's shard, once (SURVEY.md §8e: 0.63 ms instead of 4.4 ms per 14B layer at world 8 if RCCL rings);
+      * ``"native"``: ``icv_allgather_kv`` of libicvideo on this group's own RCCL communicator (``icv_comm_create``; the id
+        travels through the torch.distributed group once) and a dedicated HIP stream fenced with events — the same
+        transfer without torch.distributed in the per-layer path (SURVEY §8b's C export; GPU ranks only)."""
 
-    MODES = ("allgather", "p2p")
+    MODES = ("allgather", "p2p", "native")
 
     def __init__(self, plan: ShardPlan, group=None, mode: Optional[str] = None):
         import os
@@ -135,12 +138,17 @@ class KVGather:
             self.peers = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
             if len(self.peers) != plan.world:
                 raise ValueError(f"K/V exchange group has {len(self.peers)} ranks, the shard plan {plan.world}")
+            self._native = None
+            if self.mode == "native":
+                self._native = _NativeComm(dist, group, self.peers, plan.rank, plan.world)
 
     def start(self, rows: torch.Tensor, out: torch.Tensor):
         if self.plan.world == 1:
             raise RuntimeError("KVGather used with world == 1 (attend over the local buffers directly)")
         assert rows.is_contiguous() and out.is_contiguous() and out.shape[0] == self.plan.world * rows.shape[0]
         self.n_collectives += 1
+        if self.mode == "native":
+            return (self._native.allgather(rows, out),)
         if self.mode == "allgather":
             return (self.dist.all_gather_into_tensor(out, rows, group=self.group, async_op=True),)
         m, dist = rows.shape[0], self.dist
@@ -164,6 +172,56 @@ class KVGather:
             return
         for w in handle:
             w.wait()   # nccl: the CURRENT STREAM waits (host does not block); gloo: host blocks
+
+
+class _NativeComm:
+    """libicvideo's own RCCL communicator for one sequence-parallel group + a side stream (KVGather mode "native")."""
+
+    def __init__(self, dist, group, peers, rank: int, world: int):
+        import ctypes
+        from .. import native
+        self.lib, self.native = native.lib(), native
+        dev = torch.device("cuda", torch.cuda.current_device())
+        idbuf = ctypes.create_string_buffer(native.COMM_ID_BYTES)
+        if rank == 0:
+            native.check(self.lib.icv_comm_unique_id(idbuf), "icv_comm_unique_id")
+        # ship the id through the existing process group (nccl groups move device tensors, gloo host tensors)
+        on_dev = dist.get_backend(group) == "nccl"
+        t = torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8).clone()
+        t = t.to(dev) if on_dev else t
+        dist.broadcast(t, src=peers[0], group=group)
+        h = ctypes.c_void_p()
+        native.check(self.lib.icv_comm_create(bytes(t.cpu().tolist()), rank, world, ctypes.byref(h)), "icv_comm_create")
+        self.handle = h
+        self.stream = torch.cuda.Stream(device=dev)
+
+    def allgather(self, rows: torch.Tensor, out: torch.Tensor):
+        ready = torch.cuda.Event()
+        ready.record()                                   # the rows were produced on the compute stream
+        self.stream.wait_event(ready)
+        self.native.check(self.lib.icv_allgather_kv(self.handle, rows.data_ptr(), out.data_ptr(), rows.shape[0],
+                                                    rows.shape[1] * rows.element_size(), self.stream.cuda_stream), "icv_allgather_kv")
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        return _EventWork(done)
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h is not None:
+            try:
+                self.lib.icv_comm_destroy(h)
+            except Exception:  # pragma: no cover - interpreter shutdown
+                pass
+
+
+class _EventWork:
+    """wait() = the current stream waits for the transfer (like an async nccl work handle)."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
 
 
 def chunk_bounds(n_rows: int, chunks: int):

@@ -274,8 +274,11 @@ def test_sequence_parallel_path_on_one_gpu(hip_ops, chunks, model, gemm_dtype):
     assert rel < (6e-2 if attn_dtype == "fp8" else 5e-3), f"sharded vs unsharded forward rel-L2 {rel}"
 
 
-def test_sequence_parallel_gather_on_rccl_stream(hip_ops):
-    """The same sharded path, but each shard's OWN K/V rows travel through a real RCCL collective
+@pytest.mark.parametrize("transport", ["torch", "native"])
+def test_sequence_parallel_gather_on_rccl_stream(hip_ops, transport):
+    """transport = "torch": torch.distributed's collective; "native": libicvideo's own RCCL communicator and side stream
+    (icv_comm_unique_id / icv_comm_create / icv_allgather_kv, seqpar._NativeComm), id shipped through the nccl group.
+    The same sharded path, but each shard's OWN K/V rows travel through a real RCCL collective
     (`nccl` backend, a one-rank group: the only RCCL this one-GPU box can run) issued async on RCCL's
     stream while the compute stream keeps projecting Q; peer rows come from the unsharded run.  Checks
     the stream hand-off KVGather relies on: the collective must see K/V written by earlier kernels on
@@ -305,6 +308,8 @@ def test_sequence_parallel_gather_on_rccl_stream(hip_ops):
     finally:
         hip_ops.attention = raw
     chunks, outs = 3, []
+    from infinicube_amd.videogen.seqpar import _NativeComm
+    ncomm = _NativeComm(dist, None, [0], 0, 1) if transport == "native" else None
     for r in range(2):
         plan = ShardPlan.make(grid.S, 2, r)
         n = plan.n_tok
@@ -319,7 +324,10 @@ def test_sequence_parallel_gather_on_rccl_stream(hip_ops):
                 m, r0, peer = rows.shape[0], self.r0, 1 - r
                 out[peer * m:(peer + 1) * m, :dd].copy_(kf[peer * n + r0: peer * n + r0 + m])
                 out[peer * m:(peer + 1) * m, dd:].copy_(vf[peer * n + r0: peer * n + r0 + m])
-                h = (dist.all_gather_into_tensor(out[r * m:(r + 1) * m], rows, async_op=True),)
+                if ncomm is not None:
+                    h = (ncomm.allgather(rows, out[r * m:(r + 1) * m]),)
+                else:
+                    h = (dist.all_gather_into_tensor(out[r * m:(r + 1) * m], rows, async_op=True),)
                 self.calls += 1
                 self.r0 += m
                 if self.calls % chunks == 0:
