@@ -5,6 +5,7 @@ Tolerance (SURVEY.md §8d, bf16 outputs vs fp32 oracle on identical bf16-rounded
 fp32 outputs use rtol 1e-4 of rms unless noted.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -895,3 +896,14 @@ def test_single_frame_generation_grid(hip_ops):
     v = R.unpatchify(m.head_out[0].cpu(), (grid.T, grid.Hp, grid.Wp), cfg.out_dim)
     ref = R.dit_forward(R.round_state_dict_to_bf16(sd), cfg, noise, ctx, 500.0, R.buffer_embed(R.round_state_dict_to_bf16(bsd), bl))
     assert float((v - ref).norm() / ref.norm()) < 2e-2
+
+
+def test_fuzz_gemm_and_attention_20s():
+    """tools/fuzz_kernels.py for 20 s (seed 7): random ragged shapes, strides, epilogues, tile families, schedules, key
+    chunks of both MFMA entry points against stock PyTorch fp32 on the GPU, every launch repeated bit-identically.
+    (A 240 s + 150 s run of the same tool is recorded in profiles/r02/fuzz_kernels.txt.)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_kernels.py"), "20", "7"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " 0 failures" in r.stdout

@@ -1,0 +1,167 @@
+"""Randomised differential test of the two MFMA kernels' C entry points (run on the GPU box).
+
+Shapes are drawn at random inside each entry point's documented contract (ragged M / N / Sq / Skv, strided operands,
+split-plane outputs, every epilogue, both tile families, carried-state key chunks) and each result is compared with a
+stock PyTorch fp32 computation of the same op on the GPU (test infrastructure; independent of libicvideo).  Every launch
+is repeated and must be bit-identical (race screen for the counted-vmcnt rings).
+
+    python tools/fuzz_kernels.py [seconds] [seed]      -> prints one line per failure and a summary; exit code 1 on any failure
+"""
+import math
+import os
+import random
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+from infinicube_amd.videogen.ops import EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_F32, HipOps  # noqa: E402
+
+DEV = "cuda:0"
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = random.Random(seed)
+ops = HipOps(DEV)
+fails = []
+
+
+def close_bf16(got, ref, what, abs_floor=2.0 ** -8, rms_bound=None):
+    """the test suite's per-op bar (tests/test_kernels_gpu.py assert_bf16_close): |d| <= 2^-7 |ref| + abs_floor * rms(ref),
+    and optionally rms(d) <= rms_bound * rms(ref)"""
+    got, ref = got.float(), ref.float()
+    rms = float(ref.pow(2).mean().sqrt())
+    err = (got - ref).abs()
+    bad = err > 2.0 ** -7 * ref.abs() + abs_floor * rms
+    rms_err = float((got - ref).pow(2).mean().sqrt())
+    if not torch.isfinite(got).all() or bad.any() or (rms_bound is not None and rms_err > rms_bound * rms):
+        fails.append(f"{what}: {int(bad.sum())} of {bad.numel()} outside tolerance, max err {float(err.max()):.4g}, rms err {rms_err:.3g} vs rms {rms:.3g}")
+        return False
+    return True
+
+
+def close_f32(got, ref, what, rtol=3e-3):
+    err = float((got.float() - ref).abs().max())
+    scale = float(ref.abs().max()) + 1e-6
+    if not torch.isfinite(got).all() or err > rtol * scale:
+        fails.append(f"{what}: max err {err:.4g} vs scale {scale:.4g}")
+        return False
+    return True
+
+
+def fuzz_gemm():
+    M = rng.choice([1, 7, 63, 64, 65, 127, 129, 255, 256, 257, 300, 511, 513, 777, 1000, 1500, 2049]) if rng.random() < 0.7 else rng.randint(1, 3000)
+    N = 4 * rng.choice([1, 3, 16, 31, 32, 33, 64, 65, 96, 128, 192, 256, 320, 384, 513]) if rng.random() < 0.7 else 4 * rng.randint(1, 700)
+    K = 64 * rng.choice([1, 2, 3, 4, 8, 16, 24, 32, 41])
+    epi = rng.choice([EPI_BF16, EPI_GELU_BF16, EPI_RESID_F32, EPI_F32])
+    tile = rng.choice([0, 1, 2])         # 128-tile kernel, 256-tile kernel, heuristic
+    mfma = rng.choice([16, 16, 32])
+    sched = rng.choice([0, 1, 2, 3])
+    pad = rng.choice([0, 0, 64])         # strided A
+    ops.lib.icv_set_option(b"gemm256", tile); ops.lib.icv_set_option(b"gemm256_mfma", mfma); ops.lib.icv_set_option(b"gemm256_sched", sched)
+    g = torch.Generator(device=DEV).manual_seed(rng.randint(0, 2 ** 31))
+    a_full = torch.randn((M, K + pad), device=DEV, generator=g).to(torch.bfloat16)
+    a = a_full[:, :K]
+    w = (torch.randn((N, K), device=DEV, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    bias = torch.randn((N,), device=DEV, generator=g) * 0.1 if rng.random() < 0.8 else None
+    acc = a.float() @ w.float().t() + (bias if bias is not None else 0.0)
+    what = f"gemm M={M} N={N} K={K} epi={epi} tile={tile} mfma={mfma} sched={sched} pad={pad} bias={bias is not None}"
+    if epi in (EPI_BF16, EPI_GELU_BF16):
+        ref = F.gelu(acc, approximate="tanh") if epi == EPI_GELU_BF16 else acc
+        nsplit = None
+        if epi == EPI_BF16 and N % 12 == 0 and rng.random() < 0.4:
+            nsplit = N // 3
+        outs = []
+        for _ in range(2):
+            out = torch.full((M, N) if nsplit is None else (3, M, nsplit), 7.0, dtype=torch.bfloat16, device=DEV)
+            ops.gemm(a, w, bias, out, epi, **({} if nsplit is None else {"nsplit": nsplit}))
+            outs.append(out)
+        if nsplit is not None:
+            ref = ref.reshape(M, 3, nsplit).permute(1, 0, 2)
+            what += f" nsplit={nsplit}"
+        ok = close_bf16(outs[0], ref, what)
+    elif epi == EPI_RESID_F32:
+        resid = torch.randn((M, N), device=DEV, generator=g)
+        gate = torch.randn((N,), device=DEV, generator=g) if rng.random() < 0.7 else None
+        outs = []
+        for _ in range(2):
+            x = resid.clone()
+            ops.gemm(a, w, bias, x, epi, resid=x, gate=gate)
+            outs.append(x)
+        ok = close_f32(outs[0], resid + (gate if gate is not None else 1.0) * acc, what + f" gate={gate is not None}")
+    else:
+        outs = []
+        for _ in range(2):
+            out = torch.empty((M, N), device=DEV)
+            ops.gemm(a, w, bias, out, epi)
+            outs.append(out)
+        ok = close_f32(outs[0], acc, what)
+    if ok and not torch.equal(outs[0], outs[1]):
+        fails.append(what + ": two identical launches differ (race?)")
+
+
+def ref_attention(q, k, v, H, scale):
+    Sq, Skv = q.shape[0], k.shape[0]
+    qh, kh, vh = (t.float().reshape(-1, H, 128).transpose(0, 1) for t in (q, k, v))
+    return (torch.softmax(qh @ kh.transpose(1, 2) * scale, -1) @ vh).transpose(0, 1).reshape(Sq, H * 128)
+
+
+def fuzz_attention():
+    H = rng.choice([1, 2, 3, 5])
+    Sq = rng.choice([1, 31, 32, 33, 255, 256, 257, 300, 511, 513, 1000]) if rng.random() < 0.7 else rng.randint(1, 1500)
+    Skv = rng.choice([1, 63, 64, 65, 127, 128, 129, 257, 512, 640, 1100, 3000]) if rng.random() < 0.7 else rng.randint(1, 4000)
+    d = H * 128
+    unit = rng.random() < 0.5            # the DiT's call: the softmax scale folded into K, scale argument = ln 2
+    var = rng.choice([0, 0, 1, 4, 8])
+    ops.lib.icv_set_option(b"attn_kernel", 7); ops.lib.icv_set_option(b"attn7_variant", var)
+    g = torch.Generator(device=DEV).manual_seed(rng.randint(0, 2 ** 31))
+    amp = rng.choice([1.0, 1.0, 3.0])    # larger scores stress the lazy-max rescale path
+    q = (torch.randn((Sq, d), device=DEV, generator=g) * amp).to(torch.bfloat16)
+    k = torch.randn((Skv, d), device=DEV, generator=g).to(torch.bfloat16)
+    v = torch.randn((Skv, d), device=DEV, generator=g).to(torch.bfloat16)
+    if rng.random() < 0.5:               # a few keys aligned with a query: a late, large maximum
+        k[Skv - 1] = q[min(3, Sq - 1)]
+        k[Skv // 2] = q[min(40, Sq - 1)]
+    scale = 128 ** -0.5
+    if unit:
+        k = (k.float() * (scale * math.log2(math.e))).to(torch.bfloat16)
+        ref = ref_attention(q, k, v, H, math.log(2.0))
+        call_scale = math.log(2.0)
+    else:
+        ref = ref_attention(q, k, v, H, scale)
+        call_scale = scale
+    what = f"attention Sq={Sq} Skv={Skv} H={H} unit={unit} variant={var} amp={amp}"
+    chunks = rng.choice([1, 1, 2, 3]) if Skv >= 8 else 1
+    outs = []
+    for _ in range(2):
+        o = torch.zeros((Sq, d), dtype=torch.bfloat16, device=DEV)
+        if chunks == 1:
+            ops.attention(q, k, v, o, H, call_scale)
+        else:                              # the sequence-parallel form: key chunks with the carried fp32 softmax state
+            acc = torch.empty((Sq, d), device=DEV)
+            ml = torch.empty((Sq, H, 2), device=DEV)
+            cuts = sorted(rng.sample(range(1, Skv), chunks - 1)) if _ == 0 else cuts
+            b = [0] + cuts + [Skv]
+            for c in range(chunks):
+                ops.attention_chunk(q, k[b[c]:b[c + 1]], v[b[c]:b[c + 1]], o, acc, ml, H, call_scale, first=(c == 0), last=(c == chunks - 1))
+        outs.append(o)
+    ok = close_bf16(outs[0], ref, what + f" chunks={chunks}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
+    if ok and not torch.equal(outs[0], outs[1]):
+        fails.append(what + ": two identical launches differ (race?)")
+
+
+t0, n = time.time(), {"gemm": 0, "attention": 0}
+try:
+    while time.time() - t0 < budget:
+        if rng.random() < 0.6:
+            fuzz_gemm(); n["gemm"] += 1
+        else:
+            fuzz_attention(); n["attention"] += 1
+finally:
+    ops.lib.icv_set_option(b"gemm256", 2); ops.lib.icv_set_option(b"gemm256_mfma", 16); ops.lib.icv_set_option(b"gemm256_sched", 3)
+    ops.lib.icv_set_option(b"attn_kernel", 7); ops.lib.icv_set_option(b"attn7_variant", 0)
+torch.cuda.synchronize()
+for f in fails[:40]:
+    print("FAIL", f)
+print(f"fuzz seed {seed}: {n['gemm']} GEMM cases, {n['attention']} attention cases in {time.time() - t0:.0f} s, {len(fails)} failures")
+sys.exit(1 if fails else 0)
