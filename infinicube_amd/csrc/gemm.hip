@@ -172,6 +172,10 @@ int icv_gemm256w_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw
                           int64_t M, int64_t N, int64_t K, int epilogue, void* out, int64_t ldo,
                           int64_t nsplit, int64_t split_stride, const float* resid, int64_t ldr,
                           const float* gate, hipStream_t st);
+int icv_gemm256x_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                          int64_t M, int64_t N, int64_t K, int epilogue, void* out, int64_t ldo,
+                          int64_t nsplit, int64_t split_stride, const float* resid, int64_t ldr,
+                          const float* gate, hipStream_t st);
 int icv_gemm256_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                          int64_t M, int64_t N, int64_t K, int epilogue, void* out, int64_t ldo,
                          int64_t nsplit, int64_t split_stride, const float* resid, int64_t ldr,
@@ -203,6 +207,15 @@ extern "C" int icv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t 
                                    resid, ldr, gate, (hipStream_t)stream);
 #else
       icv_set_error("gemm256 = 3 is an experiment: rebuild libicvideo with ICV_EXPERIMENTS=1");
+      return 1;
+#endif
+    }
+    if (mode == 4) {  // experiment: 4 waves x (128 x 128), whole-tile double buffer, one barrier per K-tile (experiments/gemm256x.hip)
+#ifdef ICV_EXPERIMENTS
+      return icv_gemm256x_dispatch(A, lda, W, ldw, bias, M, N, K, epilogue, out, ldo, nsplit, split_stride,
+                                   resid, ldr, gate, (hipStream_t)stream);
+#else
+      icv_set_error("gemm256 = 4 is an experiment: rebuild libicvideo with ICV_EXPERIMENTS=1");
       return 1;
 #endif
     }

@@ -820,15 +820,17 @@ def test_attention_add_into_output(hip_ops, Sq, Skv, H):
 
 @pytest.mark.parametrize("M,N,K,epi", [(256, 256, 64, "f32"), (300, 512, 192, "f32"), (1000, 768, 1536, "bf16"), (513, 1024, 512, "gelu"),
                                        (640, 512, 1280, "resid"), (515, 768, 384, "split")])
-def test_gemm_4wave_variant(hip_ops, M, N, K, epi):
+@pytest.mark.parametrize("kernel", [3, 4])
+def test_gemm_4wave_variant(hip_ops, M, N, K, epi, kernel):
     """gemm256w.hip (option gemm256 = 3): 4 waves x 128x128 wave tiles, accumulators pinned to AGPRs, fragments read one
-    half-phase ahead.  Same results as the default kernels for every epilogue and for ragged M."""
+    half-phase ahead; gemm256x.hip (= 4): the same wave tiles with whole-tile double buffering and one barrier per K-tile.
+    Same results as the default kernels for every epilogue and for ragged M."""
     need_experiments(hip_ops)
     a = rnd((M, K), 431).to(torch.bfloat16)
     w = rnd((N, K), 432, 1.0 / math.sqrt(K)).to(torch.bfloat16)
     bias = rnd((N,), 433, 0.1)
     acc = a.float() @ w.float().t() + bias
-    hip_ops.lib.icv_set_option(b"gemm256", 3)
+    hip_ops.lib.icv_set_option(b"gemm256", kernel)
     try:
         if epi == "f32":
             out = torch.full((M + 1, N), 5.0, device=DEV)

@@ -17,8 +17,8 @@ for name, M, N, K, epi in shapes:
     bias = torch.randn((N,), device="cuda")
     out = torch.empty((M, N), device="cuda", dtype=torch.float32 if epi == EPI_RESID_F32 else torch.bfloat16)
     res = {}
-    for variant in (0, 1, 2, 3) + ((4,) if ops.lib.icv_set_option(b"require_experiments", 1) == 0 else ()):
-        ops.lib.icv_set_option(b"gemm256", 3 if variant == 4 else (min(variant, 1) if variant != 2 else 2))
+    for variant in (0, 1, 2, 3) + ((4, 5) if ops.lib.icv_set_option(b"require_experiments", 1) == 0 else ()):
+        ops.lib.icv_set_option(b"gemm256", 4 if variant == 5 else 3 if variant == 4 else (min(variant, 1) if variant != 2 else 2))
         ops.lib.icv_set_option(b"gemm256_mfma", 32 if variant == 3 else 16)
         kw = dict(resid=out, gate=bias) if epi == EPI_RESID_F32 else {}
         for _ in range(2):
@@ -45,5 +45,5 @@ for name, M, N, K, epi in shapes:
         e1.record(); torch.cuda.synchronize()
         res["lib"] = 2.0 * M * N * K / (e0.elapsed_time(e1) / 10) / 1e9
         print(f"{name:14s} vendor-library bf16 GEMM (no epilogue): {res['lib']:7.1f} TF")
-    print(f"{name:14s} M={M} N={N} K={K}: 128-tile {res[0]:7.1f} TF | 256-tile {res[1]:7.1f} TF | heuristic {res[2]:7.1f} TF | 256-tile/mfma32 {res[3]:7.1f} TF " + (f" | 4-wave 128x128 {res[4]:7.1f} TF" if 4 in res else ""))
+    print(f"{name:14s} M={M} N={N} K={K}: 128-tile {res[0]:7.1f} TF | 256-tile {res[1]:7.1f} TF | heuristic {res[2]:7.1f} TF | 256-tile/mfma32 {res[3]:7.1f} TF " + (f" | 4-wave 128x128 {res[4]:7.1f} TF | 4-wave 1-barrier {res[5]:7.1f} TF" if 4 in res else ""))
 ops.lib.icv_set_option(b"gemm256", 2); ops.lib.icv_set_option(b"gemm256_mfma", 16)

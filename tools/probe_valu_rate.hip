@@ -9,6 +9,7 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define REP16(X) X X X X X X X X X X X X X X X X
 
@@ -48,6 +49,27 @@ __device__ __forceinline__ void body(float (&r)[16], f32x2 (&q)[8], f32x16& acc,
     for (int i = 0; i < 16; ++i) {
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
       asm volatile("v_exp_f32 %0, %0" : "+v"(r[i]));
+    }
+  } else if (OP == 11) {   // 16 INDEPENDENT v_mfma_f32_16x16x32_bf16 (4 passes each), accumulators aliased onto acc / r / q
+    f32x4* a4 = reinterpret_cast<f32x4*>(&acc);
+    f32x4* r4 = reinterpret_cast<f32x4*>(&r[0]);
+    f32x4* q4 = reinterpret_cast<f32x4*>(&q[0]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a4[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, a4[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r4[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, r4[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q4[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, q4[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a4[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, a4[i], 0, 0, 0);
+  } else if (OP == 12) {   // 16 v_mfma_f32_32x32x16_bf16 on 3 rotating accumulators (independent neighbours)
+    f32x16* r16 = reinterpret_cast<f32x16*>(&r[0]);
+    f32x16* q16 = reinterpret_cast<f32x16*>(&q[0]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (i % 3 == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+      else if (i % 3 == 1) *r16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, *r16, 0, 0, 0);
+      else *q16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, *q16, 0, 0, 0);
     }
   } else if (OP == 10) {   // the fast path's VALU mix per MFMA: 1 exp + 1 add + 1/2 cvt, next to each MFMA
 #pragma unroll
@@ -118,6 +140,9 @@ int main() {
   run<6, 0>("v_max_f32", 256, 16);
   run<3, 0>("v_cvt_pk_bf16_f32", 256, 16);
   run<8, 0>("v_mfma_f32_32x32x16_bf16 (dependent chain)", 256, 16);
+  run<11, 0>("v_mfma_f32_16x16x32_bf16 x16 independent", 256, 16);
+  run<12, 0>("v_mfma_f32_32x32x16_bf16 3 rotating accumulators", 256, 16);
+  run<11, 0>("v_mfma_f32_16x16x32_bf16 x16 independent", 512, 16);
   run<1, 0>("v_add_f32", 512, 16);
   run<0, 0>("v_exp_f32", 512, 16);
   run<8, 0>("v_mfma_f32_32x32x16_bf16", 512, 16);
