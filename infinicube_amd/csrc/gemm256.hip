@@ -49,6 +49,7 @@ struct Params {
   const float* gate;
   int tiles_m, tiles_n;
   int gm;   // M-tiles per group of the grouped tile order
+  int ablate;   // timing experiments ("gemm256_ablate"): 1 = no DMA inside the main loop, 2 = every DMA re-reads K-tile 0 (L2-resident source); results are then WRONG
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -123,7 +124,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
   const char* Ab = reinterpret_cast<const char*>(p.A);
   const char* Wb = reinterpret_cast<const char*>(p.W);
   const int nt = (int)(p.K / BK);
-  auto kbyte = [&](int t) -> int64_t { return (int64_t)(t < nt ? t : nt - 1) * (BK * 2); };
+  const bool k0_only = p.ablate & 2;
+  auto kbyte = [&](int t) -> int64_t { return k0_only ? 0 : (int64_t)(t < nt ? t : nt - 1) * (BK * 2); };
 
   f32x4 acc[8][4];     // MF == 16
   f32x16 acc32[4][2];  // MF == 32
@@ -212,8 +214,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
         for (int i = 0; i < NAF; ++i)
           af[i][ks] = *reinterpret_cast<const bf16x8*>(cur + U_A0 * UNIT_BYTES + a_off[ks] + i * FROWS);
       }
-      dma_unit(Wb, offB[1], kbyte(t + 1), oth + U_B1 * UNIT_BYTES, wave);
-      dma_unit(Ab, offA[1], kbyte(t + 1), oth + U_A1 * UNIT_BYTES, wave);
+      if (!(p.ablate & 1)) dma_unit(Wb, offB[1], kbyte(t + 1), oth + U_B1 * UNIT_BYTES, wave);
+      if (!(p.ablate & 1)) dma_unit(Ab, offA[1], kbyte(t + 1), oth + U_A1 * UNIT_BYTES, wave);
       asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
       G256_BARRIER();
       G256_MFMA(0, b0f, 0);
@@ -225,8 +227,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
 #pragma unroll
         for (int i = 0; i < NAF; ++i)
           af[i][ks] = *reinterpret_cast<const bf16x8*>(cur + U_A1 * UNIT_BYTES + a_off[ks] + i * FROWS);
-      dma_unit(Ab, offA[0], kbyte(t + 2), cur + U_A0 * UNIT_BYTES, wave);
-      dma_unit(Wb, offB[0], kbyte(t + 2), cur + U_B0 * UNIT_BYTES, wave);
+      if (!(p.ablate & 1)) dma_unit(Ab, offA[0], kbyte(t + 2), cur + U_A0 * UNIT_BYTES, wave);
+      if (!(p.ablate & 1)) dma_unit(Wb, offB[0], kbyte(t + 2), cur + U_B0 * UNIT_BYTES, wave);
       asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
       G256_BARRIER();
       G256_MFMA(1, b0f, 0);
@@ -405,6 +407,7 @@ int icv_gemm256_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw,
   p.tiles_m = (int)((M + g256::BM - 1) / g256::BM);
   p.tiles_n = (int)((N + g256::BN - 1) / g256::BN);
   p.gm = icv_get_option_int("gemm256_gm", 4);
+  p.ablate = icv_get_option_int("gemm256_ablate", 0);
   const bool m32 = icv_get_option_int("gemm256_mfma", 16) == 32;
   // schedule variant (A/B switch "gemm256_sched"): bit 0 = two 32-MFMA phases per K-tile, bit 1 = batched residual loads
   const int sch = icv_get_option_int("gemm256_sched", G256_SCHED_DEFAULT) & 3;
