@@ -486,3 +486,24 @@ def test_native_forward_matches_python_driver(hip_ops, name):
     bad = native.DitConfig(dim=100, ffn_dim=64, heads=1, layers=1, n_tok=4, tok0=0, T=1, Hp=2, Wp=2, k_patch=64, out_cols=64, eps=1e-6)
     hh = ctypes.c_void_p()
     assert hip_ops.lib.icv_dit_create(ctypes.byref(bad), ctypes.byref(hh)) != 0
+
+
+def test_native_forward_under_graph_replay(hip_ops):
+    """icv_dit_forward inside hipGraph capture (graphs=True: every forward after the first is a replay): the C driver only
+    enqueues on the capture stream, so the replayed loop equals the eager per-op loop bit for bit."""
+    cfg, grid = preset("tiny"), TokenGrid(9, 64, 96)
+    sd, bsd = syn.make_dit_state_dict(cfg), syn.make_buffer_embedder_state_dict(cfg)
+    noise, c1, c2 = syn.make_latent_noise(grid), syn.make_text_context(cfg, 1), syn.make_text_context(cfg, 2)
+    bl = syn.make_buffer_latents(cfg, grid)
+    outs = []
+    for native_on, graphs in ((False, False), (True, True)):
+        m = WanDiT(cfg, sd, hip_ops, bsd).prepare(grid, graphs=graphs)
+        m.native_forward = native_on
+        ck, cu, add = m.encode_context(c1), m.encode_context(c2), m.embed_buffers(bl)
+        lat = noise.clone().to("cuda:0")
+        m.denoise(lat, ck, cu, add, FlowMatchScheduler(4), 5.0)
+        torch.cuda.synchronize()
+        if graphs:
+            assert m._graphs_on and len(m._graphs) >= 1
+        outs.append(lat.cpu())
+    assert torch.equal(outs[0], outs[1])
