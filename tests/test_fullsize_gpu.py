@@ -299,3 +299,38 @@ def test_config3_wan_14b_one_step_full_depth(hip_ops):
           f"uncond forward rel-L2 {ru:.4g} cos {cu_:.6f}; CFG velocity rel-L2 {rv:.4g} cos {cv:.6f}; latent PSNR after the step {p:.1f} dB")
     assert cc >= 0.999 and rc <= 2e-2 and cu_ >= 0.999 and ru <= 2e-2, f"config #3 forward parity: cond {rc}/{cc}, uncond {ru}/{cu_}"
     assert cv >= 0.999 and rv <= 5e-2 and p >= 40.0, f"config #3 one-step parity: CFG velocity rel-L2 {rv}, cosine {cv}, PSNR {p:.1f} dB"
+
+
+def test_config3_wan_14b_four_step_loop_full_depth(hip_ops):
+    """Config #3's LOOP at full depth and size: Wan2.1-14B, S = 37 440, a complete 4-step flow-match schedule from noise
+    to sigma 0 with CFG 5 (8 forwards of 40 layers), product loop (WanDiT.denoise) vs oracle/wan_ref.denoise_loop run in
+    fp32 by stock PyTorch on the GPU on the same bf16-rounded weights.  Bar: final-latent PSNR >= 40 dB (north star) and
+    decoded-frame PSNR >= 40 dB through the same pooling VAE on both arms."""
+    from infinicube_amd.videogen.standins import PoolVAE
+    cfg, grid, steps = preset("14b"), GRID_480P, 4
+    sd = syn.make_dit_state_dict(cfg, seed=0, device=DEV, dtype=torch.bfloat16)
+    bsd = syn.make_buffer_embedder_state_dict(cfg, device=DEV, dtype=torch.bfloat16)
+    noise = syn.make_latent_noise(grid)
+    c1, c2, bl = syn.make_text_context(cfg, 1), syn.make_text_context(cfg, 2), syn.make_buffer_latents(cfg, grid)
+    m = WanDiT(cfg, sd, hip_ops, bsd).prepare(grid, graphs=False)
+    lat = noise.clone().to(DEV)
+    ck, cu, bt = m.encode_context(c1), m.encode_context(c2), m.embed_buffers(bl)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    m.denoise(lat, ck, cu, bt, FlowMatchScheduler(steps), 5.0)
+    torch.cuda.synchronize()
+    t_hip = time.time() - t0
+    lat = lat.cpu()
+    del m, ck, cu, bt
+    torch.cuda.empty_cache()
+    sdr = {k: v.float() for k, v in sd.items()}
+    bsdr = {k: v.float() for k, v in bsd.items()}
+    del sd, bsd
+    torch.cuda.empty_cache()
+    t0 = time.time()
+    ref = R.denoise_loop(sdr, bsdr, cfg, noise.to(DEV), c1.to(DEV), c2.to(DEV), bl.to(DEV), num_steps=steps).cpu()
+    t_ref = time.time() - t0
+    p = R.psnr(lat, ref)
+    pf = frame_psnr(lat, ref, PoolVAE())
+    print(f"config #3, {steps}-step loop at full depth: HIP {t_hip:.1f}s, fp32 torch oracle on GPU {t_ref:.1f}s; latent PSNR {p:.1f} dB, frame PSNR {pf:.1f} dB")
+    assert torch.isfinite(lat).all() and p >= 40.0 and pf >= 40.0, f"config #3 {steps}-step loop: latent PSNR {p:.1f} dB, frame PSNR {pf:.1f} dB"
