@@ -143,6 +143,67 @@ __global__ __launch_bounds__(512) void mix(long long* out, float* sink, int tile
   if (lane == 0) out[blockIdx.x * 8 + wave] = t1 - t0;
 }
 
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+// MFMA only, e4m3: 16 x v_mfma_scale_f32_32x32x64_f8f6f4 (unit scales) per wave per "tile" = the same 32768 x 32 flops as the
+// 32 bf16 MFMAs above; RANDOM = hashed e4m3 bit patterns (sign + 3 mantissa bits random, exponent in a 4-value window)
+template <int RANDOM>
+__global__ __launch_bounds__(512) void mix8(long long* out, float* sink, int tiles) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  f32x16 st[2], ot[2];
+  i32x8 qf[8];
+  for (int i = 0; i < 16; ++i) st[0][i] = st[1][i] = ot[0][i] = ot[1][i] = 0.f;
+  unsigned h = 0x9E3779B9u * (unsigned)(blockIdx.x * 512 + tid + 1);
+  for (int i = 0; i < 8; ++i)
+    for (int e = 0; e < 8; ++e) {
+      unsigned w = 0;
+      for (int b = 0; b < 4; ++b) {
+        h = h * 1664525u + 1013904223u;
+        const unsigned byte = RANDOM ? (((h >> 16) & 0x87u) | ((6u + ((h >> 8) & 3u)) << 3)) : 0x30u;   // e4m3: s eeee mmm
+        w |= byte << (8 * b);
+      }
+      qf[i][e] = (int)w;
+    }
+  __syncthreads();
+  const long long t0 = __builtin_readcyclecounter();
+  for (int t = 0; t < tiles; ++t) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      if (s & 1) ot[(s >> 1) & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(qf[s & 7], qf[(s + 3) & 7], ot[(s >> 1) & 1], 0, 0, 0, 127, 0, 127);
+      else st[(s >> 1) & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(qf[(s + 1) & 7], qf[s & 7], st[(s >> 1) & 1], 0, 0, 0, 127, 0, 127);
+    }
+  }
+  const long long t1 = __builtin_readcyclecounter();
+  float sum = 0.f;
+  for (int i = 0; i < 16; ++i) sum += st[0][i] + st[1][i] + ot[0][i] + ot[1][i];
+  sink[blockIdx.x * 512 + tid] = sum;
+  if (lane == 0) out[blockIdx.x * 8 + wave] = t1 - t0;
+}
+
+template <int RANDOM>
+static void run8(const char* name, int tiles) {
+  const int blocks = 256;
+  long long* d_out; float* d_sink;
+  (void)hipMalloc(&d_out, blocks * 8 * sizeof(long long));
+  (void)hipMalloc(&d_sink, blocks * 512 * sizeof(float));
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  hipLaunchKernelGGL((mix8<RANDOM>), dim3(blocks), dim3(512), 0, 0, d_out, d_sink, tiles);
+  (void)hipEventRecord(e0, 0);
+  hipLaunchKernelGGL((mix8<RANDOM>), dim3(blocks), dim3(512), 0, 0, d_out, d_sink, tiles);
+  (void)hipEventRecord(e1, 0);
+  (void)hipDeviceSynchronize();
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  long long* hh = (long long*)malloc(blocks * 8 * sizeof(long long));
+  (void)hipMemcpy(hh, d_out, blocks * 8 * sizeof(long long), hipMemcpyDeviceToHost);
+  double s = 0;
+  for (int i = 0; i < blocks * 8; ++i) s += (double)hh[i];
+  const double tf = (double)blocks * 8 * tiles * 16 * (32.0 * 32 * 64 * 2) / (ms * 1e-3) / 1e12;
+  printf("%-52s %8.1f counter ticks / tile   %7.1f TF/s of MFMA work   (%.3f ms)\n", name, s / (blocks * 8) / tiles, tf, ms);
+  free(hh); (void)hipFree(d_out); (void)hipFree(d_sink);
+}
+
 template <int MODE>
 static void run(const char* name, int tiles = 2000) {
   const int blocks = 256;
@@ -185,5 +246,7 @@ int main() {
   run<6>("long: MFMA only, random, A and B change", 20000);
   run<7>("long: MFMA only, random, A and B fixed", 20000);
   run<0>("long: PHASED mix, benign data", 20000);
+  run8<0>("long: e4m3 MFMA only (32x32x64), benign data", 20000);
+  run8<1>("long: e4m3 MFMA only (32x32x64), random operands", 20000);
   return 0;
 }
