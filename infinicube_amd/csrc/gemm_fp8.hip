@@ -62,8 +62,11 @@ __device__ __forceinline__ i32x8 read_frag(const char* p0, const char* p1) {
   return (i32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <int EPI>
+// SCH bit 0: two phases of 16 MFMAs per K-tile (gemm256.hip's round-2 schedule: half the barriers); bit 1: the RESID
+// epilogue issues the 16 residual loads of a half-tile before consuming any.  A/B switch "gemm_fp8_sched" (default 3).
+template <int EPI, int SCH>
 __global__ __launch_bounds__(512) void gemm_fp8_kernel(Params p) {
+  constexpr bool TWO_PHASE = SCH & 1, BATCH_EPI = SCH & 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -128,7 +131,8 @@ __global__ __launch_bounds__(512) void gemm_fp8_kernel(Params p) {
   dma_unit(p.A, offA[1], kbyte(0), smem + U_A1 * UNIT_BYTES, wave);
   dma_unit(p.A, offA[0], kbyte(1), smem + STAGE_BYTES + U_A0 * UNIT_BYTES, wave);
   dma_unit(p.W, offB[0], kbyte(1), smem + STAGE_BYTES + U_B0 * UNIT_BYTES, wave);
-  GF8_VMCNT8();
+  if (TWO_PHASE) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // A0(0), B0(0), B1(0) landed (3 younger units in flight)
+  else GF8_VMCNT8();
   GF8_BARRIER();
   if (wr == 1) GF8_BARRIER();  // stagger: group 1 runs one barrier behind group 0
 
@@ -146,6 +150,39 @@ __global__ __launch_bounds__(512) void gemm_fp8_kernel(Params p) {
     __builtin_amdgcn_sched_barrier(0);                                                                    \
   }
 
+  if (TWO_PHASE) {
+    // P1: read a0,b0,b1 | DMA B1(t+1),A1(t+1) -> s^1 | vmcnt(8) | a0 x b0, a0 x b1
+    // P2: read a1       | DMA A0(t+2),B0(t+2) -> s   | vmcnt(6) | a1 x b0, a1 x b1      (hazards: see gemm256.hip)
+    for (int t = 0; t < nt; ++t) {
+      char* cur = smem + (t & 1) * STAGE_BYTES;
+      char* oth = smem + ((t + 1) & 1) * STAGE_BYTES;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        b0f[j] = read_frag(cur + U_B0 * UNIT_BYTES + b_lo + j * FROWS, cur + U_B0 * UNIT_BYTES + b_hi + j * FROWS);
+        b1f[j] = read_frag(cur + U_B1 * UNIT_BYTES + b_lo + j * FROWS, cur + U_B1 * UNIT_BYTES + b_hi + j * FROWS);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        af[i] = read_frag(cur + U_A0 * UNIT_BYTES + a_lo + i * FROWS, cur + U_A0 * UNIT_BYTES + a_hi + i * FROWS);
+      dma_unit(p.W, offB[1], kbyte(t + 1), oth + U_B1 * UNIT_BYTES, wave);
+      dma_unit(p.A, offA[1], kbyte(t + 1), oth + U_A1 * UNIT_BYTES, wave);
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      GF8_BARRIER();
+      GF8_MFMA(0, b0f, 0);
+      GF8_MFMA(0, b1f, 1);
+      GF8_BARRIER();
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        af[i] = read_frag(cur + U_A1 * UNIT_BYTES + a_lo + i * FROWS, cur + U_A1 * UNIT_BYTES + a_hi + i * FROWS);
+      dma_unit(p.A, offA[0], kbyte(t + 2), cur + U_A0 * UNIT_BYTES, wave);
+      dma_unit(p.W, offB[0], kbyte(t + 2), cur + U_B0 * UNIT_BYTES, wave);
+      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+      GF8_BARRIER();
+      GF8_MFMA(1, b0f, 0);
+      GF8_MFMA(1, b1f, 1);
+      GF8_BARRIER();
+    }
+  } else
   for (int t = 0; t < nt; ++t) {
     char* cur = smem + (t & 1) * STAGE_BYTES;
     char* oth = smem + ((t + 1) & 1) * STAGE_BYTES;
@@ -190,6 +227,50 @@ __global__ __launch_bounds__(512) void gemm_fp8_kernel(Params p) {
   if (wr == 0) GF8_BARRIER();                        // re-balance the stagger
 
   // ---- epilogue: a lane owns ONE row m and runs of 4 consecutive n (swapped MFMA operands) ----
+  if (EPI == ICV_EPI_RESID_F32 && BATCH_EPI && n0 + BN <= p.N && p.nsplit == p.N) {
+    // x[m, n] = resid[m, n] + gate[n] * (acc * a_scale[m] * w_scale[n] + bias[n]), the 16 residual loads of a half-tile
+    // in flight together (gemm256.hip); rows past M load a clamped row and skip the store
+    float4 bs[4], gt[4], sw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + wc * 64 + (j >> 1) * 32 + (j & 1) * 16 + kg * 4;
+      sw[j] = *reinterpret_cast<const float4*>(p.w_scale + n);
+      bs[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      gt[j] = p.gate ? *reinterpret_cast<const float4*>(p.gate + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      float4 rs[4][4];
+      float sa[4];
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const int64_t m = m0 + wr * 128 + hf * 64 + ii * 16 + fr;
+        const int64_t mc = m < p.M ? m : p.M - 1;
+        sa[ii] = p.a_scale[mc];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          rs[ii][j] = *reinterpret_cast<const float4*>(p.resid + mc * p.ldr + n0 + wc * 64 + (j >> 1) * 32 + (j & 1) * 16 + kg * 4);
+      }
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const int64_t m = m0 + wr * 128 + hf * 64 + ii * 16 + fr;
+        if (m < p.M) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int64_t n = n0 + wc * 64 + (j >> 1) * 32 + (j & 1) * 16 + kg * 4;
+            const f32x4 a = acc[hf * 4 + ii][j];
+            const float4 r = rs[ii][j];
+            // same operation order as the per-fragment path below: acc * (sa * sw) + bias, then r + gate * v
+            const float v0 = a[0] * (sa[ii] * sw[j].x) + bs[j].x, v1 = a[1] * (sa[ii] * sw[j].y) + bs[j].y;
+            const float v2 = a[2] * (sa[ii] * sw[j].z) + bs[j].z, v3 = a[3] * (sa[ii] * sw[j].w) + bs[j].w;
+            *reinterpret_cast<float4*>((float*)p.out + m * p.ldo + n) =
+                make_float4(r.x + gt[j].x * v0, r.y + gt[j].y * v1, r.z + gt[j].z * v2, r.w + gt[j].w * v3);
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int64_t m = m0 + wr * 128 + (i >> 2) * 64 + (i & 3) * 16 + fr;
@@ -229,11 +310,11 @@ __global__ __launch_bounds__(512) void gemm_fp8_kernel(Params p) {
   }
 }
 
-template <int EPI>
+template <int EPI, int SCH>
 int launch(const Params& p, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_fp8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_fp8_kernel<EPI, SCH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) {
       icv_set_error("icv_gemm_fp8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return 2;
@@ -241,7 +322,7 @@ int launch(const Params& p, hipStream_t st) {
     attr_set = true;
   }
   const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL((gemm_fp8_kernel<EPI>), dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p);
+  hipLaunchKernelGGL((gemm_fp8_kernel<EPI, SCH>), dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p);
   return icv_check_launch("icv_gemm_fp8");
 }
 
@@ -265,12 +346,15 @@ extern "C" int icv_gemm_fp8(const void* A, int64_t lda, const float* a_scale, co
   p.tiles_m = (int)((M + gf8::BM - 1) / gf8::BM);
   p.tiles_n = (int)((N + gf8::BN - 1) / gf8::BN);
   hipStream_t st = (hipStream_t)stream;
+  const bool r2 = icv_get_option_int("gemm_fp8_sched", 3) != 0;   // 0 = round 1's four-phase loop and per-fragment epilogue (A/B)
+#define GF8_LAUNCH(E_) (r2 ? gf8::launch<E_, 3>(p, st) : gf8::launch<E_, 0>(p, st))
   switch (epilogue) {
-    case ICV_EPI_BF16: return gf8::launch<ICV_EPI_BF16>(p, st);
-    case ICV_EPI_GELU_BF16: return gf8::launch<ICV_EPI_GELU_BF16>(p, st);
-    case ICV_EPI_RESID_F32: return gf8::launch<ICV_EPI_RESID_F32>(p, st);
-    case ICV_EPI_F32: return gf8::launch<ICV_EPI_F32>(p, st);
+    case ICV_EPI_BF16: return GF8_LAUNCH(ICV_EPI_BF16);
+    case ICV_EPI_GELU_BF16: return GF8_LAUNCH(ICV_EPI_GELU_BF16);
+    case ICV_EPI_RESID_F32: return GF8_LAUNCH(ICV_EPI_RESID_F32);
+    case ICV_EPI_F32: return GF8_LAUNCH(ICV_EPI_F32);
   }
+#undef GF8_LAUNCH
   icv_set_error("icv_gemm_fp8: unknown epilogue %d", epilogue);
   return 1;
 }

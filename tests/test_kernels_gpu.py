@@ -713,7 +713,17 @@ def test_ln_modulate_fp8(hip_ops, rows, d, mode):
 @pytest.mark.parametrize("M,N,K,epi", [
     (256, 256, 128, "f32"), (300, 260, 256, "f32"), (1, 4, 128, "f32"), (513, 1536, 1536, "bf16"),
     (777, 1024, 512, "gelu"), (640, 512, 8960, "resid"), (515, 768, 384, "split")])
-def test_gemm_fp8(hip_ops, M, N, K, epi):
+@pytest.mark.parametrize("sched", [3, 0])
+def test_gemm_fp8(hip_ops, M, N, K, epi, sched):
+    """sched 3 = two-phase main loop + batched residual epilogue (default), 0 = round 1's four-phase loop (A/B switch)."""
+    hip_ops.lib.icv_set_option(b"gemm_fp8_sched", sched)
+    try:
+        _gemm_fp8_case(hip_ops, M, N, K, epi)
+    finally:
+        hip_ops.lib.icv_set_option(b"gemm_fp8_sched", 3)
+
+
+def _gemm_fp8_case(hip_ops, M, N, K, epi):
     a = rnd((M, K), 421, 1.5)
     a[:, 3] *= 25.0
     w = rnd((N, K), 422, 1.0 / math.sqrt(K))

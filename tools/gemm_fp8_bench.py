@@ -34,10 +34,13 @@ for name, M, N, K, epi in shapes:
     w8, wsc = torch.empty((N, K), dtype=FP8, device="cuda"), torch.empty((N,), device="cuda")
     ops.quantize_rows(a, a8, asc); ops.quantize_rows(w, w8, wsc)
     t16 = timeit(lambda: ops.gemm(a, w, bias, out, epi, **kw))
+    ops.lib.icv_set_option(b"gemm_fp8_sched", 0)
+    t8_r1 = timeit(lambda: ops.gemm_fp8(a8, asc, w8, wsc, bias, out, epi, **kw))
+    ops.lib.icv_set_option(b"gemm_fp8_sched", 3)
     t8 = timeit(lambda: ops.gemm_fp8(a8, asc, w8, wsc, bias, out, epi, **kw))
     tq = timeit(lambda: ops.quantize_rows(a, a8, asc))
     fl = 2.0 * M * N * K / 1e9
-    print(f"{name:13s} M={M} N={N} K={K}: bf16 {fl / t16:7.1f} TF ({t16:.3f} ms) | fp8 {fl / t8:7.1f} TF ({t8:.3f} ms) | "
+    print(f"{name:13s} M={M} N={N} K={K}: bf16 {fl / t16:7.1f} TF ({t16:.3f} ms) | fp8 {fl / t8:7.1f} TF ({t8:.3f} ms; round-1 schedule {fl / t8_r1:7.1f} TF) | "
           f"quantise A {tq:.3f} ms = {M * K * 3 / tq / 1e6:.0f} GB/s | fp8+quant speed-up {t16 / (t8 + tq):.2f}x")
 x = torch.randn((S, 5120), device="cuda")
 h, h8, hs = torch.empty((S, 5120), dtype=torch.bfloat16, device="cuda"), torch.empty((S, 5120), dtype=FP8, device="cuda"), torch.empty((S,), device="cuda")
