@@ -80,6 +80,8 @@ __device__ __forceinline__ void dma_unit(const char* __restrict__ base, const un
 template <int EPI, int MF, int SCH>
 __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
   constexpr bool TWO_PHASE = (SCH & 1) != 0, BATCH_EPI = (SCH & 2) != 0;
+  constexpr bool EARLY_B1 = (SCH & 4) != 0;   // two-phase only: B1 of the next tile is requested with A0/B0 (a full tile ahead), not half a tile
+  static_assert(!EARLY_B1 || TWO_PHASE, "EARLY_B1 is a variant of the two-phase schedule");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -165,7 +167,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
   dma_unit(Ab, offA[1], kbyte(0), smem + U_A1 * UNIT_BYTES, wave);
   dma_unit(Ab, offA[0], kbyte(1), smem + STAGE_BYTES + U_A0 * UNIT_BYTES, wave);
   dma_unit(Wb, offB[0], kbyte(1), smem + STAGE_BYTES + U_B0 * UNIT_BYTES, wave);
-  if (TWO_PHASE) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // A0(0), B0(0), B1(0) landed (3 younger units in flight)
+  if (EARLY_B1) dma_unit(Wb, offB[1], kbyte(1), smem + STAGE_BYTES + U_B1 * UNIT_BYTES, wave);
+  if (EARLY_B1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // A0(0), B0(0), B1(0) landed (4 younger units in flight)
+  else if (TWO_PHASE) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // A0(0), B0(0), B1(0) landed (3 younger units in flight)
   else G256_VMCNT8();     // A0(0), B0(0) landed (4 younger units in flight)
   G256_BARRIER();
   if (wr == 1) G256_BARRIER();  // stagger: group 1 runs one barrier behind group 0
@@ -214,8 +218,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
         for (int i = 0; i < NAF; ++i)
           af[i][ks] = *reinterpret_cast<const bf16x8*>(cur + U_A0 * UNIT_BYTES + a_off[ks] + i * FROWS);
       }
-      if (!(p.ablate & 1)) dma_unit(Wb, offB[1], kbyte(t + 1), oth + U_B1 * UNIT_BYTES, wave);
+      if (!EARLY_B1 && !(p.ablate & 1)) dma_unit(Wb, offB[1], kbyte(t + 1), oth + U_B1 * UNIT_BYTES, wave);
       if (!(p.ablate & 1)) dma_unit(Ab, offA[1], kbyte(t + 1), oth + U_A1 * UNIT_BYTES, wave);
+      // A1(t) must have landed.  Younger: A0,B0(t+1) + this phase's B1,A1(t+1) = 8 instructions; EARLY_B1: A0,B0,B1(t+1) + A1(t+1) = 8
       asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
       G256_BARRIER();
       G256_MFMA(0, b0f, 0);
@@ -229,6 +234,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
           af[i][ks] = *reinterpret_cast<const bf16x8*>(cur + U_A1 * UNIT_BYTES + a_off[ks] + i * FROWS);
       if (!(p.ablate & 1)) dma_unit(Ab, offA[0], kbyte(t + 2), cur + U_A0 * UNIT_BYTES, wave);
       if (!(p.ablate & 1)) dma_unit(Wb, offB[0], kbyte(t + 2), cur + U_B0 * UNIT_BYTES, wave);
+      if (EARLY_B1) {
+        // B1 of this stage was last read in P1(t): re-stage it now, a full tile before P1(t+2) reads it.  A0,B0,B1(t+1)
+        // must have landed; younger: A1(t+1) + A0,B0,B1(t+2) = 8 instructions
+        if (!(p.ablate & 1)) dma_unit(Wb, offB[1], kbyte(t + 2), cur + U_B1 * UNIT_BYTES, wave);
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      } else
       asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
       G256_BARRIER();
       G256_MFMA(1, b0f, 0);
@@ -409,8 +420,9 @@ int icv_gemm256_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw,
   p.gm = icv_get_option_int("gemm256_gm", 4);
   p.ablate = icv_get_option_int("gemm256_ablate", 0);
   const bool m32 = icv_get_option_int("gemm256_mfma", 16) == 32;
-  // schedule variant (A/B switch "gemm256_sched"): bit 0 = two 32-MFMA phases per K-tile, bit 1 = batched residual loads
-  const int sch = icv_get_option_int("gemm256_sched", G256_SCHED_DEFAULT) & 3;
+  // schedule variant (A/B switch "gemm256_sched"): bit 0 = two 32-MFMA phases per K-tile, bit 1 = batched residual loads,
+  // bit 2 (with both: 7) = B1 of the next tile requested a full tile ahead
+  const int sch = icv_get_option_int("gemm256_sched", G256_SCHED_DEFAULT) & 7;
 #define G256_CASE(E_)                                                                              \
   case E_:                                                                                         \
     if (m32) return (sch & 1) ? g256::launch<E_, 32, 1>(p, st) : g256::launch<E_, 32, 0>(p, st);   \
@@ -418,6 +430,7 @@ int icv_gemm256_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw,
       case 0: return g256::launch<E_, 16, 0>(p, st);                                               \
       case 1: return g256::launch<E_, 16, 1>(p, st);                                               \
       case 2: return g256::launch<E_, 16, 2>(p, st);                                               \
+      case 7: return g256::launch<E_, 16, 7>(p, st);                                               \
       default: return g256::launch<E_, 16, 3>(p, st);                                              \
     }
   switch (epilogue) {

@@ -54,4 +54,4 @@ for name, M, N, K, epi in SHAPES:
     fl = 2.0 * M * N * K
     print(f"{name:13s} M={M} N={N} K={K} epi={epi}: " + " | ".join(
         f"sched {v}: {fl / statistics.median(times[v]) / 1e9:7.1f} TF (best {fl / min(times[v]) / 1e9:7.1f}){'' if ok[v] else ' MISMATCH'}" for v in VARIANTS), flush=True)
-ops.lib.icv_set_option(b"gemm256_sched", 0); ops.lib.icv_set_option(b"gemm256", 2)
+ops.lib.icv_set_option(b"gemm256_sched", 3); ops.lib.icv_set_option(b"gemm256", 2)

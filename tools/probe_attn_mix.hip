@@ -18,6 +18,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ bf16x4 lds_tr(const char* p) {
   return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p));
@@ -143,6 +145,75 @@ __global__ __launch_bounds__(512) void mix(long long* out, float* sink, int tile
   if (lane == 0) out[blockIdx.x * 8 + wave] = t1 - t0;
 }
 
+// LDS port alone: the attention tile's 16 ds_read_b128 + 32 ds_read_b64_tr_b16 per wave (32 KiB per wave, 256 KiB per
+// block and tile), or 32 ds_read_b128 per wave (the same bytes), nothing else; results folded into a sink with v_xor
+template <int TR>
+__global__ __launch_bounds__(512) void ldsonly(long long* out, float* sink, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 32768; i += 512) reinterpret_cast<float*>(smem)[i] = 0.001f * (i & 255);
+  __syncthreads();
+  const char* kbase = smem + (lane & 31) * 256;
+  int koff[8];
+  for (int ds = 0; ds < 8; ++ds) koff[ds] = ((ds * 2 + (lane >> 5)) ^ (lane & 15)) << 4;
+  const char* vbase = smem + 16384 + (lane >> 4) * 512 + (lane & 15) * 8;
+  unsigned acc0 = 0, acc1 = 0;
+  // inline asm so that the compiler can neither narrow nor drop the loads; destination registers are scratch
+  unsigned kaddr[8];
+  for (int ds = 0; ds < 8; ++ds) kaddr[ds] = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)(kbase + koff[ds]));
+  const unsigned vaddr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)vbase);
+  const long long t0 = __builtin_readcyclecounter();
+  for (int t = 0; t < tiles; ++t) {
+    const unsigned so = (unsigned)((t & 3) * 32768);
+    u32x4 d;
+    u32x2 e;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(kaddr[i] + so));
+      asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(d) : "v"(kaddr[i] + so));
+    }
+    if (TR) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(e) : "v"(vaddr + so + (unsigned)((i >> 1) * 4096 + (i & 1) * 64)));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(e) : "v"(vaddr + so + (unsigned)((i >> 1) * 4096 + (i & 1) * 64)));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:128" : "=v"(e) : "v"(vaddr + so + (unsigned)((i >> 1) * 4096 + (i & 1) * 64)));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2176" : "=v"(e) : "v"(vaddr + so + (unsigned)((i >> 1) * 4096 + (i & 1) * 64)));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        asm volatile("ds_read_b128 %0, %1 offset:16384" : "=v"(d) : "v"(kaddr[i] + so));
+        asm volatile("ds_read_b128 %0, %1 offset:24576" : "=v"(d) : "v"(kaddr[i] + so));
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    acc0 ^= d[0];
+    acc1 ^= e[0];
+  }
+  const long long t1 = __builtin_readcyclecounter();
+  sink[blockIdx.x * 512 + tid] = (float)(acc0 ^ acc1);
+  if (lane == 0) out[blockIdx.x * 8 + wave] = t1 - t0;
+}
+
+template <int TR>
+static void run_lds(const char* name, int tiles) {
+  const int blocks = 256;
+  long long* d_out; float* d_sink;
+  (void)hipMalloc(&d_out, blocks * 8 * sizeof(long long));
+  (void)hipMalloc(&d_sink, blocks * 512 * sizeof(float));
+  (void)hipFuncSetAttribute((const void*)ldsonly<TR>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((ldsonly<TR>), dim3(blocks), dim3(512), 131072, 0, d_out, d_sink, tiles);
+  (void)hipDeviceSynchronize();
+  long long* hh = (long long*)malloc(blocks * 8 * sizeof(long long));
+  (void)hipMemcpy(hh, d_out, blocks * 8 * sizeof(long long), hipMemcpyDeviceToHost);
+  double s = 0;
+  for (int i = 0; i < blocks * 8; ++i) s += (double)hh[i];
+  const double ticks = s / (blocks * 8) / tiles;
+  printf("%-52s %8.1f counter ticks / tile   = %.1f LDS bytes per clock per CU (256 KiB per tile)\n", name, ticks, 262144.0 / ticks);
+  free(hh); (void)hipFree(d_out); (void)hipFree(d_sink);
+}
+
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 // MFMA only, e4m3: 16 x v_mfma_scale_f32_32x32x64_f8f6f4 (unit scales) per wave per "tile" = the same 32768 x 32 flops as the
@@ -246,6 +317,8 @@ int main() {
   run<6>("long: MFMA only, random, A and B change", 20000);
   run<7>("long: MFMA only, random, A and B fixed", 20000);
   run<0>("long: PHASED mix, benign data", 20000);
+  run_lds<1>("LDS only: 16 ds_read_b128 + 32 ds_read_b64_tr_b16 / wave", 2000);
+  run_lds<0>("LDS only: 32 ds_read_b128 / wave", 2000);
   run8<0>("long: e4m3 MFMA only (32x32x64), benign data", 20000);
   run8<1>("long: e4m3 MFMA only (32x32x64), random operands", 20000);
   return 0;
