@@ -56,12 +56,15 @@ __device__ __forceinline__ void dma16s(const void* base, unsigned off, unsigned 
 
 // VAR bit flags: 1 = stagger wave groups, 2 = issue all 16 K-fragment reads ahead of the QK^T MFMAs,
 //                4 = s_setprio(1) around MFMA clusters, 8 = K/V DMA three tiles ahead instead of two (not with 1),
-//                16 = unit scale
+//                16 = unit scale, 32 = QK^T MFMAs in key-block-major order (round 1's; the default is d-step major)
 // (tried and dropped: row sums with v_pk_add_f32 — 8 fewer VALU issues per 32-key block, 1142.6 vs 1149.5 TF/s, noise:
 //  the kernel is power-limited, profiles/r02/power_limit_probes.md)
 template <int VAR>
 __global__ __launch_bounds__(512) void attn7_kernel(Params p) {
   constexpr bool STAGGER = VAR & 1, KPREFETCH = VAR & 2, SETPRIO = VAR & 4, DEEP = VAR & 8, UNIT = VAR & 16;
+  // QK^T MFMA order: d-step major (consecutive MFMAs share the Q fragment: less operand toggling, +0.6...1.4 % under the power
+  // cap, profiles/r02/attention_variants.md) unless bit 32 asks for round 1's key-block-major order
+  constexpr bool DSMAJOR = !(VAR & 32);
   static_assert(!(STAGGER && DEEP), "the staggered group already runs its DMA three tiles ahead");   // 16: unit scale (set by the dispatcher)
   const float p_lim = __builtin_amdgcn_exp2f(p.thr);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -198,6 +201,15 @@ __global__ __launch_bounds__(512) void attn7_kernel(Params p) {
         for (int kb = 0; kb < 2; ++kb)
           st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][ds], qf[ds], ds == 0 ? (UNIT ? cinit : zero16) : st[kb], 0, 0, 0);
       if (SETPRIO) __builtin_amdgcn_s_setprio(0);
+    } else if (DSMAJOR) {
+#pragma unroll
+      for (int ds = 0; ds < 8; ++ds)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          const int c = ds * 2 + hi;
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + kb * 8192 + k_row_off + ((c ^ k_sw) << 4));
+          st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], ds == 0 ? (UNIT ? cinit : zero16) : st[kb], 0, 0, 0);
+        }
     } else {
       if (SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -334,6 +346,8 @@ int icv_attn7_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, c
     case 7: return att7::launch<7>(p, st);
     case 8: return att7::launch<8>(p, st);
     case 24: return att7::launch<24>(p, st);
+    case 32: return att7::launch<32>(p, st);
+    case 48: return att7::launch<48>(p, st);
     case 16: return att7::launch<16>(p, st);
     case 17: return att7::launch<17>(p, st);
     case 20: return att7::launch<20>(p, st);
