@@ -80,6 +80,7 @@ __device__ __forceinline__ void dma_unit(const char* __restrict__ base, const un
 template <int EPI, int MF, int SCH>
 __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
   constexpr bool TWO_PHASE = (SCH & 1) != 0, BATCH_EPI = (SCH & 2) != 0;
+  constexpr bool SERP = (SCH & 8) != 0;       // MFMA order inside a phase: serpentine over the (a, b) fragment grid
   constexpr bool EARLY_B1 = (SCH & 4) != 0;   // two-phase only: B1 of the next tile is requested with A0/B0 (a full tile ahead), not half a tile
   static_assert(!EARLY_B1 || TWO_PHASE, "EARLY_B1 is a variant of the two-phase schedule");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -182,7 +183,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
     __builtin_amdgcn_s_setprio(1);                                                              \
     _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks)                                          \
     _Pragma("unroll") for (int i = 0; i < NAF; ++i)                                             \
-    _Pragma("unroll") for (int j = 0; j < NBF; ++j) {                                           \
+    _Pragma("unroll") for (int jj = 0; jj < NBF; ++jj) {                                        \
+      /* SERP: boustrophedon over (i, j) so that every consecutive MFMA pair shares one operand */ \
+      const int j = (SERP && ((i + ks * NAF) & 1)) ? NBF - 1 - jj : jj;                         \
       if (MF == 16)                                                                             \
         acc[(AH) * 4 + i][(BH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(              \
             BF[j][ks], af[i][ks], acc[(AH) * 4 + i][(BH) * 2 + j], 0, 0, 0);                    \
@@ -422,7 +425,7 @@ int icv_gemm256_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw,
   const bool m32 = icv_get_option_int("gemm256_mfma", 16) == 32;
   // schedule variant (A/B switch "gemm256_sched"): bit 0 = two 32-MFMA phases per K-tile, bit 1 = batched residual loads,
   // bit 2 (with both: 7) = B1 of the next tile requested a full tile ahead
-  const int sch = icv_get_option_int("gemm256_sched", G256_SCHED_DEFAULT) & 7;
+  const int sch = icv_get_option_int("gemm256_sched", G256_SCHED_DEFAULT) & 15;
 #define G256_CASE(E_)                                                                              \
   case E_:                                                                                         \
     if (m32) return (sch & 1) ? g256::launch<E_, 32, 1>(p, st) : g256::launch<E_, 32, 0>(p, st);   \
@@ -431,6 +434,7 @@ int icv_gemm256_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw,
       case 1: return g256::launch<E_, 16, 1>(p, st);                                               \
       case 2: return g256::launch<E_, 16, 2>(p, st);                                               \
       case 7: return g256::launch<E_, 16, 7>(p, st);                                               \
+      case 11: return g256::launch<E_, 16, 11>(p, st);                                             \
       default: return g256::launch<E_, 16, 3>(p, st);                                              \
     }
   switch (epilogue) {

@@ -56,7 +56,7 @@ def fuzz_gemm():
     epi = rng.choice([EPI_BF16, EPI_GELU_BF16, EPI_RESID_F32, EPI_F32])
     tile = rng.choice([0, 1, 2])         # 128-tile kernel, 256-tile kernel, heuristic
     mfma = rng.choice([16, 16, 32])
-    sched = rng.choice([0, 1, 2, 3, 7])
+    sched = rng.choice([0, 1, 2, 3, 7, 11])
     pad = rng.choice([0, 0, 64])         # strided A
     ops.lib.icv_set_option(b"gemm256", tile); ops.lib.icv_set_option(b"gemm256_mfma", mfma); ops.lib.icv_set_option(b"gemm256_sched", sched)
     g = torch.Generator(device=DEV).manual_seed(rng.randint(0, 2 ** 31))
