@@ -12,6 +12,7 @@ Tolerances: SURVEY.md §8d (one forward: cosine >= 0.999, rel-L2 <= 2e-2; loop: 
 """
 import dataclasses
 import math
+import os
 import time
 
 import numpy as np
@@ -334,3 +335,50 @@ def test_config3_wan_14b_four_step_loop_full_depth(hip_ops):
     pf = frame_psnr(lat, ref, PoolVAE())
     print(f"config #3, {steps}-step loop at full depth: HIP {t_hip:.1f}s, fp32 torch oracle on GPU {t_ref:.1f}s; latent PSNR {p:.1f} dB, frame PSNR {pf:.1f} dB")
     assert torch.isfinite(lat).all() and p >= 40.0 and pf >= 40.0, f"config #3 {steps}-step loop: latent PSNR {p:.1f} dB, frame PSNR {pf:.1f} dB"
+
+
+@pytest.mark.skipif(os.environ.get("ICV_SLOW_TESTS", "0") != "1", reason="~3 GPU-minutes; run with ICV_SLOW_TESTS=1 (recorded in profiles/r02/parity_config5_full_depth.txt)")
+def test_config5_wan_14b_i2v_720p_one_forward_full_depth(hip_ops):
+    """Config #5 at FULL depth and size: Wan2.1-14B image-to-video (36 input channels, CLIP cross-attention branch), 93 frames
+    720x1280 (S = 86 400), ONE conditional forward of all 40 layers; bf16 product and the e4m3 mode (torch_dtype =
+    float8_e4m3fn's kernels) against oracle/wan_ref.py run UNQUANTISED in fp32 by stock PyTorch on the GPU."""
+    cfg, grid = preset("14b-i2v"), GRID_720P
+    sd = syn.make_dit_state_dict(cfg, seed=0, device=DEV, dtype=torch.bfloat16)
+    bsd = syn.make_buffer_embedder_state_dict(cfg, device=DEV, dtype=torch.bfloat16)
+    noise, c1, bl = syn.make_latent_noise(grid), syn.make_text_context(cfg, 1), syn.make_buffer_latents(cfg, grid)
+    clip, y = syn.make_clip_features(cfg), syn.make_cond_latents(cfg, grid)
+    sched = FlowMatchScheduler(50)
+    ts = float(sched.timesteps[0])
+    gshape = (grid.T, grid.Hp, grid.Wp)
+    got = {}
+    for mode in ("bf16", "fp8"):
+        kw = {} if mode == "bf16" else dict(gemm_dtype="fp8", attn_dtype="fp8")
+        m = WanDiT(cfg, sd, hip_ops, bsd, **kw).prepare(grid, graphs=False)
+        ck = m.encode_context(c1, clip)
+        add = m.embed_cond_latents(y, add_to=m.embed_buffers(bl))
+        lat = noise.clone().to(DEV)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        m.forward_tokens(lat, ck, ts, add, m.head_out[0])
+        torch.cuda.synchronize()
+        got[mode] = (R.unpatchify(m.head_out[0].cpu(), gshape, cfg.out_dim), time.time() - t0)
+        del m, ck, add
+        torch.cuda.empty_cache()
+    sdr = {k: v.float() for k, v in sd.items()}
+    bsdr = {k: v.float() for k, v in bsd.items()}
+    del sd, bsd
+    torch.cuda.empty_cache()
+    t0 = time.time()
+    buf = R.buffer_embed(bsdr, bl.to(DEV))
+    v = R.dit_forward(sdr, cfg, noise.to(DEV), c1.to(DEV), ts, buf, clip_fea=clip.to(DEV), y=y.to(DEV)).cpu()
+    torch.cuda.synchronize()
+    print(f"config #5, Wan2.1-14B i2v, 93 f 720x1280, S={grid.S}, one forward of {cfg.num_layers} layers; fp32 torch oracle on the GPU: {time.time() - t0:.1f} s")
+    res = {}
+    for mode, (vh, t) in got.items():
+        rel = float((vh - v).norm() / v.norm())
+        cos = float(torch.nn.functional.cosine_similarity(vh.flatten().double(), v.flatten().double(), dim=0))
+        p = R.psnr(noise + vh * sched.dsigma(0), noise + v * sched.dsigma(0))
+        res[mode] = (rel, cos)
+        print(f"  product {mode:4s}: {t:6.2f} s   velocity rel-L2 {rel:.4g}  cosine {cos:.6f}   latent PSNR after one Euler step {p:.1f} dB")
+    assert res["bf16"][1] >= 0.999 and res["bf16"][0] <= 2e-2, f"config #5 bf16 forward: {res['bf16']}"
+    assert res["fp8"][1] >= 0.998 and res["fp8"][0] <= 8e-2, f"config #5 e4m3 forward vs the unquantised oracle: {res['fp8']}"
