@@ -919,3 +919,67 @@ def test_fuzz_gemm_and_attention_20s():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_kernels.py"), "20", "7"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " 0 failures" in r.stdout
+
+
+def test_randomised_token_local_kernels(hip_ops):
+    """Seeded random sweep of the token-local entry points against the oracle (the GEMM / attention counterpart is
+    tools/fuzz_kernels.py): LayerNorm + modulate over ragged row counts and every supported width, RMSNorm + 3-D RoPE on
+    random (T, Hp, Wp) grids with a random shard [tok0, tok0 + n), the e4m3 GEMM on ragged M / N, and the image-branch
+    attention that ADDS into an existing output."""
+    import random
+    rng = random.Random(2024)
+    dv = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    for case in range(40):
+        # --- K3 / K8 ---
+        d = rng.choice([256, 512, 1536, 5120])
+        rows = rng.choice([1, 2, 31, 64, 65, 257, rng.randint(1, 700)])
+        x = rnd((rows, d), 1000 + case, rng.choice([0.5, 2.0, 8.0])) + rng.choice([0.0, 0.5, -3.0])
+        affine, mod = rng.random() < 0.5, rng.random() < 0.7
+        w = 1 + rnd((d,), 2000 + case, 0.1) if affine else None
+        b = rnd((d,), 3000 + case, 0.1) if affine else None
+        sh = rnd((d,), 4000 + case, 0.3) if mod else None
+        sc = rnd((d,), 5000 + case, 0.3) if mod else None
+        ref = R.layer_norm(x, w, b, 1e-6)
+        if mod:
+            ref = R.modulate(ref, sh, sc)
+        out = torch.full((rows + 1, d), 3.0, dtype=torch.bfloat16, device=DEV)
+        hip_ops.ln_modulate(x.to(DEV), out[:rows], dv(w), dv(b), dv(sh), dv(sc), 1e-6)
+        assert_bf16_close(out[:rows], ref, f"ln rows={rows} d={d} affine={affine} mod={mod}")
+        assert bool((out[rows:] == 3.0).all()), "ln_modulate wrote past the last row"
+        # --- K5 ---
+        T, Hp, Wp = rng.randint(1, 6), rng.randint(1, 9), rng.randint(1, 11)
+        S = T * Hp * Wp
+        n = rng.randint(1, S)
+        tok0 = rng.randint(0, S - n)
+        d = rng.choice([256, 512, 1536, 5120])
+        planes = rnd((2, n, d), 6000 + case).to(torch.bfloat16)
+        w0, w1 = 1 + rnd((d,), 7000 + case, 0.1), 1 + rnd((d,), 8000 + case, 0.1)
+        freqs = R.rope_freqs_3d(128, T, Hp, Wp)[tok0: tok0 + n]
+        g = planes.to(DEV)
+        hip_ops.rmsnorm_rope(g[0], w0.to(DEV), g[1], w1.to(DEV), 1e-6, RopeTable.build(T, Hp, Wp, DEV), tok0)
+        what = f"rms+rope grid=({T},{Hp},{Wp}) tok0={tok0} n={n} d={d}"
+        assert_bf16_close(g[0], R.rope_apply(R.rms_norm(planes[0].float(), w0, 1e-6), freqs, d // 128), what + " q")
+        assert_bf16_close(g[1], R.rope_apply(R.rms_norm(planes[1].float(), w1, 1e-6), freqs, d // 128), what + " k")
+    for case in range(12):
+        # --- e4m3 GEMM, ragged M / N ---
+        M, N, K = rng.choice([1, 63, 257, 300, 777, 1030]), 4 * rng.choice([1, 33, 64, 65, 192, 260]), 128 * rng.choice([1, 2, 3, 12])
+        a = rnd((M, K), 9000 + case, 1.5)
+        w = rnd((N, K), 9100 + case, 1.0 / math.sqrt(K))
+        bias = rnd((N,), 9200 + case, 0.1)
+        aq, asc = R.quantize_rows_fp8(a)
+        wq, wsc = R.quantize_rows_fp8(w)
+        acc = (aq.double() @ wq.double().t()).float() * asc[:, None] * wsc[None, :] + bias
+        out = torch.full((M + 1, N), 5.0, device=DEV)
+        hip_ops.gemm_fp8(aq.to(FP8).to(DEV), asc.to(DEV), wq.to(FP8).to(DEV), wsc.to(DEV), bias.to(DEV), out[:M], EPI_F32)
+        assert_f32_close(out[:M], acc, rtol=1e-4, what=f"gemm_fp8 {M}x{N}x{K}")
+        assert bool((out[M:] == 5.0).all()), "gemm_fp8 wrote past the last row"
+        # --- K9 image branch: o += attention(q, k_img, v_img) ---
+        H, Sq, Skv = rng.choice([1, 2, 3]), rng.choice([1, 33, 257, 300, 640]), rng.choice([1, 64, 65, 257])
+        dd = H * 128
+        q, k, v = (rnd((Sq, dd), 9300 + case).to(torch.bfloat16), rnd((Skv, dd), 9400 + case).to(torch.bfloat16),
+                   rnd((Skv, dd), 9500 + case).to(torch.bfloat16))
+        prev = rnd((Sq, dd), 9600 + case).to(torch.bfloat16)
+        o = prev.clone().to(DEV)
+        hip_ops.attention_add(q.to(DEV), k.to(DEV), v.to(DEV), o, H, 1.0 / math.sqrt(128))
+        assert_bf16_close(o, prev.float() + R.attention(q.float(), k.float(), v.float(), H), f"attention_add Sq={Sq} Skv={Skv} H={H}",
+                          abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
