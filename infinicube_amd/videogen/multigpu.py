@@ -131,19 +131,39 @@ class WorkerPool:
                     pass
                 raise RuntimeError(f"multi-GPU worker rank {i + 1} exited with code {rc}:\n{tail}")
 
+    def _blame_dead_worker(self, grace_s: float = 10.0):
+        """A transport error usually means a worker is going down: give it a moment to exit, then report ITS log."""
+        deadline = time.time() + grace_s
+        while time.time() < deadline:
+            self._check_alive()
+            time.sleep(0.2)
+
     def wait_ready(self):
         """Every rank has built its generator (weights resident)."""
         self._check_alive()
-        self.dist.barrier(group=self.ctrl)
+        try:
+            work = self.dist.barrier(group=self.ctrl, async_op=True)
+            while not work.is_completed():      # a worker that dies while loading must not cost the whole collective timeout
+                self._check_alive()
+                time.sleep(0.2)
+            work.wait()
+        except RuntimeError as e:
+            if "multi-GPU worker rank" not in str(e):
+                self._blame_dead_worker()       # prefer the dead worker's own log to the transport's error
+            raise
 
     def generate(self, semantic: np.ndarray, coordinate: np.ndarray, call_kwargs: dict, pipe) -> None:
         """Hand one request to the workers; the caller then runs its own share through ``pipe(...)``."""
         self._check_alive()
         msg = dict(cmd="generate", shape=tuple(semantic.shape), call=call_kwargs,
                    settings={k: getattr(pipe, k) for k in _PIPE_SETTINGS if hasattr(pipe, k)})
-        self.dist.broadcast_object_list([msg], src=0, group=self.ctrl)
-        for arr in (semantic, coordinate):
-            self.dist.broadcast(torch.from_numpy(np.ascontiguousarray(arr)), src=0, group=self.ctrl)
+        try:
+            self.dist.broadcast_object_list([msg], src=0, group=self.ctrl)
+            for arr in (semantic, coordinate):
+                self.dist.broadcast(torch.from_numpy(np.ascontiguousarray(arr)), src=0, group=self.ctrl)
+        except Exception:
+            self._blame_dead_worker()
+            raise
 
     def close(self):
         if getattr(self, "_closed", True):

@@ -18,3 +18,11 @@ def factory(torch_dtype, device, model_configs):
                             ops=OracleOps())
     pipe.num_inference_steps = 2
     return pipe
+
+
+def failing_factory(torch_dtype, device, model_configs):
+    """Workers (ICV_WORKER_RANK set) fail while building their pipeline; rank 0 builds normally."""
+    import os
+    if os.environ.get("ICV_WORKER_RANK") is not None:
+        raise RuntimeError("synthetic worker failure while loading the checkpoint")
+    return factory(torch_dtype, device, model_configs)

@@ -93,3 +93,29 @@ def test_device_literal_maps_to_local_rank(monkeypatch):
     assert P.resolve_device("cuda:0") == "cuda:0"        # LOCAL_RANK alone (world 1) changes nothing
     monkeypatch.setenv("WORLD_SIZE", "8")
     assert P.resolve_device("cuda:0") == "cuda:5" and P.resolve_device("cuda") == "cuda:5" and P.resolve_device("cpu") == "cpu"
+
+
+def test_worker_that_dies_while_loading_is_reported(tmp_path, monkeypatch):
+    """A worker that fails after joining the process group (missing checkpoint, out of memory, ...) must surface as an error
+    with ITS log in the caller within seconds, not as a collective timeout."""
+    import time
+    import mgpu_factory as F
+    from infinicube.videogen import WanVideoGenerator
+    from infinicube_amd.videogen import multigpu
+    path = _checkpoint(tmp_path)
+    monkeypatch.setenv("ICV_WORLD", "2")
+    monkeypatch.setenv("ICV_DIST_BACKEND", "gloo")
+    monkeypatch.setenv("ICV_WORKER_FACTORY", "mgpu_factory:failing_factory")
+    monkeypatch.setenv("ICV_WORLD_TIMEOUT_S", "300")
+    monkeypatch.setenv("PYTHONPATH", os.pathsep.join([os.path.dirname(HERE), HERE, os.environ.get("PYTHONPATH", "")]))
+    t0 = time.time()
+    try:
+        with pytest.raises(RuntimeError, match="synthetic worker failure"):
+            with contextlib.redirect_stdout(io.StringIO()):
+                WanVideoGenerator(path, device="cpu", use_wan_1pt3b=True, pipeline_factory=F.factory)
+        assert time.time() - t0 < 120
+    finally:
+        if multigpu._ACTIVE_POOL is not None:
+            multigpu._ACTIVE_POOL.close()
+    import torch.distributed as dist
+    assert not dist.is_initialized()
