@@ -39,3 +39,32 @@ def test_argument_validation_without_gpu():
     assert rc != 0 and b"multiple of 256" in lib.icv_last_error()
     rc = lib.icv_attention_fwd(1, 128, 1, 128, 1, 128, 1, 128, 0, 5, 1, 0.1, None)                  # Sq=0
     assert rc != 0 and b"empty problem" in lib.icv_last_error()
+
+
+def test_context_entry_points_validate_without_gpu():
+    """icv_dit_* / icv_comm_* argument checks return before any HIP or RCCL call."""
+    lib = native.lib()
+    h = ctypes.c_void_p()
+    bad = native.DitConfig(dim=100, ffn_dim=64, heads=1, layers=1, n_tok=4, tok0=0, T=1, Hp=2, Wp=2, k_patch=64, out_cols=64, eps=1e-6)
+    assert lib.icv_dit_create(ctypes.byref(bad), ctypes.byref(h)) != 0 and b"heads * 128" in lib.icv_last_error()
+    shard = native.DitConfig(dim=256, ffn_dim=512, heads=2, layers=2, n_tok=8, tok0=3, T=1, Hp=2, Wp=4, k_patch=64, out_cols=64, eps=1e-6)
+    assert lib.icv_dit_create(ctypes.byref(shard), ctypes.byref(h)) != 0 and b"token shard outside" in lib.icv_last_error()
+    ok = native.DitConfig(dim=256, ffn_dim=512, heads=2, layers=2, n_tok=8, tok0=0, T=1, Hp=2, Wp=4, k_patch=64, out_cols=64, eps=1e-6)
+    assert lib.icv_dit_create(ctypes.byref(ok), ctypes.byref(h)) == 0 and h.value
+    try:
+        assert lib.icv_dit_bind(h, b"wqkv", 2, 8) != 0 and b"out of range" in lib.icv_last_error()
+        assert lib.icv_dit_bind(h, b"nonsense", -1, 8) != 0 and b"unknown tensor" in lib.icv_last_error()
+        assert lib.icv_dit_bind(h, b"nonsense", 0, 8) != 0 and b"unknown per-layer tensor" in lib.icv_last_error()
+        assert lib.icv_dit_bind(h, b"wqkv", 0, 8) == 0
+        # forward with unbound tensors is refused before anything is enqueued
+        rc = lib.icv_dit_forward(h, 8, 16, 4, 8, 8, 8, 8, 8, 1, 0, None, None, 0, 0, None, 8, -1, 0, 1.0, None)
+        assert rc != 0 and b"bind" in lib.icv_last_error()
+        assert lib.icv_dit_forward(h, 8, 16, 4, 8, 8, 8, 8, 8, 1, 0, None, None, 0, 0, None, 8, 5, 0, 1.0, None) != 0
+        assert b"num_layers" in lib.icv_last_error()
+        ms, n = ctypes.c_double(-1.0), ctypes.c_int64(-1)
+        assert lib.icv_dit_profile(h, 1) == 0 and lib.icv_dit_profile_read(h, ctypes.byref(ms), ctypes.byref(n)) == 0
+        assert (ms.value, n.value) == (0.0, 0)
+    finally:
+        lib.icv_dit_destroy(h)
+    assert lib.icv_comm_create(b"\0" * native.COMM_ID_BYTES, 2, 2, ctypes.byref(h)) != 0 and b"bad (rank, world)" in lib.icv_last_error()
+    assert lib.icv_allgather_kv(None, 8, 8, 4, 16, None) != 0 and b"null argument" in lib.icv_last_error()
