@@ -68,3 +68,17 @@ def test_context_entry_points_validate_without_gpu():
         lib.icv_dit_destroy(h)
     assert lib.icv_comm_create(b"\0" * native.COMM_ID_BYTES, 2, 2, ctypes.byref(h)) != 0 and b"bad (rank, world)" in lib.icv_last_error()
     assert lib.icv_allgather_kv(None, 8, 8, 4, 16, None) != 0 and b"null argument" in lib.icv_last_error()
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/icvideo.h is the drop-in boundary: it must compile as C99 (no C++ / torch types) and as C++."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        import pytest
+        pytest.skip("no gcc")
+    src = tmp_path / "h.c"
+    src.write_text('#include "icvideo.h"\nint main(void) { return icv_abi_version == 0; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)], check=True)
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, "-x", "c++", str(src)], check=True)
