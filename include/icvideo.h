@@ -36,12 +36,15 @@ const char* icv_last_error(void);
 int icv_device_info(int device, int64_t out[4]);
 
 /* Kernel-variant switches for A/B measurement; defaults = shipped configuration.  "gemm256" = 0 | 1 | 2 (heuristic),
- * "gemm256_mfma" = 16 | 32, "gemm256_sched" = bit 0: two 32-MFMA phases per K-tile, bit 1: batched residual loads (default 3),
- * "gemm256_gm" (tile-group size), "attn_kernel" = 7 (attn7.hip, default) | 2 (attn2.hip); 1, 3..6, 9 and "gemm256" = 3 are the
- * measured-slower experiments under csrc/experiments/, present only in a library built with ICV_EXPERIMENTS=1
- * ("require_experiments" returns 0 exactly then), "attn<N>_variant" (bit flags, see each file), "attn_defer_max_log2"
- * (rescale threshold, default 8), "attn_unit_scale" = 0 | 1, "ln_waves_per_row" = 0 | 1 | 2 | 4.  The Python host also reads
- * them from the environment: ICV_OPTIONS="name=value,name=value". */
+ * "gemm256_mfma" = 16 | 32, "gemm256_sched" = bit 0: two 32-MFMA phases per K-tile, bit 1: batched residual loads (default 3;
+ * 7 = + B1 requested a full tile ahead, 11 = + serpentine MFMA order: both measured ties), "gemm256_gm" (tile-group size),
+ * "gemm_fp8_sched" = 3 (default) | 0 (round 1's four-phase loop), "attn_kernel" = 7 (attn7.hip, default) | 2 (attn2.hip);
+ * attention families 1, 3..6, 9 and "gemm256" = 3 | 4 (the two 4-wave GEMMs) are the measured-slower experiments under
+ * csrc/experiments/, present only in a library built with ICV_EXPERIMENTS=1 ("require_experiments" returns 0 exactly then),
+ * "attn<N>_variant" (bit flags, see each file), "attn_defer_max_log2" (rescale threshold, default 8), "attn_unit_scale" = 0 | 1,
+ * "ln_waves_per_row" = 0 | 1 | 2 | 4.  TIMING ABLATIONS that make results WRONG on purpose (tools/ only): "gemm256_ablate",
+ * "gemm256x_ablate", "attn7_ablate".  The Python host also reads options from the environment:
+ * ICV_OPTIONS="name=value,name=value". */
 int icv_set_option(const char* name, int value);
 
 /* ---- GEMM with fused epilogues (K1, K2, K4, K7, K9, K10, K11 of SURVEY §8a-3) ------------
