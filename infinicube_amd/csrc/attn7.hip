@@ -65,6 +65,9 @@ __global__ __launch_bounds__(512) void attn7_kernel(Params p) {
   // QK^T MFMA order: d-step major (consecutive MFMAs share the Q fragment: less operand toggling, +0.6...1.4 % under the power
   // cap, profiles/r02/attention_variants.md) unless bit 32 asks for round 1's key-block-major order
   constexpr bool DSMAJOR = !(VAR & 32);
+  // bit 64: K / V tile bases as running pointers instead of two 64-bit scalar multiplies per tile - fewer SALU issues, yet
+  // 1 % SLOWER (1159 vs 1171 TF/s, profiles/r02/attention_variants.md): kept as a switch only
+  constexpr bool RUNPTR = (VAR & 64) != 0;
   static_assert(!(STAGGER && DEEP), "the staggered group already runs its DMA three tiles ahead");   // 16: unit scale (set by the dispatcher)
   const float p_lim = __builtin_amdgcn_exp2f(p.thr);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -115,7 +118,39 @@ __global__ __launch_bounds__(512) void attn7_kernel(Params p) {
   const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
   const unsigned ko0 = (unsigned)(((int64_t)dkey0 * p.ldk + kcol0) * 2), ko1 = (unsigned)(((int64_t)dkey1 * p.ldk + kcol1) * 2);
   const unsigned vo0 = (unsigned)(((int64_t)dkey0 * p.ldv + vcol0) * 2), vo1 = (unsigned)(((int64_t)dkey1 * p.ldv + vcol1) * 2);
-#define A7_DMA_TILE(T_)                                                                              \
+  // The tiles are requested strictly in order (0, 1, 2, ... by every wave), so the K / V tile bases are RUNNING pointers
+  // advanced by one tile per request (clamped at the last tile: requests past the end re-read it into a dead stage) -
+  // two 64-bit scalar adds instead of the two 64-bit multiplies per tile the indexed form cost.
+  const int n_full = (int)(p.Skv / KVB);                      // tiles that need no row clamping
+  const int64_t kstep = (int64_t)KVB * p.ldk, vstep = (int64_t)KVB * p.ldv;
+  int dma_t = 0, dma_tile = 0;                                // request counter, tile it maps to (= min(dma_t, nt - 1))
+  const bf16_t* kt_run = kh;
+  const bf16_t* vt_run = vh;
+#define A7_DMA_TILE_RUN(T_)                                                                          \
+  {                                                                                                  \
+    const unsigned l0_ = lds_base + (unsigned)((dma_t & (NSTAGE - 1)) * STAGE_BYTES + (wave * 2) * 1024); \
+    if (dma_tile < n_full) {                                                                         \
+      dma16s(kt_run, ko0, l0_);                                                                      \
+      dma16s(kt_run, ko1, l0_ + 1024);                                                               \
+      dma16s(vt_run, vo0, l0_ + TILE_BYTES);                                                         \
+      dma16s(vt_run, vo1, l0_ + TILE_BYTES + 1024);                                                  \
+    } else {                                                                                         \
+      int64_t r0_ = (int64_t)dma_tile * KVB + dkey0, r1_ = (int64_t)dma_tile * KVB + dkey1;          \
+      r0_ = r0_ < p.Skv ? r0_ : p.Skv - 1;                                                           \
+      r1_ = r1_ < p.Skv ? r1_ : p.Skv - 1;                                                           \
+      dma16(kh + r0_ * p.ldk + kcol0, l0_);                                                          \
+      dma16(kh + r1_ * p.ldk + kcol1, l0_ + 1024);                                                   \
+      dma16(vh + r0_ * p.ldv + vcol0, l0_ + TILE_BYTES);                                             \
+      dma16(vh + r1_ * p.ldv + vcol1, l0_ + TILE_BYTES + 1024);                                      \
+    }                                                                                                \
+    ++dma_t;                                                                                         \
+    if (dma_t < nt) {                                                                                \
+      dma_tile = dma_t;                                                                              \
+      kt_run += kstep;                                                                               \
+      vt_run += vstep;                                                                               \
+    }                                                                                                \
+  }
+#define A7_DMA_TILE_IDX(T_)                                                                          \
   {                                                                                                  \
     const int tt_ = (T_) < nt ? (T_) : nt - 1;                                                       \
     const unsigned l0_ = lds_base + (unsigned)(((T_) & (NSTAGE - 1)) * STAGE_BYTES + (wave * 2) * 1024); \
@@ -136,6 +171,11 @@ __global__ __launch_bounds__(512) void attn7_kernel(Params p) {
       dma16(vh + r1_ * p.ldv + vcol1, l0_ + TILE_BYTES + 1024);                                      \
     }                                                                                                \
   }
+#define A7_DMA_TILE(T_)                  \
+  do {                                   \
+    if (RUNPTR) A7_DMA_TILE_RUN(T_)      \
+    else A7_DMA_TILE_IDX(T_)             \
+  } while (0)
 // counted wait: the youngest tile (4 DMA instructions per wave) - DEEP: the two youngest - may still be in flight
 #define A7_VMCNT4()                                              \
   do {                                                           \
@@ -346,6 +386,8 @@ int icv_attn7_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, c
     case 7: return att7::launch<7>(p, st);
     case 8: return att7::launch<8>(p, st);
     case 24: return att7::launch<24>(p, st);
+    case 64: return att7::launch<64>(p, st);
+    case 80: return att7::launch<80>(p, st);
     case 32: return att7::launch<32>(p, st);
     case 48: return att7::launch<48>(p, st);
     case 16: return att7::launch<16>(p, st);

@@ -324,7 +324,7 @@ def test_attention2_variants(hip_ops, variant):
         hip_ops.lib.icv_set_option(b"attn2_variant", 12); hip_ops.lib.icv_set_option(b"attn_kernel", ATTN_DEFAULT)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 4, 5, 6, 7, 8, 32])
+@pytest.mark.parametrize("variant", [0, 1, 4, 5, 6, 7, 8, 32, 64])
 def test_attention7_variants(hip_ops, variant):
     """attn7.hip (LDS-DMA ring + lazy max + persistent reference vector) at the generic scale; the unit-scale route is
     covered by test_attention_unit_scale[kernel 7]."""
