@@ -303,10 +303,11 @@ def _layout_worker(rank, world, port, q, mode, kv_exchange="allgather"):
 
 
 @pytest.mark.parametrize("world,mode,kv_exchange", [(2, "cfg+sp", "allgather"), (4, "cfg+sp", "allgather"), (4, "cfg+sp", "p2p"),
-                                                   (3, "sp", "p2p")])
+                                                   (3, "sp", "p2p"), (8, "auto", "allgather")])
 def test_gloo_cfg_branch_parallel_equals_single(world, mode, kv_exchange):
     """cfg+sp layout over real processes (gloo): world 2 = one rank per CFG branch and no K/V exchange; world 4 =
-    two branch groups x two token shards (group-local K/V all-gather + the per-step velocity swap)."""
+    two branch groups x two token shards (group-local K/V all-gather + the per-step velocity swap); world 8 with "auto" =
+    exactly what `bench.py --gpus 8` builds on an 8-GPU node (two groups of four token shards, four pair groups)."""
     sd, bsd, noise, c1, c2, bl = _inputs()
     single = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID)
     ref = noise.clone()
