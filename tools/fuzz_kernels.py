@@ -5,7 +5,9 @@ split-plane outputs, every epilogue, both tile families, carried-state key chunk
 stock PyTorch fp32 computation of the same op on the GPU (test infrastructure; independent of libicvideo).  Every launch
 is repeated and must be bit-identical (race screen for the counted-vmcnt rings).
 
-    python tools/fuzz_kernels.py [seconds] [seed]      -> prints one line per failure and a summary; exit code 1 on any failure
+    python tools/fuzz_kernels.py [seconds] [seed] [cases]   -> prints one line per failure and a summary; exit code 1 on any failure
+                                                              (cases > 0: stop after exactly that many cases instead of after
+                                                              `seconds` - the sequence is then a pure function of the seed)
 """
 import math
 import os
@@ -21,6 +23,7 @@ from infinicube_amd.videogen.ops import EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RE
 DEV = "cuda:0"
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+max_cases = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 rng = random.Random(seed)
 ops = HipOps(DEV)
 fails = []
@@ -152,7 +155,7 @@ def fuzz_attention():
 
 t0, n = time.time(), {"gemm": 0, "attention": 0}
 try:
-    while time.time() - t0 < budget:
+    while (n["gemm"] + n["attention"] < max_cases) if max_cases > 0 else (time.time() - t0 < budget):
         if rng.random() < 0.6:
             fuzz_gemm(); n["gemm"] += 1
         else:
