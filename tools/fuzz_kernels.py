@@ -18,7 +18,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
-from infinicube_amd.videogen.ops import EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_F32, HipOps  # noqa: E402
+from infinicube_amd.videogen.ops import EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_F32, FP8, HipOps  # noqa: E402
 
 DEV = "cuda:0"
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
@@ -103,6 +103,80 @@ def fuzz_gemm():
         fails.append(what + ": two identical launches differ (race?)")
 
 
+def fuzz_gemm_fp8():
+    """e4m3 GEMM: operands quantised by the library's own row quantiser, reference = the dequantised product in fp32"""
+    M = rng.choice([1, 63, 64, 257, 300, 777, 1030, 2049]) if rng.random() < 0.7 else rng.randint(1, 2500)
+    N = 4 * rng.choice([1, 16, 33, 64, 65, 128, 192, 260, 384]) if rng.random() < 0.7 else 4 * rng.randint(1, 500)
+    K = 128 * rng.choice([1, 2, 3, 4, 12, 20])
+    epi = rng.choice([EPI_BF16, EPI_GELU_BF16, EPI_RESID_F32, EPI_F32])
+    ops.lib.icv_set_option(b"gemm_fp8_sched", rng.choice([3, 3, 0]))
+    g = torch.Generator(device=DEV).manual_seed(rng.randint(0, 2 ** 31))
+    a = torch.randn((M, K), device=DEV, generator=g) * 1.5
+    if rng.random() < 0.5:
+        a[:, 3 % K] *= 25.0                # an outlier channel: the per-row scale is set by it
+    w = torch.randn((N, K), device=DEV, generator=g) / math.sqrt(K)
+    a8, asc = torch.empty((M, K), dtype=FP8, device=DEV), torch.empty((M,), device=DEV)
+    w8, wsc = torch.empty((N, K), dtype=FP8, device=DEV), torch.empty((N,), device=DEV)
+    ops.quantize_rows(a, a8, asc); ops.quantize_rows(w, w8, wsc)
+    bias = torch.randn((N,), device=DEV, generator=g) * 0.1 if rng.random() < 0.8 else None
+    acc = (a8.float() * asc[:, None]).double() @ (w8.float() * wsc[:, None]).double().t()
+    acc = acc.float() + (bias if bias is not None else 0.0)
+    what = f"gemm_fp8 M={M} N={N} K={K} epi={epi} bias={bias is not None}"
+    outs = []
+    if epi in (EPI_BF16, EPI_GELU_BF16):
+        ref = F.gelu(acc, approximate="tanh") if epi == EPI_GELU_BF16 else acc
+        for _ in range(2):
+            out = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV)
+            ops.gemm_fp8(a8, asc, w8, wsc, bias, out, epi)
+            outs.append(out)
+        ok = close_bf16(outs[0], ref, what)
+    elif epi == EPI_RESID_F32:
+        resid = torch.randn((M, N), device=DEV, generator=g)
+        gate = torch.randn((N,), device=DEV, generator=g) if rng.random() < 0.7 else None
+        for _ in range(2):
+            x = resid.clone()
+            ops.gemm_fp8(a8, asc, w8, wsc, bias, x, epi, resid=x, gate=gate)
+            outs.append(x)
+        ok = close_f32(outs[0], resid + (gate if gate is not None else 1.0) * acc, what + f" gate={gate is not None}", rtol=1e-3)
+    else:
+        for _ in range(2):
+            out = torch.empty((M, N), device=DEV)
+            ops.gemm_fp8(a8, asc, w8, wsc, bias, out, epi)
+            outs.append(out)
+        ok = close_f32(outs[0], acc, what, rtol=1e-3)
+    if ok and not torch.equal(outs[0], outs[1]):
+        fails.append(what + ": two identical launches differ (race?)")
+
+
+def fuzz_attention_fp8():
+    """e4m3 attention against exact softmax attention on the SAME bf16 inputs: the bar is the e4m3 noise floor (rms error
+    <= 6 % of the output rms: the GPU test suite holds it to 3 % against an oracle with the same quantisation)"""
+    H = rng.choice([1, 2, 3])
+    Sq = rng.choice([1, 33, 256, 257, 300, 513]) if rng.random() < 0.7 else rng.randint(1, 1200)
+    Skv = rng.choice([64, 65, 128, 257, 640, 1100, 3000]) if rng.random() < 0.7 else rng.randint(1, 3000)
+    d = H * 128
+    g = torch.Generator(device=DEV).manual_seed(rng.randint(0, 2 ** 31))
+    q = torch.randn((Sq, d), device=DEV, generator=g).to(torch.bfloat16)
+    k = (torch.randn((Skv, d), device=DEV, generator=g) * (128 ** -0.5 * math.log2(math.e))).to(torch.bfloat16)
+    v = torch.randn((Skv, d), device=DEV, generator=g).to(torch.bfloat16)
+    ref = ref_attention(q, k, v, H, math.log(2.0))
+    ws = ops.attention_fp8_buffers(Sq, Skv, d, H)
+    outs = []
+    for _ in range(2):
+        o = torch.zeros((Sq, d), dtype=torch.bfloat16, device=DEV)
+        ops.attention_fp8(q, k, v, o, H, ws)
+        outs.append(o)
+    what = f"attention_fp8 Sq={Sq} Skv={Skv} H={H}"
+    rms = float(ref.pow(2).mean().sqrt())
+    err = float((outs[0].float() - ref).pow(2).mean().sqrt())
+    # few rows = a noisy estimate of the relative error (one row of uniform attention over many keys has a tiny output)
+    bar = 0.06 if Sq * H >= 64 else 0.15
+    if not torch.isfinite(outs[0].float()).all() or err > bar * rms:
+        fails.append(f"{what}: rms err {err:.3g} vs rms {rms:.3g}")
+    elif not torch.equal(outs[0], outs[1]):
+        fails.append(what + ": two identical launches differ (race?)")
+
+
 def ref_attention(q, k, v, H, scale):
     Sq, Skv = q.shape[0], k.shape[0]
     qh, kh, vh = (t.float().reshape(-1, H, 128).transpose(0, 1) for t in (q, k, v))
@@ -153,18 +227,27 @@ def fuzz_attention():
         fails.append(what + ": two identical launches differ (race?)")
 
 
-t0, n = time.time(), {"gemm": 0, "attention": 0}
+t0, n = time.time(), {"gemm": 0, "attention": 0, "gemm_fp8": 0, "attention_fp8": 0}
+FP8_TOO = os.environ.get("FUZZ_FP8", "0") == "1"     # FUZZ_FP8=1 adds the e4m3 entry points (a different case sequence)
 try:
-    while (n["gemm"] + n["attention"] < max_cases) if max_cases > 0 else (time.time() - t0 < budget):
-        if rng.random() < 0.6:
+    while (sum(n.values()) < max_cases) if max_cases > 0 else (time.time() - t0 < budget):
+        if FP8_TOO and rng.random() < 0.3:
+            if rng.random() < 0.6:
+                fuzz_gemm_fp8(); n["gemm_fp8"] += 1
+            else:
+                fuzz_attention_fp8(); n["attention_fp8"] += 1
+        elif rng.random() < 0.6:
             fuzz_gemm(); n["gemm"] += 1
         else:
             fuzz_attention(); n["attention"] += 1
 finally:
     ops.lib.icv_set_option(b"gemm256", 2); ops.lib.icv_set_option(b"gemm256_mfma", 16); ops.lib.icv_set_option(b"gemm256_sched", 3)
     ops.lib.icv_set_option(b"attn_kernel", 7); ops.lib.icv_set_option(b"attn7_variant", 0)
+    ops.lib.icv_set_option(b"gemm_fp8_sched", 3)
 torch.cuda.synchronize()
 for f in fails[:40]:
     print("FAIL", f)
-print(f"fuzz seed {seed}: {n['gemm']} GEMM cases, {n['attention']} attention cases in {time.time() - t0:.0f} s, {len(fails)} failures")
+print(f"fuzz seed {seed}: {n['gemm']} GEMM cases, {n['attention']} attention cases" +
+      (f", {n['gemm_fp8']} e4m3 GEMM cases, {n['attention_fp8']} e4m3 attention cases" if FP8_TOO else "") +
+      f" in {time.time() - t0:.0f} s, {len(fails)} failures")
 sys.exit(1 if fails else 0)
