@@ -92,6 +92,51 @@ def cpu_baseline(cfg, grid, threads):
     }
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without torch.distributed.run: start N copies of this script, one per GPU, with the
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* environment torch.distributed.run would give them; rank 0 inherits this
+    process's stdout (its ONE JSON line is the output), the other ranks' stdout goes to stderr.  A rank that fails takes
+    the others down (exactly the PIDs started here) and its exit code is returned."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("ICV_BENCH_SHARE_GPU", "0") != "1":
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "4")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr, stdin=subprocess.DEVNULL))
+    rc = 0
+    try:
+        alive = set(range(n))
+        while alive:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                    for o in alive:
+                        procs[o].terminate()
+            time.sleep(0.2)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+                pr.wait()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,13 +172,15 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N` (no launcher): become the launcher — one rank per GPU, exactly the processes
+        # torch.distributed.run would start — and hand rank 0's JSON line through
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
-        args.gpus = world
+        args.gpus = world        # the launcher's world size is authoritative
     # one process per GPU.  ICV_BENCH_SHARE_GPU=1 (+ ICV_DIST_BACKEND=gloo) lets several ranks share the only GPU of a
     # development box so the N>1 code path can be exercised there; it is never a measurement mode.
     share = os.environ.get("ICV_BENCH_SHARE_GPU", "0") == "1"
@@ -248,16 +295,31 @@ def main():
     calls0 = native.N_CALLS[0]
     t0 = time.perf_counter()
     run_steps(args.warmup, args.steps)
-    t_enqueued = time.perf_counter() - t0    # the host has ISSUED every launch of the timed steps (GPU still running)
+    t_in_loop = time.perf_counter() - t0     # host time inside the timed loop: issue time PLUS blocking on a full HIP queue
     sync()
     elapsed = time.perf_counter() - t0
     record["on"] = False
     abi_calls = native.N_CALLS[0] - calls0
+    kv_waits = list(model.kv_gather.timing or []) if model.kv_gather is not None else []
+    n_coll = model.kv_gather.n_collectives if model.kv_gather is not None else 0
+    if model.kv_gather is not None:
+        model.kv_gather.timing = None
+    native_reads = None
+    if args.native_forward:   # events recorded by the C driver around its own self-attention launches of the TIMED steps
+        native_reads = [model.native_profile_read()] + ([model._twin[0].native_profile_read()] if model._twin is not None else [])
+        model.native_profile(False)
+        if model._twin is not None:
+            model._twin[0].native_profile(False)
+    # host ISSUE time of one step, measured where nothing back-pressures it: the queue is empty (sync above) and one step's
+    # launches fit in it, so this is what the host needs to enqueue a step; the GPU then runs it (outside the timed region)
+    t1 = time.perf_counter()
+    run_steps(args.warmup + args.steps, 1)
+    t_issue_one = time.perf_counter() - t1
+    sync()
     comm = None
     if world > 1:
-        waits = (model.kv_gather.timing or []) if model.kv_gather is not None else []   # cfg+sp at N=2: no K|V exchange at all
+        waits = kv_waits                                   # cfg+sp at N=2: no K|V exchange at all
         exposed_ms = sum(a.elapsed_time(b) for a, b in waits)
-        n_coll = model.kv_gather.n_collectives if model.kv_gather is not None else 0
         tt = torch.tensor([exposed_ms, float(len(waits)), float(n_coll)], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         comm = {"rccl_ranks": world, "kv_exchange": args.kv_exchange, "sp_chunks": args.sp_chunks,
@@ -266,8 +328,6 @@ def main():
                 "kv_bytes_sent_per_exchange_layer": 2 * 2 * plan.n_tok * cfg.dim if layout.sp_world > 1 else 0,
                 "exposed_kv_wait_ms_per_step": tt[0].item() / args.steps,      # max over ranks of the compute-stream stalls
                 "kv_chunk_waits_per_step": tt[1].item() / args.steps}
-        if model.kv_gather is not None:
-            model.kv_gather.timing = None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -279,7 +339,7 @@ def main():
         attn_flops = 4.0 * plan.n_tok * (sum(kk for _, _, kk in chunk_events) / len(chunk_events)) * cfg.dim
         attn_events = chunk_events
     elif args.native_forward:   # events recorded by the C driver around its own self-attention launches
-        reads = [model.native_profile_read()] + ([model._twin[0].native_profile_read()] if model._twin is not None else [])
+        reads = native_reads
         n_timed = sum(n for _, n in reads)
         attn_ms = sum(ms for ms, _ in reads) / max(n_timed, 1)
         attn_events = [None] * n_timed
@@ -325,7 +385,8 @@ def main():
                 "wallclock_50_steps_s": 50.0 * elapsed / args.steps,
                 "cfg_stem_shared": bool(args.share_stem),
                 "c_abi_calls_per_forward": abi_calls / (args.steps * (1 if layout.mode == "cfg+sp" else 2)),
-                "host_enqueue_ms_per_step": 1e3 * t_enqueued / args.steps,
+                "host_enqueue_ms_per_step": 1e3 * t_issue_one,       # one extra step issued on a drained queue (untimed for the metric)
+                "host_ms_in_timed_loop_per_step": 1e3 * t_in_loop / args.steps,   # includes blocking inside launches once the HIP queue is full: NOT issue cost
                 "forward_driver": "icv_dit_forward (C)" if args.native_forward else "per-op C entry points driven from videogen/dit.py",
                 "algorithmic_pflop_per_step": f_step / 1e15,
                 "model_tflops_all_gpus": f_step * args.steps / elapsed / 1e12,

@@ -22,6 +22,20 @@ int icv_check_launch(const char* what) {
   return 0;
 }
 
+int icv_ensure_dynamic_lds(const void* func, int bytes, icv_dev_flags* flags, const char* what) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+  const bool tracked = dev >= 0 && dev < ICV_MAX_DEVICES;
+  if (tracked && flags->set[dev]) return 0;
+  hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    icv_set_error("%s: hipFuncSetAttribute(%d bytes of LDS) failed on device %d: %s", what, bytes, dev, hipGetErrorString(e));
+    return 2;
+  }
+  if (tracked) flags->set[dev] = true;   // benign race: two threads of one device may both set the attribute once
+  return 0;
+}
+
 // ---- runtime options (A/B switches for kernel variants; defaults are the shipped configuration) ----
 #include <map>
 #include <mutex>

@@ -17,11 +17,8 @@ using attc::NEG_BIG;
 using attc::Params;
 using attc::lds_read_tr16;
 constexpr int KVB = 64;
-constexpr int QB = 256;
 constexpr int TILE_BYTES = KVB * D * 2;      // 16 KiB (K or V)
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;  // 32 KiB
-constexpr int NSTAGE = 4;
-constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;  // 128 KiB
 
 // LDS-DMA through inline asm: hipcc does not count it, so it never guards the (alias-info-free)
 // ds_read_b64_tr_b16 reads with vmcnt(0); completion is tracked by our own counted s_waitcnt vmcnt.
@@ -54,21 +51,36 @@ __device__ __forceinline__ void dma16s(const void* base, unsigned off, unsigned 
       : "memory");
 }
 
+#ifndef ATTN7_SHORT_DEFAULT
+#define ATTN7_SHORT_DEFAULT 1024
+#endif
+
 // VAR bit flags: 1 = stagger wave groups, 2 = issue all 16 K-fragment reads ahead of the QK^T MFMAs,
 //                4 = s_setprio(1) around MFMA clusters, 8 = K/V DMA three tiles ahead instead of two (not with 1),
 //                16 = unit scale, 32 = QK^T MFMAs in key-block-major order (round 1's; the default is d-step major)
 // (tried and dropped: row sums with v_pk_add_f32 — 8 fewer VALU issues per 32-key block, 1142.6 vs 1149.5 TF/s, noise:
 //  the kernel is power-limited, profiles/r02/power_limit_probes.md)
-template <int VAR>
-__global__ __launch_bounds__(512) void attn7_kernel(Params p) {
+// Geometry (template NW, NST): NW waves x 32 query rows per block, NST ring stages of one 64-key K + V tile (32 KiB).
+//   <8, 4> (default, self-attention): 256 rows, 128 KiB ring, one block per CU, counted vmcnt (DMA two tiles ahead);
+//   <4, 2> (short key sequences, i.e. the 512 / 257-key cross-attention, option "attn7_short"): 128 rows, 64 KiB, so TWO
+//          blocks share a CU and one block's prologue (Q load, ring fill) and epilogue (O store) - half of a launch that
+//          has only 8 key tiles per row - run under the other's MFMAs; DMA one interval ahead, vmcnt(0) + barrier per tile.
+template <int VAR, int NW, int NST>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) void attn7_kernel(Params p) {
   constexpr bool STAGGER = VAR & 1, KPREFETCH = VAR & 2, SETPRIO = VAR & 4, DEEP = VAR & 8, UNIT = VAR & 16;
   // QK^T MFMA order: d-step major (consecutive MFMAs share the Q fragment: less operand toggling, +0.6...1.4 % under the power
   // cap, profiles/r02/attention_variants.md) unless bit 32 asks for round 1's key-block-major order
   constexpr bool DSMAJOR = !(VAR & 32);
-  // bit 64: K / V tile bases as running pointers instead of two 64-bit scalar multiplies per tile - fewer SALU issues, yet
-  // 1 % SLOWER (1159 vs 1171 TF/s, profiles/r02/attention_variants.md): kept as a switch only
-  constexpr bool RUNPTR = (VAR & 64) != 0;
+  // bit 128: 128-key publish granularity - the ring is used as two halves of two 64-key tiles; an interval computes tiles
+  // (t, t+1) from one half while the DMA of (t+2, t+3) fills the other, ONE vmcnt(0) + barrier per 128 keys instead of a
+  // counted wait + barrier per 64 (round 3's bounded attempt at the per-tile barrier cost; profiles/r03/attention_variants.md)
+  constexpr bool PAIR = (VAR & 128) != 0;
+  static_assert(!(PAIR && (STAGGER || DEEP)), "the paired schedule has its own DMA distance");
   static_assert(!(STAGGER && DEEP), "the staggered group already runs its DMA three tiles ahead");   // 16: unit scale (set by the dispatcher)
+  static_assert(NST == 4 || !(PAIR || STAGGER || DEEP), "the two-stage ring has one schedule");
+  static_assert(NW == 8 || !STAGGER, "the stagger pairs waves 0-3 with 4-7");
+  constexpr int NI = 16 / NW;                    // DMA instructions per wave per K (or V) tile: 16 KiB = 16 x 1 KiB
+  constexpr int QB = NW * 32;
   const float p_lim = __builtin_amdgcn_exp2f(p.thr);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -99,84 +111,53 @@ __global__ __launch_bounds__(512) void attn7_kernel(Params p) {
   for (int r = 0; r < 16; ++r) cinit[r] = UNIT ? -m_base : 0.f;
 
   bf16x8 qf[8];
-  {
-    const bf16_t* qp = qh + qr_c * p.ldq + hi * 8;
-#pragma unroll
-    for (int ds = 0; ds < 8; ++ds) qf[ds] = *reinterpret_cast<const bf16x8*>(qp + ds * 16);
+#define A7_LOAD_Q()                                                                                   \
+  {                                                                                                   \
+    const bf16_t* qp = qh + qr_c * p.ldq + hi * 8;                                                    \
+    _Pragma("unroll") for (int ds = 0; ds < 8; ++ds) qf[ds] = *reinterpret_cast<const bf16x8*>(qp + ds * 16); \
   }
-  // Retire the ordinary (VGPR-destination) prologue loads before any LDS-DMA is in flight: beside a
-  // DMA hipcc waits vmcnt(0) for every ordinary load, which would drain the ring (guide §5 trap (b)).
-  __builtin_amdgcn_s_waitcnt(0x0F70);
+  if (NST != 2) {
+    A7_LOAD_Q();
+    // Retire the ordinary (VGPR-destination) prologue loads before any LDS-DMA is in flight: beside a
+    // DMA hipcc waits vmcnt(0) for every ordinary load, which would drain the ring (guide §5 trap (b)).
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+  }
 
-  // ---- LDS-DMA lane mapping: instruction j of this wave covers keys (wave*2 + j)*4 + lane/16 ----
-  const int dkey0 = (wave * 2 + 0) * 4 + (lane >> 4);
-  const int dkey1 = (wave * 2 + 1) * 4 + (lane >> 4);
+  // ---- LDS-DMA lane mapping: instruction j of this wave covers keys (wave*NI + j)*4 + lane/16 ----
   const int pc = lane & 15;
-  const int kcol0 = (pc ^ (dkey0 & 15)) * 8, kcol1 = (pc ^ (dkey1 & 15)) * 8;        // elements
-  const int vcol0 = (pc ^ ((dkey0 & 3) << 2)) * 8, vcol1 = (pc ^ ((dkey1 & 3) << 2)) * 8;
   const int nt = (int)((p.Skv + KVB - 1) / KVB);
   const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
-  const unsigned ko0 = (unsigned)(((int64_t)dkey0 * p.ldk + kcol0) * 2), ko1 = (unsigned)(((int64_t)dkey1 * p.ldk + kcol1) * 2);
-  const unsigned vo0 = (unsigned)(((int64_t)dkey0 * p.ldv + vcol0) * 2), vo1 = (unsigned)(((int64_t)dkey1 * p.ldv + vcol1) * 2);
-  // The tiles are requested strictly in order (0, 1, 2, ... by every wave), so the K / V tile bases are RUNNING pointers
-  // advanced by one tile per request (clamped at the last tile: requests past the end re-read it into a dead stage) -
-  // two 64-bit scalar adds instead of the two 64-bit multiplies per tile the indexed form cost.
-  const int n_full = (int)(p.Skv / KVB);                      // tiles that need no row clamping
-  const int64_t kstep = (int64_t)KVB * p.ldk, vstep = (int64_t)KVB * p.ldv;
-  int dma_t = 0, dma_tile = 0;                                // request counter, tile it maps to (= min(dma_t, nt - 1))
-  const bf16_t* kt_run = kh;
-  const bf16_t* vt_run = vh;
-#define A7_DMA_TILE_RUN(T_)                                                                          \
-  {                                                                                                  \
-    const unsigned l0_ = lds_base + (unsigned)((dma_t & (NSTAGE - 1)) * STAGE_BYTES + (wave * 2) * 1024); \
-    if (dma_tile < n_full) {                                                                         \
-      dma16s(kt_run, ko0, l0_);                                                                      \
-      dma16s(kt_run, ko1, l0_ + 1024);                                                               \
-      dma16s(vt_run, vo0, l0_ + TILE_BYTES);                                                         \
-      dma16s(vt_run, vo1, l0_ + TILE_BYTES + 1024);                                                  \
-    } else {                                                                                         \
-      int64_t r0_ = (int64_t)dma_tile * KVB + dkey0, r1_ = (int64_t)dma_tile * KVB + dkey1;          \
-      r0_ = r0_ < p.Skv ? r0_ : p.Skv - 1;                                                           \
-      r1_ = r1_ < p.Skv ? r1_ : p.Skv - 1;                                                           \
-      dma16(kh + r0_ * p.ldk + kcol0, l0_);                                                          \
-      dma16(kh + r1_ * p.ldk + kcol1, l0_ + 1024);                                                   \
-      dma16(vh + r0_ * p.ldv + vcol0, l0_ + TILE_BYTES);                                             \
-      dma16(vh + r1_ * p.ldv + vcol1, l0_ + TILE_BYTES + 1024);                                      \
-    }                                                                                                \
-    ++dma_t;                                                                                         \
-    if (dma_t < nt) {                                                                                \
-      dma_tile = dma_t;                                                                              \
-      kt_run += kstep;                                                                               \
-      vt_run += vstep;                                                                               \
-    }                                                                                                \
+  int dkey[NI], kcol[NI], vcol[NI];              // key row inside the tile, swizzled source column (elements)
+  unsigned ko[NI], vo[NI];                       // per-lane byte offsets from the tile base (saddr form)
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    dkey[j] = (wave * NI + j) * 4 + (lane >> 4);
+    kcol[j] = (pc ^ (dkey[j] & 15)) * 8;
+    vcol[j] = (pc ^ ((dkey[j] & 3) << 2)) * 8;
+    ko[j] = (unsigned)(((int64_t)dkey[j] * p.ldk + kcol[j]) * 2);
+    vo[j] = (unsigned)(((int64_t)dkey[j] * p.ldv + vcol[j]) * 2);
   }
-#define A7_DMA_TILE_IDX(T_)                                                                          \
+  // tile T_ (clamped to the last one: requests past the end re-read it into a dead stage, keeping the waits uniform)
+  // -> stage T_ % NST.  (A running-pointer form of the two 64-bit tile-base multiplies measured 1 % slower in round 2.)
+#define A7_DMA_TILE(T_)                                                                              \
   {                                                                                                  \
     const int tt_ = (T_) < nt ? (T_) : nt - 1;                                                       \
-    const unsigned l0_ = lds_base + (unsigned)(((T_) & (NSTAGE - 1)) * STAGE_BYTES + (wave * 2) * 1024); \
+    const unsigned l0_ = lds_base + (unsigned)(((T_) & (NST - 1)) * STAGE_BYTES + (wave * NI) * 1024); \
     if ((int64_t)(tt_ + 1) * KVB <= p.Skv) {                                                         \
       const bf16_t* kt_ = kh + (int64_t)tt_ * KVB * p.ldk;                                           \
       const bf16_t* vt_ = vh + (int64_t)tt_ * KVB * p.ldv;                                           \
-      dma16s(kt_, ko0, l0_);                                                                         \
-      dma16s(kt_, ko1, l0_ + 1024);                                                                  \
-      dma16s(vt_, vo0, l0_ + TILE_BYTES);                                                            \
-      dma16s(vt_, vo1, l0_ + TILE_BYTES + 1024);                                                     \
+      _Pragma("unroll") for (int j_ = 0; j_ < NI; ++j_) dma16s(kt_, ko[j_], l0_ + j_ * 1024);        \
+      _Pragma("unroll") for (int j_ = 0; j_ < NI; ++j_) dma16s(vt_, vo[j_], l0_ + TILE_BYTES + j_ * 1024); \
     } else {                                                                                         \
-      int64_t r0_ = (int64_t)tt_ * KVB + dkey0, r1_ = (int64_t)tt_ * KVB + dkey1;                    \
-      r0_ = r0_ < p.Skv ? r0_ : p.Skv - 1;                                                           \
-      r1_ = r1_ < p.Skv ? r1_ : p.Skv - 1;                                                           \
-      dma16(kh + r0_ * p.ldk + kcol0, l0_);                                                          \
-      dma16(kh + r1_ * p.ldk + kcol1, l0_ + 1024);                                                   \
-      dma16(vh + r0_ * p.ldv + vcol0, l0_ + TILE_BYTES);                                             \
-      dma16(vh + r1_ * p.ldv + vcol1, l0_ + TILE_BYTES + 1024);                                      \
+      _Pragma("unroll") for (int j_ = 0; j_ < NI; ++j_) {                                            \
+        int64_t r_ = (int64_t)tt_ * KVB + dkey[j_];                                                  \
+        r_ = r_ < p.Skv ? r_ : p.Skv - 1;                                                            \
+        dma16(kh + r_ * p.ldk + kcol[j_], l0_ + j_ * 1024);                                          \
+        dma16(vh + r_ * p.ldv + vcol[j_], l0_ + TILE_BYTES + j_ * 1024);                             \
+      }                                                                                              \
     }                                                                                                \
   }
-#define A7_DMA_TILE(T_)                  \
-  do {                                   \
-    if (RUNPTR) A7_DMA_TILE_RUN(T_)      \
-    else A7_DMA_TILE_IDX(T_)             \
-  } while (0)
-// counted wait: the youngest tile (4 DMA instructions per wave) - DEEP: the two youngest - may still be in flight
+// counted wait (8 waves: 4 DMA instructions per wave and tile): the youngest tile - DEEP: the two youngest - may still be in flight
 #define A7_VMCNT4()                                              \
   do {                                                           \
     if (DEEP) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   \
@@ -196,7 +177,14 @@ __global__ __launch_bounds__(512) void attn7_kernel(Params p) {
   A7_DMA_TILE(0);
   A7_DMA_TILE(1);
   if (DEEP) A7_DMA_TILE(2);
-  A7_VMCNT4();
+  if (NST == 2) {
+    // short rows (8 key tiles): the Q fragments are requested AFTER the first two tiles' DMA and one vmcnt(0) retires all
+    // three (vmcnt is in order), so the Q latency and the ring fill overlap instead of adding up - a visible share of a
+    // block that lives for 8 tiles; both ring stages are then full, which the loop's first wait expects anyway
+    A7_LOAD_Q();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else if (PAIR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // both tiles of the first half
+  else A7_VMCNT4();
   A7_BARRIER();
   if (grp == 1) {   // group 1's idle interval I_0: it still owes its DMA duties (issue tile 2, retire tile 1)
     A7_DMA_TILE(2);
@@ -212,13 +200,11 @@ __global__ __launch_bounds__(512) void attn7_kernel(Params p) {
   const int v_sw = (t16 >> 2) << 6;
   const int ahead = 2 + grp + (DEEP ? 1 : 0);   // group 1 runs one tile behind, so its DMA duties are one tile further ahead
 
-  for (int t = 0; t < nt; ++t) {
-    const char* ks = smem + (t & (NSTAGE - 1)) * STAGE_BYTES;
+  // one 64-key tile: K reads -> 16 QK^T MFMAs -> softmax -> V tr-reads -> 16 PV MFMAs (no DMA, no waits)
+  auto tile = [&](const int t) __attribute__((always_inline)) {
+    const char* ks = smem + (t & (NST - 1)) * STAGE_BYTES;
     const char* vs = ks + TILE_BYTES;
     const int64_t key0 = (int64_t)t * KVB;
-
-    // DMA of tile t+ahead first (longest possible flight), counted wait at the end of the interval
-    if (!(p.ablate & 1)) A7_DMA_TILE(t + ahead);
 
     f32x16 st[2];
     const bool no_ref = UNIT && m_run < -1.0e29f;
@@ -340,9 +326,36 @@ __global__ __launch_bounds__(512) void attn7_kernel(Params p) {
     }
     if (SETPRIO) __builtin_amdgcn_s_setprio(0);
     l_run += psum;
+  };
 
-    A7_VMCNT4();    // this wave's share of tile t+ahead-1 has landed (tile t+ahead may still be in flight)
-    if (!(p.ablate & 2)) A7_BARRIER();   // ... and is published to the block
+  if (NST == 2) {
+    // two-stage ring: tile t+1 was requested one interval ago; its stage is re-requested (tile t+2 -> stage t % 2) right
+    // after the barrier that ends the last read of tile t
+    for (int t = 0; t < nt; ++t) {
+      tile(t);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      A7_BARRIER();
+      A7_DMA_TILE(t + 2);
+    }
+  } else if (PAIR) {
+    for (int t = 0; t < nt; t += 2) {
+      if (!(p.ablate & 1)) {           // the other half of the ring: last read in the previous interval, before its barrier
+        A7_DMA_TILE(t + 2);
+        A7_DMA_TILE(t + 3);
+      }
+      tile(t);
+      if (t + 1 < nt) tile(t + 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // issued a whole 128-key interval ago
+      if (!(p.ablate & 2)) A7_BARRIER();
+    }
+  } else {
+    for (int t = 0; t < nt; ++t) {
+      // DMA of tile t+ahead first (longest possible flight), counted wait at the end of the interval
+      if (!(p.ablate & 1)) A7_DMA_TILE(t + ahead);
+      tile(t);
+      A7_VMCNT4();    // this wave's share of tile t+ahead-1 has landed (tile t+ahead may still be in flight)
+      if (!(p.ablate & 2)) A7_BARRIER();   // ... and is published to the block
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail DMAs before the LDS is released
   if (grp == 0 && STAGGER) A7_BARRIER();             // re-balance the stagger
@@ -350,20 +363,13 @@ __global__ __launch_bounds__(512) void attn7_kernel(Params p) {
   attc::store_result(p, q0 + l31, head, hi, ot, m_run, l_run);
 }
 
-template <int VAR>
+template <int VAR, int NW = 8, int NST = 4>
 int launch(const Params& p, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn7_kernel<VAR>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) {
-      icv_set_error("attn7: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return 2;
-    }
-    attr_set = true;
-  }
+  constexpr int LDS_BYTES = NST * STAGE_BYTES;   // 128 KiB (one block per CU) or 64 KiB (two)
+  static icv_dev_flags attr_set = {};
+  if (int rc = icv_ensure_dynamic_lds((const void*)attn7_kernel<VAR, NW, NST>, LDS_BYTES, &attr_set, "attn7")) return rc;
   const int64_t nwg = (int64_t)p.heads * p.nqb;
-  hipLaunchKernelGGL(attn7_kernel<VAR>, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p);
+  hipLaunchKernelGGL((attn7_kernel<VAR, NW, NST>), dim3((unsigned)nwg), dim3(NW * 64), LDS_BYTES, st, p);
   return icv_check_launch("icv_attention(7)");
 }
 
@@ -374,9 +380,15 @@ int icv_attn7_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, c
                        int state_out, int64_t Sq, int64_t Skv, int64_t heads, float scale, int var,
                        hipStream_t st) {
   att7::Params p;
-  attc::fill_params(p, q, ldq, k, ldk, v, ldv, o, ldo, acc, ldacc, ml, state_in, state_out, Sq, Skv, heads, scale, att7::QB);
+  // short key sequences (cross-attention: 512 text / 257 image keys = 8 / 5 tiles per row): 4-wave blocks on a two-stage ring,
+  // two per CU (see the kernel header); "attn7_short" = largest Skv that takes this shape (0 = never)
+  int short_max = icv_get_option_int("attn7_short", -1);
+  if (short_max < 0) short_max = ATTN7_SHORT_DEFAULT;            // negative = the built-in default
+  const bool short_kv = Skv <= short_max;
+  attc::fill_params(p, q, ldq, k, ldk, v, ldv, o, ldo, acc, ldacc, ml, state_in, state_out, Sq, Skv, heads, scale, short_kv ? 128 : 256);
   if (p.sc == 1.0f && icv_get_option_int("attn_unit_scale", 1)) var |= 16;
   p.ablate = icv_get_option_int("attn7_ablate", 0);   // timing experiments only (tools/attn_bench.py)
+  if (short_kv) return (var & 16) ? att7::launch<16, 4, 2>(p, st) : att7::launch<0, 4, 2>(p, st);
   switch (var) {
     case 0: return att7::launch<0>(p, st);
     case 1: return att7::launch<1>(p, st);
@@ -386,10 +398,12 @@ int icv_attn7_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, c
     case 7: return att7::launch<7>(p, st);
     case 8: return att7::launch<8>(p, st);
     case 24: return att7::launch<24>(p, st);
-    case 64: return att7::launch<64>(p, st);
-    case 80: return att7::launch<80>(p, st);
     case 32: return att7::launch<32>(p, st);
     case 48: return att7::launch<48>(p, st);
+    case 128: return att7::launch<128>(p, st);
+    case 144: return att7::launch<144>(p, st);
+    case 132: return att7::launch<132>(p, st);
+    case 148: return att7::launch<148>(p, st);
     case 16: return att7::launch<16>(p, st);
     case 17: return att7::launch<17>(p, st);
     case 20: return att7::launch<20>(p, st);

@@ -333,15 +333,8 @@ __global__ __launch_bounds__(512) void attn8_kernel(Params p) {
 
 template <int VAR>
 int launch(const Params& p, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn8_kernel<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) {
-      icv_set_error("attn8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return 2;
-    }
-    attr_set = true;
-  }
+  static icv_dev_flags attr_set = {};
+  if (int rc = icv_ensure_dynamic_lds((const void*)attn8_kernel<VAR>, LDS_BYTES, &attr_set, "attn8")) return rc;
   const int64_t nwg = (int64_t)p.heads * p.nqb;
   hipLaunchKernelGGL(attn8_kernel<VAR>, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p);
   return icv_check_launch("icv_attention_fp8_fwd");

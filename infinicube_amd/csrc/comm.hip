@@ -10,6 +10,8 @@
 #include <dlfcn.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "icv_common.h"
 
 namespace {
@@ -33,26 +35,25 @@ struct Rccl {
 
 Rccl* rccl() {
   static Rccl r;
-  static bool tried = false;
-  if (tried) return r.lib ? &r : nullptr;
-  tried = true;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
-  for (const char* nme : names) {
-    r.lib = dlopen(nme, RTLD_NOW | RTLD_GLOBAL);
-    if (r.lib) break;
-  }
-  if (!r.lib) return nullptr;
-  r.get_uid = (fn_get_uid)dlsym(r.lib, "ncclGetUniqueId");
-  r.init_rank = (fn_init_rank)dlsym(r.lib, "ncclCommInitRank");
-  r.destroy = (fn_destroy)dlsym(r.lib, "ncclCommDestroy");
-  r.allgather = (fn_allgather)dlsym(r.lib, "ncclAllGather");
-  r.errstr = (fn_errstr)dlsym(r.lib, "ncclGetErrorString");
-  if (!r.get_uid || !r.init_rank || !r.destroy || !r.allgather) {
-    dlclose(r.lib);
-    r.lib = nullptr;
-    return nullptr;
-  }
-  return &r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* nme : names) {
+      r.lib = dlopen(nme, RTLD_NOW | RTLD_GLOBAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) return;
+    r.get_uid = (fn_get_uid)dlsym(r.lib, "ncclGetUniqueId");
+    r.init_rank = (fn_init_rank)dlsym(r.lib, "ncclCommInitRank");
+    r.destroy = (fn_destroy)dlsym(r.lib, "ncclCommDestroy");
+    r.allgather = (fn_allgather)dlsym(r.lib, "ncclAllGather");
+    r.errstr = (fn_errstr)dlsym(r.lib, "ncclGetErrorString");
+    if (!r.get_uid || !r.init_rank || !r.destroy || !r.allgather) {
+      dlclose(r.lib);
+      r.lib = nullptr;
+    }
+  });
+  return r.lib ? &r : nullptr;
 }
 
 int fail(Rccl* r, const char* what, int rc) {

@@ -3,8 +3,9 @@
 // for a host that does not want to drive the per-op entry points itself.  It computes nothing of its own: every step is
 // one of the per-op launchers of this library, called in exactly the order infinicube_amd/videogen/dit.py issues them, so
 // the two drivers are bit-identical by construction (tests/test_dit_gpu.py::test_native_forward_matches_python_driver).
-// Scope: the bf16 single-rank path (t2v and i2v).  The fp8 modes and the sequence-parallel schedule (whose K|V exchange
-// lives in torch.distributed / RCCL on the host side) stay with the per-op driver.
+// Modes (all of dit.py's): bf16 and the e4m3 projection / e4m3 self-attention modes (icv_dit_set_fp8), t2v and i2v,
+// single rank and the sequence-parallel schedule (icv_dit_set_seqpar: K|V rows of every layer travel by icv_allgather_kv
+// on a side stream fenced with events, attention consumes the row chunks in arrival order with carried softmax state).
 #include <string.h>
 
 #include <map>
@@ -15,10 +16,22 @@
 
 namespace {
 
+// one projection weight: bf16 [N, K] (scale == nullptr) or e4m3 [N, K] + f32 scale per output row
+struct Wt {
+  const void* w = nullptr;
+  const float* s = nullptr;
+};
+
 struct Layer {
-  const void *wqkv = nullptr, *wo = nullptr, *xq_w = nullptr, *xo_w = nullptr, *f0_w = nullptr, *f2_w = nullptr;
+  Wt wqkv, wo, xq_w, xo_w, f0_w, f2_w;
   const float *bqkv = nullptr, *nq = nullptr, *nk = nullptr, *bo = nullptr, *n3w = nullptr, *n3b = nullptr, *xq_b = nullptr, *xnq = nullptr,
               *xo_b = nullptr, *f0_b = nullptr, *f2_b = nullptr;
+};
+
+// GEMM A operand: bf16 rows (s == nullptr) or e4m3 rows + one f32 scale per row
+struct Act {
+  const void* p = nullptr;
+  const float* s = nullptr;
 };
 
 }  // namespace
@@ -32,12 +45,29 @@ struct icv_dit {
   // workspace (borrowed, like every tensor of this ABI)
   float *x = nullptr, *x_stem = nullptr;
   void *h = nullptr, *qkv = nullptr, *att = nullptr, *ff = nullptr, *patches = nullptr;
+  // fp8 modes: e4m3 activations + row scales, e4m3 attention workspace
+  void *h8 = nullptr, *att8 = nullptr, *ff8 = nullptr;
+  float *h8s = nullptr, *att8s = nullptr, *ff8s = nullptr;
+  void *a8_qq = nullptr, *a8_kq = nullptr, *a8_vt = nullptr;
+  float* a8_amax = nullptr;
+  bool attn_fp8 = false;
+  // sequence-parallel schedule
+  icv_comm* comm = nullptr;
+  int64_t world = 1;
+  std::vector<int64_t> bounds;       // row bounds of the K|V exchange chunks inside the local shard
+  hipStream_t side = nullptr;
+  hipEvent_t ev_ready = nullptr;
+  std::vector<hipEvent_t> ev_done;
+  void *kv_loc = nullptr, *kv_full = nullptr;
+  float *sp_acc = nullptr, *sp_ml = nullptr;
   // optional per-launch timing of the self-attention kernel (icv_dit_profile): event pairs recorded on the launch stream
   bool profile = false;
   std::vector<hipEvent_t> events;   // 2 per timed launch; reused by the next profiled run after icv_dit_profile_read
   size_t n_events = 0;
   ~icv_dit() {
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev_done) (void)hipEventDestroy(e);
+    if (ev_ready) (void)hipEventDestroy(ev_ready);
   }
   hipEvent_t next_event() {
     if (n_events == events.size()) {
@@ -71,11 +101,11 @@ extern "C" int icv_dit_bind(icv_dit* d, const char* name, int64_t layer, const v
   if (layer >= 0) {
     ICV_REQUIRE(layer < (int64_t)d->layers.size(), "icv_dit_bind: layer %lld out of range", (long long)layer);
     Layer& L = d->layers[(size_t)layer];
-#define BINDV(F) if (n == #F) { L.F = ptr; return 0; }
+#define BINDW(F) if (n == #F) { L.F.w = ptr; return 0; } if (n == #F "_s") { L.F.s = (const float*)ptr; return 0; }
 #define BINDF(F) if (n == #F) { L.F = (const float*)ptr; return 0; }
-    BINDV(wqkv) BINDV(wo) BINDV(xq_w) BINDV(xo_w) BINDV(f0_w) BINDV(f2_w)
+    BINDW(wqkv) BINDW(wo) BINDW(xq_w) BINDW(xo_w) BINDW(f0_w) BINDW(f2_w)
     BINDF(bqkv) BINDF(nq) BINDF(nk) BINDF(bo) BINDF(n3w) BINDF(n3b) BINDF(xq_b) BINDF(xnq) BINDF(xo_b) BINDF(f0_b) BINDF(f2_b)
-#undef BINDV
+#undef BINDW
 #undef BINDF
     icv_set_error("icv_dit_bind: unknown per-layer tensor '%s'", name);
     return 1;
@@ -83,9 +113,44 @@ extern "C" int icv_dit_bind(icv_dit* d, const char* name, int64_t layer, const v
 #define BINDG(F, T) if (n == #F) { d->F = (T)ptr; return 0; }
   BINDG(patch_w, const void*) BINDG(head_w, const void*) BINDG(patch_b, const float*) BINDG(head_b, const float*) BINDG(rope, const float*)
   BINDG(x, float*) BINDG(x_stem, float*) BINDG(h, void*) BINDG(qkv, void*) BINDG(att, void*) BINDG(ff, void*) BINDG(patches, void*)
+  BINDG(h8, void*) BINDG(att8, void*) BINDG(ff8, void*) BINDG(h8s, float*) BINDG(att8s, float*) BINDG(ff8s, float*)
+  BINDG(a8_qq, void*) BINDG(a8_kq, void*) BINDG(a8_vt, void*) BINDG(a8_amax, float*)
+  BINDG(kv_loc, void*) BINDG(kv_full, void*) BINDG(sp_acc, float*) BINDG(sp_ml, float*)
 #undef BINDG
   icv_set_error("icv_dit_bind: unknown tensor '%s'", name);
   return 1;
+}
+
+extern "C" int icv_dit_set_fp8(icv_dit* d, int attn_fp8) {
+  ICV_REQUIRE(d, "icv_dit_set_fp8: null context");
+  d->attn_fp8 = attn_fp8 != 0;
+  return 0;
+}
+
+extern "C" int icv_dit_set_seqpar(icv_dit* d, icv_comm* comm, int64_t world, int64_t n_chunks, const int64_t* bounds, void* side_stream) {
+  ICV_REQUIRE(d, "icv_dit_set_seqpar: null context");
+  if (!comm) {                       // back to the single-rank schedule
+    d->comm = nullptr; d->world = 1; d->bounds.clear(); d->side = nullptr;
+    return 0;
+  }
+  ICV_REQUIRE(world >= 1 && n_chunks >= 1 && bounds && side_stream, "icv_dit_set_seqpar: world >= 1, n_chunks >= 1, bounds and a side stream are required");
+  ICV_REQUIRE(bounds[0] == 0 && bounds[n_chunks] == d->cfg.n_tok, "icv_dit_set_seqpar: bounds must run from 0 to n_tok");
+  for (int64_t c = 0; c < n_chunks; ++c) ICV_REQUIRE(bounds[c + 1] > bounds[c], "icv_dit_set_seqpar: empty chunk %lld", (long long)c);
+  d->comm = comm; d->world = world; d->side = (hipStream_t)side_stream;
+  d->bounds.assign(bounds, bounds + n_chunks + 1);
+  if (!d->ev_ready && hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming) != hipSuccess) {
+    icv_set_error("icv_dit_set_seqpar: hipEventCreate failed");
+    return 2;
+  }
+  while ((int64_t)d->ev_done.size() < n_chunks) {
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+      icv_set_error("icv_dit_set_seqpar: hipEventCreate failed");
+      return 2;
+    }
+    d->ev_done.push_back(e);
+  }
+  return 0;
 }
 
 #define ICV_HIP_CHECK(expr)                                                \

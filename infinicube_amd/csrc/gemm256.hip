@@ -392,16 +392,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
 
 template <int EPI, int MF, int SCH>
 int launch(const Params& p, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI, MF, SCH>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) {
-      icv_set_error("gemm256: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return 2;
-    }
-    attr_set = true;
-  }
+  static icv_dev_flags attr_set = {};
+  if (int rc = icv_ensure_dynamic_lds((const void*)gemm256_kernel<EPI, MF, SCH>, LDS_BYTES, &attr_set, "gemm256")) return rc;
   const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
   hipLaunchKernelGGL((gemm256_kernel<EPI, MF, SCH>), dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p);
   return icv_check_launch("icv_gemm_bf16(256)");

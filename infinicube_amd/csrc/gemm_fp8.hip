@@ -312,15 +312,8 @@ __global__ __launch_bounds__(512) void gemm_fp8_kernel(Params p) {
 
 template <int EPI, int SCH>
 int launch(const Params& p, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_fp8_kernel<EPI, SCH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) {
-      icv_set_error("icv_gemm_fp8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return 2;
-    }
-    attr_set = true;
-  }
+  static icv_dev_flags attr_set = {};
+  if (int rc = icv_ensure_dynamic_lds((const void*)gemm_fp8_kernel<EPI, SCH>, LDS_BYTES, &attr_set, "icv_gemm_fp8")) return rc;
   const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
   hipLaunchKernelGGL((gemm_fp8_kernel<EPI, SCH>), dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p);
   return icv_check_launch("icv_gemm_fp8");

@@ -21,6 +21,13 @@ void icv_set_error(const char* fmt, ...);
 int icv_check_launch(const char* what);
 int icv_get_option_int(const char* name, int dflt);  // runtime A/B switches (icv_set_option)
 
+// Kernels that need more than 64 KiB of dynamic LDS raise hipFuncAttributeMaxDynamicSharedMemorySize once.  The attribute
+// belongs to the (function, DEVICE) pair, so the "already done" flag is per device: a process that drives several GPUs
+// (one host thread per device, hipSetDevice before each call) gets it set on each of them.
+#define ICV_MAX_DEVICES 64
+struct icv_dev_flags { bool set[ICV_MAX_DEVICES]; };
+int icv_ensure_dynamic_lds(const void* func, int bytes, icv_dev_flags* flags, const char* what);
+
 #define ICV_REQUIRE(cond, ...)            \
   do {                                    \
     if (!(cond)) {                        \

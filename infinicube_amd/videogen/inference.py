@@ -10,6 +10,7 @@ tests/golden/boundary_trace.json, captured from the reference wrapper itself.
 
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -142,6 +143,8 @@ class WanVideoGenerator:
 
         print("Executing video generation...")
         if self._pool is not None:     # the other ranks run the same request on their token shards / CFG branch
+            if seed is None:           # unseeded call: ONE drawn seed for every rank (each would otherwise draw its own noise)
+                seed = int.from_bytes(os.urandom(7), "little")
             self._pool.generate(semantic_buffer, coordinate_buffer,
                                 dict(prompt=prompt, negative_prompt=negative_prompt, seed=seed, tiled=tiled), self.pipe)
         video = self.pipe(prompt=prompt, negative_prompt=negative_prompt, semantic_buffer_video=semantic_frames,

@@ -31,7 +31,8 @@ import numpy as np
 import torch
 
 # pipeline attributes rank 0 may have changed since construction; sent with every request so the ranks cannot drift
-_PIPE_SETTINGS = ("num_inference_steps", "cfg_scale", "sigma_shift", "parallelism", "sp_chunks", "kv_exchange")
+_PIPE_SETTINGS = ("num_inference_steps", "cfg_scale", "sigma_shift", "parallelism", "sp_chunks", "kv_exchange",
+                  "reference_rounding", "gemm_dtype", "attn_dtype")
 
 
 _ACTIVE_POOL = None   # the one WorkerPool of this process (the reference's caller keeps ONE generator per process)
@@ -85,6 +86,7 @@ class WorkerPool:
         import torch.distributed as dist
         self.world, self.dist, self.ctor_kwargs = world, dist, dict(ctor_kwargs)
         self._closed = True
+        self._ready = False          # set by the first wait_ready(): the workers then sit in their serve loop
         self.backend = backend or os.environ.get("ICV_DIST_BACKEND", "nccl")
         self.timeout_s = float(os.environ.get("ICV_WORLD_TIMEOUT_S", "3600"))
         port = _free_port()
@@ -139,14 +141,19 @@ class WorkerPool:
             time.sleep(0.2)
 
     def wait_ready(self):
-        """Every rank has built its generator (weights resident)."""
+        """Every rank has built its generator (weights resident).  A second generator built with the same arguments
+        reuses the pool (pool_for): its workers are already parked in their serve loop, where a barrier would pair with a
+        broadcast and hang, so only the first call synchronises."""
         self._check_alive()
+        if self._ready:
+            return
         try:
             work = self.dist.barrier(group=self.ctrl, async_op=True)
             while not work.is_completed():      # a worker that dies while loading must not cost the whole collective timeout
                 self._check_alive()
                 time.sleep(0.2)
             work.wait()
+            self._ready = True
         except RuntimeError as e:
             if "multi-GPU worker rank" not in str(e):
                 self._blame_dead_worker()       # prefer the dead worker's own log to the transport's error
@@ -155,6 +162,8 @@ class WorkerPool:
     def generate(self, semantic: np.ndarray, coordinate: np.ndarray, call_kwargs: dict, pipe) -> None:
         """Hand one request to the workers; the caller then runs its own share through ``pipe(...)``."""
         self._check_alive()
+        if call_kwargs.get("seed") is None:
+            raise ValueError("WorkerPool.generate: the caller resolves seed=None to one drawn integer for all ranks (WanVideoGenerator.generate does)")
         msg = dict(cmd="generate", shape=tuple(semantic.shape), call=call_kwargs,
                    settings={k: getattr(pipe, k) for k in _PIPE_SETTINGS if hasattr(pipe, k)})
         try:

@@ -323,10 +323,16 @@ class WanVideoPipeline:
             ctx_u = engine.encode_context(self.text_encoder.encode(negative_prompt), clip_fea)
         # noise: CPU generator, fp32 (rand_device='cpu' upstream) -> identical across devices/ranks
         g = torch.Generator(device="cpu")
-        if seed is not None:
-            g.manual_seed(int(seed))
-        else:
-            g.seed()     # upstream passes generator=None: a different noise on every unseeded call
+        if seed is None:
+            # upstream passes generator=None: a different noise on every unseeded call.  Under a multi-rank launch every
+            # rank must still draw the SAME noise (the ranks hold shards / CFG branches of one latent), so the seed is
+            # drawn once on rank 0 and broadcast.
+            seed = int.from_bytes(os.urandom(7), "little")
+            if world > 1:
+                box = [seed]
+                dist.broadcast_object_list(box, src=0)
+                seed = int(box[0])
+        g.manual_seed(int(seed))
         latent = torch.randn((1, 16) + grid.latent_shape()[1:], generator=g, dtype=torch.float32)[0]
         if self.reference_rounding:
             latent = latent.to(torch.bfloat16).to(torch.float32)

@@ -140,7 +140,7 @@ class KVGather:
                 raise ValueError(f"K/V exchange group has {len(self.peers)} ranks, the shard plan {plan.world}")
             self._native = None
             if self.mode == "native":
-                self._native = _NativeComm(dist, group, self.peers, plan.rank, plan.world)
+                self._native = _NativeComm.for_group(dist, group, self.peers, plan.rank, plan.world)
 
     def start(self, rows: torch.Tensor, out: torch.Tensor):
         if self.plan.world == 1:
@@ -175,7 +175,19 @@ class KVGather:
 
 
 class _NativeComm:
-    """libicvideo's own RCCL communicator for one sequence-parallel group + a side stream (KVGather mode "native")."""
+    """libicvideo's own RCCL communicator for one sequence-parallel group + a side stream (KVGather mode "native").
+    One per (process group, device) for the life of the process: a KVGather is rebuilt on every pipeline call, and
+    ncclCommInitRank is a blocking rendezvous of the whole group that must not be repeated per call."""
+
+    _cache = {}
+
+    @classmethod
+    def for_group(cls, dist, group, peers, rank: int, world: int) -> "_NativeComm":
+        key = (id(group) if group is not None else None, tuple(peers), torch.cuda.current_device())
+        comm = cls._cache.get(key)
+        if comm is None:
+            comm = cls._cache[key] = cls(dist, group, peers, rank, world)
+        return comm
 
     def __init__(self, dist, group, peers, rank: int, world: int):
         import ctypes
@@ -205,13 +217,21 @@ class _NativeComm:
         done.record(self.stream)
         return _EventWork(done)
 
-    def __del__(self):
-        h = getattr(self, "handle", None)
+    def close(self):
+        """Drain the side stream, then destroy the communicator (queued transfers must not outlive it)."""
+        h, self.handle = getattr(self, "handle", None), None
         if h is not None:
             try:
+                self.stream.synchronize()
                 self.lib.icv_comm_destroy(h)
             except Exception:  # pragma: no cover - interpreter shutdown
                 pass
+        for k, v in list(self._cache.items()):
+            if v is self:
+                del self._cache[k]
+
+    def __del__(self):
+        self.close()
 
 
 class _EventWork:

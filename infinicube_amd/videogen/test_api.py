@@ -12,6 +12,8 @@ installed, from .mp4 like the reference; `--synthetic` runs the same call path w
 from __future__ import annotations
 
 import argparse
+import os
+import sys
 import time
 
 import numpy as np
@@ -69,7 +71,12 @@ def main(argv=None):
         from . import synthetic as syn
         from .config import TokenGrid, preset
         from .pipeline import DiTHolder, WanVideoPipeline
-        from .standins import HashTextEncoder, PoolVAE
+        # --synthetic is a self-test mode: the stand-in text encoder / VAE are test infrastructure (tests/standins.py), not product code
+        tests_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests")
+        if not os.path.exists(os.path.join(tests_dir, "standins.py")):
+            ap.error("--synthetic needs the repository's tests/ directory (tests/standins.py)")
+        sys.path.insert(0, tests_dir)
+        from standins import HashTextEncoder, PoolVAE
         cfg = preset(args.model)
         grid = TokenGrid(args.frames, args.height, args.width)
         sd = syn.make_dit_state_dict(cfg, device="cuda:0", dtype=torch.bfloat16)

@@ -6,7 +6,7 @@ import torch
 from infinicube_amd.videogen import synthetic as syn
 from infinicube_amd.videogen.config import TokenGrid, preset
 from infinicube_amd.videogen.pipeline import DiTHolder, WanVideoPipeline
-from infinicube_amd.videogen.standins import HashTextEncoder, PoolVAE
+from standins import HashTextEncoder, PoolVAE
 from oracle_ops import OracleOps
 
 CFG, GRID = preset("tiny"), TokenGrid(9, 64, 96)
@@ -26,3 +26,12 @@ def failing_factory(torch_dtype, device, model_configs):
     if os.environ.get("ICV_WORKER_RANK") is not None:
         raise RuntimeError("synthetic worker failure while loading the checkpoint")
     return factory(torch_dtype, device, model_configs)
+
+
+def gpu_factory(torch_dtype, device, model_configs):
+    """The same tiny pipeline with the PRODUCT operator set on this rank's GPU (tests/test_multigpu_rccl.py: real RCCL ranks)."""
+    from infinicube_amd.videogen.ops import HipOps
+    dev = WanVideoPipeline.resolve_device(device)
+    pipe = WanVideoPipeline(dev, torch_dtype, DiTHolder(syn.make_dit_state_dict(CFG), CFG), HashTextEncoder(CFG), PoolVAE(), ops=HipOps(dev))
+    pipe.num_inference_steps = 2
+    return pipe

@@ -15,7 +15,7 @@ def frames_u8(latent, vae):
 
 def frame_psnr(lat_a, lat_b, vae=None):
     if vae is None:
-        from infinicube_amd.videogen.standins import PoolVAE
+        from standins import PoolVAE
         vae = PoolVAE()
     a, b = frames_u8(lat_a, vae).double(), frames_u8(lat_b, vae).double()
     mse = float(((a - b) ** 2).mean())

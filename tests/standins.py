@@ -12,7 +12,7 @@ import hashlib
 import torch
 import torch.nn.functional as F
 
-from .config import WanDiTConfig
+from infinicube_amd.videogen.config import WanDiTConfig
 
 
 class HashTextEncoder:

@@ -414,7 +414,7 @@ def test_generator_end_to_end_on_gpu(tmp_path, monkeypatch):
     import infinicube_amd.videogen.inference as inf
     from infinicube.videogen import WanVideoGenerator
     from infinicube_amd.videogen.pipeline import DiTHolder, WanVideoPipeline
-    from infinicube_amd.videogen.standins import HashTextEncoder, PoolVAE
+    from standins import HashTextEncoder, PoolVAE
     cfg, grid = preset("tiny"), TokenGrid(9, 64, 96)
     sd, bsd = syn.make_dit_state_dict(cfg), syn.make_buffer_embedder_state_dict(cfg)
     path = str(tmp_path / "step-1.safetensors")

@@ -197,7 +197,7 @@ def test_config2_wan_1p3b_93f_480p(hip_ops):
     from infinicube_amd.utils.buffer_utils import generate_coordinate_buffer_from_memory_global_norm
     from infinicube_amd.utils.semantic_utils import generate_rgb_semantic_buffer, semantic_to_color
     from infinicube_amd.videogen.pipeline import _video_to_tensor
-    from infinicube_amd.videogen.standins import PoolVAE
+    from standins import PoolVAE
     from PIL import Image
     cfg, grid = preset("1.3b"), GRID_480P
     from infinicube_amd.utils.voxel_render import render_voxel_buffers
@@ -307,7 +307,7 @@ def test_config3_wan_14b_four_step_loop_full_depth(hip_ops):
     to sigma 0 with CFG 5 (8 forwards of 40 layers), product loop (WanDiT.denoise) vs oracle/wan_ref.denoise_loop run in
     fp32 by stock PyTorch on the GPU on the same bf16-rounded weights.  Bar: final-latent PSNR >= 40 dB (north star) and
     decoded-frame PSNR >= 40 dB through the same pooling VAE on both arms."""
-    from infinicube_amd.videogen.standins import PoolVAE
+    from standins import PoolVAE
     cfg, grid, steps = preset("14b"), GRID_480P, 4
     sd = syn.make_dit_state_dict(cfg, seed=0, device=DEV, dtype=torch.bfloat16)
     bsd = syn.make_buffer_embedder_state_dict(cfg, device=DEV, dtype=torch.bfloat16)

@@ -16,7 +16,7 @@ from infinicube.videogen import WanVideoGenerator
 from infinicube_amd.videogen import synthetic as syn
 from infinicube_amd.videogen.config import TokenGrid, preset
 from infinicube_amd.videogen.pipeline import BufferEmbedder, DiTHolder, ModelConfig, WanVideoPipeline
-from infinicube_amd.videogen.standins import HashTextEncoder, PoolVAE
+from standins import HashTextEncoder, PoolVAE
 from oracle_ops import OracleOps
 
 CFG, GRID = preset("tiny"), TokenGrid(5, 64, 96)
@@ -119,7 +119,7 @@ def test_image_to_video_pipeline_branch():
     """BASELINE.json config #5 plumbing: an i2v DiT (in_dim 36 + CLIP branch) through the pipeline's extra
     ``input_image=`` keyword — the image must change the result, and misuse must fail loudly."""
     from PIL import Image
-    from infinicube_amd.videogen.standins import HashImageEncoder
+    from standins import HashImageEncoder
     cfg = preset("tiny-i2v")
     sd = syn.make_dit_state_dict(cfg)
     pipe = WanVideoPipeline("cpu", torch.bfloat16, DiTHolder(sd), HashTextEncoder(cfg), PoolVAE(), ops=OracleOps(),

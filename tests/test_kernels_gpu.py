@@ -324,7 +324,7 @@ def test_attention2_variants(hip_ops, variant):
         hip_ops.lib.icv_set_option(b"attn2_variant", 12); hip_ops.lib.icv_set_option(b"attn_kernel", ATTN_DEFAULT)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 4, 5, 6, 7, 8, 32, 64])
+@pytest.mark.parametrize("variant", [0, 1, 4, 5, 6, 7, 8, 32, 128])
 def test_attention7_variants(hip_ops, variant):
     """attn7.hip (LDS-DMA ring + lazy max + persistent reference vector) at the generic scale; the unit-scale route is
     covered by test_attention_unit_scale[kernel 7]."""
@@ -345,6 +345,46 @@ def test_attention7_variants(hip_ops, variant):
             assert_bf16_close(o, ref, f"attn7 variant {variant} Sq={Sq} Skv={Skv}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
     finally:
         hip_ops.lib.icv_set_option(b"attn_kernel", ATTN_DEFAULT); hip_ops.lib.icv_set_option(b"attn7_variant", 0)
+
+
+@pytest.mark.parametrize("unit", [0, 1])
+def test_attention7_short_key_shape(hip_ops, unit):
+    """The short-key launch shape of attn7 (4-wave blocks of 128 query rows on a two-stage ring, two blocks per CU; the
+    cross-attention route): plain, summed-into-output (i2v image branch) and carried-state calls, generic and unit
+    scale, ragged query / key counts incl. the 512-key and 257-key cross-attention sizes.  Forced for EVERY key count
+    here with "attn7_short" so that multi-tile rings (9+ tiles) are exercised too."""
+    H = 2
+    d = H * 128
+    fold = (1.0 / math.sqrt(128)) * math.log2(math.e)
+    scale = math.log(2.0) if unit else 1.0 / math.sqrt(128)
+    hip_ops.lib.icv_set_option(b"attn_kernel", ATTN_DEFAULT); hip_ops.lib.icv_set_option(b"attn7_short", 1 << 30)
+    try:
+        for Sq, Skv in ((300, 512), (129, 257), (128, 64), (1, 1), (513, 640), (1000, 1100), (257, 65)):
+            q, kf, v = (rnd((Sq, d), 291).to(torch.bfloat16), rnd((Skv, d), 292), rnd((Skv, d), 293).to(torch.bfloat16))
+            kf[Skv - 1] = q[min(3, Sq - 1)].float() * 5.0
+            kf[Skv // 2] = q[min(40, Sq - 1)].float() * 5.0
+            k = (kf * fold).to(torch.bfloat16) if unit else kf.to(torch.bfloat16)
+            ref = R.attention(q.float(), k.float(), v.float(), H, scale=scale)
+            qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+            o = torch.zeros((Sq, d), dtype=torch.bfloat16, device=DEV)
+            hip_ops.attention(qd, kd, vd, o, H, scale)
+            o2 = torch.zeros_like(o)
+            hip_ops.attention(qd, kd, vd, o2, H, scale)
+            assert torch.equal(o, o2), "non-deterministic attention output (LDS-DMA ring race?)"
+            assert_bf16_close(o, ref, f"attn7 short shape unit={unit} Sq={Sq} Skv={Skv}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
+            base = rnd((Sq, d), 294).to(torch.bfloat16)
+            o3 = base.clone().to(DEV)
+            hip_ops.attention_add(qd, kd, vd, o3, H, scale)
+            assert_bf16_close(o3, base.float() + ref, f"attn7 short shape add Sq={Sq} Skv={Skv}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -6)
+            if Skv >= 2:
+                acc = torch.empty((Sq, d), device=DEV); ml = torch.empty((Sq, H, 2), device=DEV)
+                o4 = torch.zeros_like(o)
+                cut = max(1, Skv // 3)
+                hip_ops.attention_chunk(qd, kd[:cut], vd[:cut], o4, acc, ml, H, scale, first=True, last=False)
+                hip_ops.attention_chunk(qd, kd[cut:], vd[cut:], o4, acc, ml, H, scale, first=False, last=True)
+                assert_bf16_close(o4, ref, f"attn7 short shape chunked Sq={Sq} Skv={Skv}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
+    finally:
+        hip_ops.lib.icv_set_option(b"attn7_short", -1)
 
 
 @pytest.mark.parametrize("variant", [0, 4])

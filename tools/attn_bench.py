@@ -5,9 +5,10 @@ import torch
 from infinicube_amd.videogen.ops import HipOps
 
 ops = HipOps("cuda:0")
-cases = [("1.3b self", 37440, 37440, 12), ("14b self", 37440, 37440, 40), ("sp8 14b", 4680, 37440, 40), ("14b cross", 37440, 512, 40)]
+cases = [("1.3b self", 37440, 37440, 12), ("14b self", 37440, 37440, 40), ("sp8 14b", 4680, 37440, 40), ("sp4 14b", 9360, 37440, 40),
+         ("14b cross", 37440, 512, 40), ("14b ximg", 37440, 257, 40), ("sp4 cross", 9360, 512, 40)]
 if len(sys.argv) > 1:
-    cases = [c for c in cases if c[0].startswith(sys.argv[1])]
+    cases = [c for c in cases if any(c[0].startswith(a) for a in sys.argv[1:])]
 n = int(os.environ.get("ATTN_ITERS", "3"))
 if os.environ.get("ATTN_ACC"):
     # accuracy of the kernel vs fp64 attention on a moderately long sequence, per defer-max threshold
@@ -44,8 +45,11 @@ for name, Sq, Skv, H in cases:
     for rd in range(rounds):           # interleaved rounds: within-process A/B
         for vv in variants:
             # variant codes: <100 -> attn.hip variant; 1000+x -> attn2.hip variant x
+            ops.lib.icv_set_option(b"attn7_short", 0)
             if vv >= 9000:
                 ops.lib.icv_set_option(b"attn_kernel", 9); ops.lib.icv_set_option(b"attn9_variant", vv - 9000)
+            elif vv >= 8000:   # attn7 variant x on the short-key launch shape (4-wave blocks, two per CU)
+                ops.lib.icv_set_option(b"attn_kernel", 7); ops.lib.icv_set_option(b"attn7_variant", vv - 8000); ops.lib.icv_set_option(b"attn7_short", 1 << 30)
             elif vv >= 7000:
                 ops.lib.icv_set_option(b"attn_kernel", 7); ops.lib.icv_set_option(b"attn7_variant", vv - 7000)
             elif vv >= 6000:
@@ -72,6 +76,7 @@ for name, Sq, Skv, H in cases:
     print(f"{name:10s} Sq={Sq} Skv={Skv} H={H}: " + " | ".join(
         f"v{vv}: {fl / sorted(best[vv])[len(best[vv]) // 2] / 1e9:6.1f} TF (min {min(best[vv]):.3f} ms)" for vv in variants))
 ops.lib.icv_set_option(b"attn_variant", 5); ops.lib.icv_set_option(b"attn_kernel", 7); ops.lib.icv_set_option(b"attn2_variant", 12)
+ops.lib.icv_set_option(b"attn7_short", -1); ops.lib.icv_set_option(b"attn7_variant", 0)
 
 # cost of splitting one self-attention over C key chunks with carried state (sequence-parallel path)
 if os.environ.get("ATTN_CHUNKS"):
