@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define ICV_ABI_VERSION 1
+/* 2: icv_unpatchify_cfg_euler gained `round_bf16` (a signature change a host built against 1 cannot detect otherwise);
+ *    icv_dit_set_fp8 / icv_dit_set_seqpar and the e4m3 / sequence-parallel bind names were added. */
+#define ICV_ABI_VERSION 2
 
 /* ---- library / device ------------------------------------------------------------------ */
 int icv_abi_version(void);
@@ -246,13 +248,26 @@ int icv_voxel_raycast(const int* vol, const unsigned char* bricks, const int* di
 /* ---- context-style driver: the whole DiT forward of a token shard in ONE call (SURVEY §8b B-native) ----------------
  * Replaces one `WanModel.forward` of the diffsynth fork reached from `self.pipe(...)`
  * [R infinicube/videogen/inference.py:216-226] for a host that does not drive the per-op entry points itself; it calls
- * exactly those launchers in the order infinicube_amd/videogen/dit.py does (bit-identical results).  bf16 single-rank
- * path (t2v and i2v).  Every tensor is BORROWED: `icv_dit_bind` records a device pointer, nothing is copied or owned.
+ * exactly those launchers in the order infinicube_amd/videogen/dit.py does (bit-identical results), in every mode of that
+ * driver: bf16 or e4m3 projections / self-attention, t2v or i2v, one rank or the sequence-parallel schedule.
+ * Every tensor is BORROWED: `icv_dit_bind` records a device pointer, nothing is copied or owned.
  *   per-layer names (layer >= 0): wqkv [3d,d] bf16, bqkv f32 [3d], nq / nk f32 [d] (nk carries the folded softmax scale),
  *     wo, bo, n3w, n3b, xq_w, xq_b, xnq, xo_w, xo_b, f0_w [ffn,d], f0_b, f2_w [d,ffn], f2_b;
+ *     e4m3 projections (config #5): bind the e4m3 rows under the weight's name AND its f32 per-output-row scales under
+ *     "<name>_s" (wqkv_s, wo_s, xq_w_s, xo_w_s, f0_w_s, f2_w_s) — a weight with scales is taken as e4m3, any subset may be;
  *   global names (layer = -1): patch_w bf16 [d,k_patch], patch_b, head_w bf16 [out_cols,d], head_b, rope (f32 table of
  *     ops.RopeTable), workspace x f32 [n,d], x_stem f32 [n,d] (optional), h bf16 [n,d], qkv bf16 [3,n,d], att bf16 [n,d],
- *     ff bf16 [n,ffn], patches bf16 [n,k_patch].
+ *     ff bf16 [n,ffn], patches bf16 [n,k_patch];
+ *     e4m3 projections: h8 / att8 e4m3 [n,d], ff8 e4m3 [n,ffn] and their row scales h8s / att8s / ff8s f32 [n];
+ *     e4m3 self-attention (icv_dit_set_fp8): a8_qq e4m3 [n,d], a8_kq e4m3 [kv_rows,d], a8_vt (icv_attention_fp8_vt_bytes),
+ *     a8_amax f32 [3,heads];
+ *     sequence-parallel (icv_dit_set_seqpar): kv_loc bf16 [n,2d] (row = k | v), kv_full bf16 [world*n,2d] (chunk-major,
+ *     rank-major inside), sp_acc f32 [n,d], sp_ml f32 [n,heads,2].
+ * icv_dit_set_fp8: attn_fp8 != 0 routes self-attention through the e4m3 kernels (cross-attention stays bf16).
+ * icv_dit_set_seqpar: this context's shard is one of `world` token shards; per layer the K|V rows [bounds[c], bounds[c+1])
+ *   of every rank are exchanged with icv_allgather_kv on `comm`, enqueued on `side_stream` (a hipStream_t the caller owns)
+ *   and fenced against the launch stream with events the context owns, and attention consumes the chunks in order with
+ *   carried softmax state (icv_attention_fwd_chunk).  comm == NULL returns to the single-rank schedule.
  * icv_dit_forward: latent f32 [C,T,H8,W8]; mod f32 [layers,6d] and hmod f32 [2,d] = this step's modulation tables;
  *   ctx_k / ctx_v bf16 [ctx_len, d] of layer 0, layer i at + i * ctx_layer_stride elements (text K/V cache); img_k / img_v
  *   likewise with img_len / img_layer_stride, or NULL; buf_tokens f32
@@ -269,6 +284,9 @@ typedef struct {
 int icv_dit_create(const icv_dit_config* cfg, icv_dit** out);
 void icv_dit_destroy(icv_dit* ctx);
 int icv_dit_bind(icv_dit* ctx, const char* name, int64_t layer, const void* device_ptr);
+typedef struct icv_comm icv_comm;
+int icv_dit_set_fp8(icv_dit* ctx, int attn_fp8);
+int icv_dit_set_seqpar(icv_dit* ctx, icv_comm* comm, int64_t world, int64_t n_chunks, const int64_t* bounds, void* side_stream);
 int icv_dit_forward(icv_dit* ctx, const float* latent, int64_t C, int64_t H8, int64_t W8, const float* mod,
                     const float* hmod, const void* ctx_k, const void* ctx_v, int64_t ctx_len,
                     int64_t ctx_layer_stride, const void* img_k, const void* img_v, int64_t img_len,
@@ -289,7 +307,6 @@ int icv_dit_profile_read(icv_dit* ctx, double* total_ms, int64_t* launches);
  * the host ships its ICV_COMM_ID_BYTES to the other ranks, every rank creates its communicator on its CURRENT device.
  * icv_allgather_kv: rows [m, row_bytes] of every rank -> out [world * m, row_bytes], rank-major, enqueued on `stream`. */
 #define ICV_COMM_ID_BYTES 128
-typedef struct icv_comm icv_comm;
 int icv_comm_unique_id(char* id);
 int icv_comm_create(const char* id, int rank, int world, icv_comm** out);
 void icv_comm_destroy(icv_comm* comm);

@@ -190,6 +190,48 @@ extern "C" int icv_dit_profile_read(icv_dit* d, double* total_ms, int64_t* launc
   return 0;
 }
 
+namespace {
+
+// K3 / K8: LayerNorm(+affine)(+modulate) of the residual stream into the A operand of the GEMM with weight W
+// (e4m3 rows + scales when that weight is quantised, bf16 otherwise) — dit.py WanDiT._norm
+int norm_into(icv_dit& D, const Wt& W, const float* weight, const float* bias, const float* shift, const float* scale, Act& out, void* stream) {
+  const icv_dit_config& c = D.cfg;
+  if (W.s) {
+    ICV_REQUIRE(D.h8 && D.h8s, "icv_dit_forward: bind h8 / h8s for the e4m3 projections");
+    DIT_CALL(icv_ln_modulate_fp8(D.x, c.dim, weight, bias, shift, scale, D.h8, c.dim, D.h8s, c.n_tok, c.dim, c.eps, stream));
+    out.p = D.h8; out.s = D.h8s;
+  } else {
+    DIT_CALL(icv_ln_modulate(D.x, c.dim, weight, bias, shift, scale, D.h, c.dim, c.n_tok, c.dim, c.eps, stream));
+    out.p = D.h; out.s = nullptr;
+  }
+  return 0;
+}
+
+// bf16 activation [n, K] produced by attention / the GELU epilogue -> A operand of the GEMM with weight W — WanDiT._operand
+int operand_of(icv_dit& D, const void* t, int64_t K, void* q8, float* s8, const Wt& W, Act& out, void* stream) {
+  if (W.s) {
+    ICV_REQUIRE(q8 && s8, "icv_dit_forward: bind att8 / att8s / ff8 / ff8s for the e4m3 projections");
+    DIT_CALL(icv_quantize_rows_fp8(t, 0, K, D.cfg.n_tok, K, q8, K, s8, stream));
+    out.p = q8; out.s = s8;
+  } else {
+    out.p = t; out.s = nullptr;
+  }
+  return 0;
+}
+
+// out = epilogue(a @ W[r0 : r0 + N].T + bias[r0 : r0 + N]) — WanDiT._mm
+int mm(icv_dit& D, const Act& a, const Wt& W, int64_t r0, int64_t N, int64_t K, const float* bias, void* out, int64_t ldo, int epi,
+       int64_t nsplit, int64_t sstride, const float* resid, const float* gate, void* stream) {
+  const int64_t n = D.cfg.n_tok;
+  ICV_REQUIRE((a.s != nullptr) == (W.s != nullptr), "icv_dit_forward: operand / weight dtype mismatch");
+  if (W.s)
+    return icv_gemm_fp8(a.p, K, a.s, (const char*)W.w + r0 * K, K, W.s + r0, bias + r0, n, N, K, epi, out, ldo, nsplit, sstride, resid,
+                        D.cfg.dim, gate, stream);
+  return icv_gemm_bf16(a.p, K, (const bf16_t*)W.w + r0 * K, K, bias + r0, n, N, K, epi, out, ldo, nsplit, sstride, resid, D.cfg.dim, gate, stream);
+}
+
+}  // namespace
+
 extern "C" int icv_dit_forward(icv_dit* dp, const float* latent, int64_t C, int64_t H8, int64_t W8, const float* mod,
                                const float* hmod, const void* ctx_k, const void* ctx_v, int64_t ctx_len,
                                int64_t ctx_layer_stride, const void* img_k, const void* img_v, int64_t img_len,
@@ -204,6 +246,9 @@ extern "C" int icv_dit_forward(icv_dit* dp, const float* latent, int64_t C, int6
               "icv_dit_forward: bind patch_w, patch_b, head_w, head_b, rope, x, h, qkv, att, ff, patches first");
   ICV_REQUIRE(stem >= 0 && stem <= 2 && (stem == 0 || D.x_stem), "icv_dit_forward: stem = 0 | 1 (save) | 2 (load); bind x_stem to use it");
   ICV_REQUIRE((img_k == nullptr) == (img_v == nullptr), "icv_dit_forward: image K and V go together");
+  const bool sp = D.comm != nullptr;
+  if (sp) ICV_REQUIRE(D.kv_loc && D.kv_full && D.sp_acc && D.sp_ml, "icv_dit_forward: bind kv_loc, kv_full, sp_acc, sp_ml for the sequence-parallel schedule");
+  if (D.attn_fp8) ICV_REQUIRE(D.a8_qq && D.a8_kq && D.a8_vt && D.a8_amax, "icv_dit_forward: bind a8_qq, a8_kq, a8_vt, a8_amax for e4m3 attention");
   hipStream_t st = (hipStream_t)stream;
   const bf16_t* qkv = (const bf16_t*)D.qkv;
   void* q = (void*)qkv;
@@ -223,25 +268,65 @@ extern "C" int icv_dit_forward(icv_dit* dp, const float* latent, int64_t C, int6
   }
   for (int64_t i = 0; i < L; ++i) {
     const Layer& W = D.layers[(size_t)i];
-    ICV_REQUIRE(W.wqkv && W.bqkv && W.nq && W.nk && W.wo && W.bo && W.n3w && W.n3b && W.xq_w && W.xq_b && W.xnq && W.xo_w && W.xo_b &&
-                W.f0_w && W.f0_b && W.f2_w && W.f2_b, "icv_dit_forward: layer %lld has unbound tensors", (long long)i);
+    ICV_REQUIRE(W.wqkv.w && W.bqkv && W.nq && W.nk && W.wo.w && W.bo && W.n3w && W.n3b && W.xq_w.w && W.xq_b && W.xnq && W.xo_w.w && W.xo_b &&
+                W.f0_w.w && W.f0_b && W.f2_w.w && W.f2_b, "icv_dit_forward: layer %lld has unbound tensors", (long long)i);
     const float* m = mod + i * 6 * d;
     const float *sh1 = m, *sc1 = m + d, *g1 = m + 2 * d, *sh2 = m + 3 * d, *sc2 = m + 4 * d, *g2 = m + 5 * d;
+    Act a;
     if (!(i == 0 && use_stem && stem == 2)) {
-      // self-attention: K3, K4 (one fused QKV GEMM, split planes), K5, K6, K7
-      DIT_CALL(icv_ln_modulate(D.x, d, nullptr, nullptr, sh1, sc1, D.h, d, n, d, c.eps, stream));
-      DIT_CALL(icv_gemm_bf16(D.h, d, W.wqkv, d, W.bqkv, n, 3 * d, d, ICV_EPI_BF16, D.qkv, d, d, n * d, nullptr, 0, nullptr, stream));
-      DIT_CALL(icv_rmsnorm_rope(q, W.nq, k, W.nk, d, n, d, c.eps, D.rope, c.T, c.Hp, c.Wp, c.tok0, stream));
       hipEvent_t e0 = nullptr, e1 = nullptr;
-      if (D.profile) {
+      if (D.profile && !sp) {
         e0 = D.next_event();
         e1 = D.next_event();
         ICV_REQUIRE(e0 && e1, "icv_dit_forward: hipEventCreate failed");
-        ICV_HIP_CHECK(hipEventRecord(e0, st));
       }
-      DIT_CALL(icv_attention_fwd(q, d, k, d, v, d, D.att, d, n, n, c.heads, attn_scale, stream));
-      if (D.profile) ICV_HIP_CHECK(hipEventRecord(e1, st));
-      DIT_CALL(icv_gemm_bf16(D.att, d, W.wo, d, W.bo, n, d, d, ICV_EPI_RESID_F32, D.x, d, d, 0, D.x, d, g1, stream));
+      DIT_CALL(norm_into(D, W.wqkv, nullptr, nullptr, sh1, sc1, a, stream));                                           // K3
+      if (sp) {
+        // K and V first, into ONE [n, 2d] matrix (row = k | v), so their exchange (K13) is moving while Q is projected
+        const int64_t nc = (int64_t)D.bounds.size() - 1;
+        bf16_t* kv_loc = (bf16_t*)D.kv_loc;
+        bf16_t* kv_full = (bf16_t*)D.kv_full;
+        DIT_CALL(mm(D, a, W.wqkv, d, 2 * d, d, W.bqkv, kv_loc, 2 * d, ICV_EPI_BF16, 2 * d, 0, nullptr, nullptr, stream));   // K4 (k | v rows)
+        DIT_CALL(icv_rmsnorm_rope(kv_loc, W.nk, nullptr, nullptr, 2 * d, n, d, c.eps, D.rope, c.T, c.Hp, c.Wp, c.tok0, stream));   // K5 (k)
+        ICV_HIP_CHECK(hipEventRecord(D.ev_ready, st));
+        ICV_HIP_CHECK(hipStreamWaitEvent(D.side, D.ev_ready, 0));
+        for (int64_t ch = 0; ch < nc; ++ch) {      // chunk = rows [r0, r1) of EVERY rank's shard, rank-major, on the side stream
+          const int64_t r0 = D.bounds[(size_t)ch], r1 = D.bounds[(size_t)ch + 1];
+          DIT_CALL(icv_allgather_kv(D.comm, kv_loc + r0 * 2 * d, kv_full + D.world * r0 * 2 * d, r1 - r0, 2 * d * (int64_t)sizeof(bf16_t), D.side));
+          ICV_HIP_CHECK(hipEventRecord(D.ev_done[(size_t)ch], D.side));
+        }
+        DIT_CALL(mm(D, a, W.wqkv, 0, d, d, W.bqkv, q, d, ICV_EPI_BF16, d, 0, nullptr, nullptr, stream));                // K4 (q)
+        DIT_CALL(icv_rmsnorm_rope(q, W.nq, nullptr, nullptr, d, n, d, c.eps, D.rope, c.T, c.Hp, c.Wp, c.tok0, stream));   // K5 (q)
+        if (D.attn_fp8)   // queries once per layer, under the first transfer
+          DIT_CALL(icv_attention_fp8_prepare(q, d, nullptr, 0, nullptr, 0, n, 0, c.heads, D.a8_qq, d, nullptr, d, nullptr, D.a8_amax, stream));
+        for (int64_t ch = 0; ch < nc; ++ch) {      // K6 pipelined with K13: consume chunk ch as soon as it has landed
+          const int64_t r0 = D.bounds[(size_t)ch], r1 = D.bounds[(size_t)ch + 1], rows = D.world * (r1 - r0);
+          const bf16_t* kc = kv_full + D.world * r0 * 2 * d;
+          ICV_HIP_CHECK(hipStreamWaitEvent(st, D.ev_done[(size_t)ch], 0));
+          if (D.attn_fp8) {
+            DIT_CALL(icv_attention_fp8_prepare(nullptr, 0, kc, 2 * d, kc + d, 2 * d, 0, rows, c.heads, nullptr, d, D.a8_kq, d, D.a8_vt, D.a8_amax, stream));
+            DIT_CALL(icv_attention_fp8_fwd_chunk(D.a8_qq, d, D.a8_kq, d, D.a8_vt, D.a8_amax, D.att, d, D.sp_acc, d, D.sp_ml, n, rows, c.heads,
+                                                 ch == 0, ch == nc - 1, stream));
+          } else {
+            DIT_CALL(icv_attention_fwd_chunk(q, d, kc, 2 * d, kc + d, 2 * d, D.att, d, D.sp_acc, d, D.sp_ml, n, rows, c.heads, attn_scale,
+                                             ch == 0, ch == nc - 1, stream));
+          }
+        }
+      } else {
+        // single rank: K4 (one fused QKV GEMM, split planes), K5, K6
+        DIT_CALL(mm(D, a, W.wqkv, 0, 3 * d, d, W.bqkv, D.qkv, d, ICV_EPI_BF16, d, n * d, nullptr, nullptr, stream));
+        DIT_CALL(icv_rmsnorm_rope(q, W.nq, k, W.nk, d, n, d, c.eps, D.rope, c.T, c.Hp, c.Wp, c.tok0, stream));
+        if (e0) ICV_HIP_CHECK(hipEventRecord(e0, st));
+        if (D.attn_fp8) {
+          DIT_CALL(icv_attention_fp8_prepare(q, d, k, d, v, d, n, n, c.heads, D.a8_qq, d, D.a8_kq, d, D.a8_vt, D.a8_amax, stream));
+          DIT_CALL(icv_attention_fp8_fwd(D.a8_qq, d, D.a8_kq, d, D.a8_vt, D.a8_amax, D.att, d, n, n, c.heads, stream));
+        } else {
+          DIT_CALL(icv_attention_fwd(q, d, k, d, v, d, D.att, d, n, n, c.heads, attn_scale, stream));
+        }
+        if (e1) ICV_HIP_CHECK(hipEventRecord(e1, st));
+      }
+      DIT_CALL(operand_of(D, D.att, d, D.att8, D.att8s, W.wo, a, stream));
+      DIT_CALL(mm(D, a, W.wo, 0, d, d, W.bo, D.x, d, ICV_EPI_RESID_F32, d, 0, D.x, g1, stream));                        // K7
       if (i == 0 && use_stem && stem == 1) {
         if (hipMemcpyAsync(D.x_stem, D.x, (size_t)n * d * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
           icv_set_error("icv_dit_forward: stem copy failed");
@@ -250,8 +335,8 @@ extern "C" int icv_dit_forward(icv_dit* dp, const float* latent, int64_t C, int6
       }
     }
     // cross-attention to the text (and, i2v, the image) tokens: K8, K9
-    DIT_CALL(icv_ln_modulate(D.x, d, W.n3w, W.n3b, nullptr, nullptr, D.h, d, n, d, c.eps, stream));
-    DIT_CALL(icv_gemm_bf16(D.h, d, W.xq_w, d, W.xq_b, n, d, d, ICV_EPI_BF16, q, d, d, 0, nullptr, 0, nullptr, stream));
+    DIT_CALL(norm_into(D, W.xq_w, W.n3w, W.n3b, nullptr, nullptr, a, stream));
+    DIT_CALL(mm(D, a, W.xq_w, 0, d, d, W.xq_b, q, d, ICV_EPI_BF16, d, 0, nullptr, nullptr, stream));
     DIT_CALL(icv_rmsnorm_rope(q, W.xnq, nullptr, nullptr, d, n, d, c.eps, nullptr, 0, 0, 0, 0, stream));
     const bf16_t* ck = (const bf16_t*)ctx_k + i * ctx_layer_stride;
     const bf16_t* cv = (const bf16_t*)ctx_v + i * ctx_layer_stride;
@@ -261,11 +346,13 @@ extern "C" int icv_dit_forward(icv_dit* dp, const float* latent, int64_t C, int6
       const bf16_t* iv = (const bf16_t*)img_v + i * img_layer_stride;
       DIT_CALL(icv_attention_fwd_add(q, d, ik, d, iv, d, D.att, d, n, img_len, c.heads, attn_scale, stream));
     }
-    DIT_CALL(icv_gemm_bf16(D.att, d, W.xo_w, d, W.xo_b, n, d, d, ICV_EPI_RESID_F32, D.x, d, d, 0, D.x, d, nullptr, stream));
+    DIT_CALL(operand_of(D, D.att, d, D.att8, D.att8s, W.xo_w, a, stream));
+    DIT_CALL(mm(D, a, W.xo_w, 0, d, d, W.xo_b, D.x, d, ICV_EPI_RESID_F32, d, 0, D.x, nullptr, stream));
     // FFN: K3, K10
-    DIT_CALL(icv_ln_modulate(D.x, d, nullptr, nullptr, sh2, sc2, D.h, d, n, d, c.eps, stream));
-    DIT_CALL(icv_gemm_bf16(D.h, d, W.f0_w, d, W.f0_b, n, c.ffn_dim, d, ICV_EPI_GELU_BF16, D.ff, c.ffn_dim, c.ffn_dim, 0, nullptr, 0, nullptr, stream));
-    DIT_CALL(icv_gemm_bf16(D.ff, c.ffn_dim, W.f2_w, c.ffn_dim, W.f2_b, n, d, c.ffn_dim, ICV_EPI_RESID_F32, D.x, d, d, 0, D.x, d, g2, stream));
+    DIT_CALL(norm_into(D, W.f0_w, nullptr, nullptr, sh2, sc2, a, stream));
+    DIT_CALL(mm(D, a, W.f0_w, 0, c.ffn_dim, d, W.f0_b, D.ff, c.ffn_dim, ICV_EPI_GELU_BF16, c.ffn_dim, 0, nullptr, nullptr, stream));
+    DIT_CALL(operand_of(D, D.ff, c.ffn_dim, D.ff8, D.ff8s, W.f2_w, a, stream));
+    DIT_CALL(mm(D, a, W.f2_w, 0, d, c.ffn_dim, W.f2_b, D.x, d, ICV_EPI_RESID_F32, d, 0, D.x, g2, stream));
   }
   // K11: head
   DIT_CALL(icv_ln_modulate(D.x, d, nullptr, nullptr, hmod, hmod + d, D.h, d, n, d, c.eps, stream));

@@ -68,6 +68,8 @@ SIGNATURES.update({
     "icv_dit_create": (c_int, [ctypes.POINTER(DitConfig), ctypes.POINTER(c_void_p)]),
     "icv_dit_destroy": (None, [c_void_p]),
     "icv_dit_bind": (c_int, [c_void_p, c_char_p, _I, _P]),
+    "icv_dit_set_fp8": (c_int, [c_void_p, c_int]),
+    "icv_dit_set_seqpar": (c_int, [c_void_p, c_void_p, _I, _I, ctypes.POINTER(c_int64), _P]),
     "icv_dit_forward": (c_int, [c_void_p, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P, _P, _I, c_int, _F, _P]),
     "icv_comm_unique_id": (c_int, [c_char_p]),
     "icv_comm_create": (c_int, [c_char_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
@@ -78,6 +80,7 @@ SIGNATURES.update({
 })
 
 COMM_ID_BYTES = 128   # ICV_COMM_ID_BYTES
+ABI_VERSION = 2       # ICV_ABI_VERSION of include/icvideo.h
 
 _lib: Optional[ctypes.CDLL] = None
 
@@ -107,8 +110,8 @@ def lib() -> ctypes.CDLL:
         fn.restype = res
         fn.argtypes = args
     got = l.icv_abi_version()
-    if got != 1:
-        raise NativeError(f"libicvideo ABI version {got}, binding expects 1")
+    if got != ABI_VERSION:
+        raise NativeError(f"libicvideo ABI version {got}, binding expects {ABI_VERSION} (rebuild with infinicube_amd/csrc/build.sh)")
     _lib = l
     return l
 

@@ -4,9 +4,17 @@
 [R infinicube/utils/buffer_utils.py:180-265]; the per-pixel work (unprojection with
 `unproject_depth_torch` [R infinicube/utils/depth_utils.py:402-466], camera-0 transform, normalisation,
 sky fill) runs in libicvideo's HIP kernels (csrc/buffers.hip) on the depth map resident in HBM.  Host-side
-PyTorch only does what the reference does on a handful of numbers: K^-1, pose_0^-1 pose_n, the random
-sample of <= 100000 finite points (same global-RNG `torch.randperm` call, so a seeded run matches the
-reference's sample) and `torch.quantile` on that sample.
+PyTorch only handles a handful of numbers: K^-1, pose_0^-1 pose_n and the two quantile vectors.
+
+The <= 100000-point sample the quantiles are taken on [R infinicube/utils/buffer_utils.py:236-241] is drawn
+  * ``sampling="device"`` (default): on the GPU — one jittered pick per stratum of the valid points (flattened
+    order), quantiles on the device.  The reference's own draw is UNSEEDED (`torch.randperm` on the global RNG,
+    [R infinicube/utils/buffer_utils.py:239-241]), so no caller can depend on a particular sample; what is
+    reproduced is the estimator (5 % / 95 % quantiles of <= 100000 of the finite points).  With <= 100000 finite
+    points the sample is all of them and the result equals the reference's bit for bit.
+  * ``sampling="reference"``: the reference's call for call — host `torch.randperm(n_valid)[:100000]` on the
+    global RNG and host `torch.quantile`, so a run seeded like the reference's reproduces its bytes (the golden
+    test).  At 93 x 480 x 832 that host permutation of 29 M indices costs ~1 s; the device path none of it.
 """
 from __future__ import annotations
 
@@ -24,10 +32,15 @@ def _f32_host(t: torch.Tensor):
 
 def generate_coordinate_buffer_from_memory_global_norm(depth_buffer: torch.Tensor, camera_model,
                                                        camera_poses: torch.Tensor, percentile: float = 0.05,
-                                                       *, device="cuda:0", return_uint8: bool = False):
+                                                       *, device="cuda:0", return_uint8: bool = False,
+                                                       sampling: str = "device", generator=None):
     """depth_buffer [N,H,W] metres (0 = infinitely far), camera_model with ``get_intrinsics_matrix()`` -> [3,3],
     camera_poses [N,4,4] camera-to-world  ->  [N,H,W,3] float32 in [0,1] (on ``device``), or with
-    ``return_uint8=True`` the uint8 buffer ``(coord * 255).astype(uint8)`` the video generator consumes."""
+    ``return_uint8=True`` the uint8 buffer ``(coord * 255).astype(uint8)`` the video generator consumes.
+    ``sampling``: "device" | "reference" (module docstring); ``generator``: optional device torch.Generator for the
+    device draw (default: the device's global generator)."""
+    if sampling not in ("device", "reference"):
+        raise ValueError(f"sampling must be 'device' or 'reference', got {sampling!r}")
     lib = native.lib()
     if not torch.cuda.is_available():
         raise native.NativeError("coordinate buffer: no GPU visible to PyTorch-ROCm; there is no CPU fallback")
@@ -49,15 +62,26 @@ def generate_coordinate_buffer_from_memory_global_norm(depth_buffer: torch.Tenso
     has_valid = int(valid_idx.numel() > 0)
     mins = ranges = None
     if has_valid:
-        pick = torch.randperm(valid_idx.numel())[:100000].to(dev)        # same global-RNG draw as the reference
-        sample_idx = valid_idx[pick].contiguous()
+        m = valid_idx.numel()
+        if sampling == "reference":
+            pick = torch.randperm(m)[:100000].to(dev)                    # same global-RNG draw as the reference
+        elif m <= 100000:
+            pick = None                                                   # every finite point: the reference's sample as a set
+        else:
+            # stratified draw on the device: stratum j = valid points [j m / k, (j+1) m / k), one uniformly jittered pick each
+            kk = 100000
+            edges = (torch.arange(kk + 1, dtype=torch.int64, device=dev) * m) // kk
+            u = torch.rand((kk,), device=dev, generator=generator, dtype=torch.float64)
+            pick = edges[:-1] + (u * (edges[1:] - edges[:-1]).to(torch.float64)).to(torch.int64).clamp_(max=m - 1)
+        sample_idx = (valid_idx if pick is None else valid_idx[pick]).contiguous()
         sample = torch.empty((sample_idx.numel(), 3), dtype=torch.float32, device=dev)
         native.check(lib.icv_coord_gather_points(depth.data_ptr(), kinv, to_cam0.data_ptr(), n, h, w,
                                                  sample_idx.data_ptr(), sample_idx.numel(), sample.data_ptr(), stream),
                      "icv_coord_gather_points")
-        # the two quantiles of <= 100000 x 3 numbers are taken on the host like the reference's CPU call: a device
-        # quantile interpolates with a different rounding, and the uint8 buffer has to match bit for bit
-        sample = sample.cpu()
+        if sampling == "reference" or pick is None:
+            # the two quantiles of <= 100000 x 3 numbers on the host like the reference's CPU call: a device quantile
+            # interpolates with a different rounding, and here the uint8 buffer has to match bit for bit
+            sample = sample.cpu()
         lo = torch.quantile(sample, percentile, dim=0)
         hi = torch.quantile(sample, 1 - percentile, dim=0)
         mins, ranges = _f32_host(lo), _f32_host(torch.clamp(hi - lo, min=1e-7))

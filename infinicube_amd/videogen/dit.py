@@ -221,7 +221,7 @@ class WanDiT:
     GRAPH_MAX_TOKENS = 8192   # graphs="auto": only sizes whose forward is made of many short kernels (cfg #1: S = 2240)
 
     def prepare(self, grid: TokenGrid, plan: Optional[ShardPlan] = None, kv_gather=None, sp_chunks: int = 4,
-                group=None, graphs=False, kv_exchange: Optional[str] = None):
+                group=None, graphs=False, kv_exchange: Optional[str] = None, force_sp: bool = False):
         """Allocate the per-generation workspace for this token grid / shard.  ``group`` = the process group the
         K/V all-gather runs in (seqpar.ParallelLayout.sp_group; None = the default group).
         ``graphs``: replay each DiT forward (its ~25 launches x L layers) as ONE hipGraph instead of issuing the
@@ -229,10 +229,13 @@ class WanDiT:
         env ICV_GRAPHS=0|1 overrides).  The time embedding and the fused Euler step take a per-step scalar by value
         and stay outside the graph.  Off by default: measured on MI355X the loop is not host-bound even at S = 400
         (10.7 us per launch eagerly AND replayed - the cost is the GPU-side dispatch of many tiny kernels), so replay
-        buys nothing today; it is kept, tested bit-identical, for hosts that are slower at issuing launches."""
+        buys nothing today; it is kept, tested bit-identical, for hosts that are slower at issuing launches.
+        ``force_sp`` (env ICV_FORCE_SP=1): run the sequence-parallel schedule even on ONE rank — K|V into the [n, 2d] row
+        matrix, a one-rank exchange, chunked attention with carried state: the one-GPU rehearsal of the N-GPU path."""
         cfg, ops = self.cfg, self.ops
         self.grid = grid
         self.plan = plan or ShardPlan.make(grid.S)
+        self.sp_on = self.plan.world > 1 or force_sp or os.environ.get("ICV_FORCE_SP", "0") == "1"
         if self.plan.S != grid.S:
             raise ValueError("shard plan does not match the token grid")
         n, d, S = self.plan.n_tok, cfg.dim, grid.S
@@ -246,7 +249,7 @@ class WanDiT:
         self.ff = a((n, cfg.ffn_dim), BF16)
         self.attn8_ws = None
         if self.attn_fp8:      # world > 1: the K/V side of the workspace holds one gathered chunk at a time
-            kv_rows = n if self.plan.world == 1 else self.plan.world * max(
+            kv_rows = n if not self.sp_on else self.plan.world * max(
                 b1 - b0 for b0, b1 in zip(chunk_bounds(n, sp_chunks)[:-1], chunk_bounds(n, sp_chunks)[1:]))
             self.attn8_ws = ops.attention_fp8_buffers(n, kv_rows, d, cfg.num_heads)
         self.h8 = self.h8s = self.att8 = self.att8s = self.ff8 = self.ff8s = None
@@ -269,15 +272,16 @@ class WanDiT:
             graphs = env == "1"
         if graphs == "auto":
             graphs = n <= self.GRAPH_MAX_TOKENS
-        self._graphs_on = bool(graphs) and self.plan.world == 1 and self._is_gpu()
+        self._graphs_on = bool(graphs) and not self.sp_on and self._is_gpu()
         self._graphs = {}
         # ICV_DUAL_STREAM=1: run the cond / uncond forwards of a step concurrently on two HIP streams (single-rank only).
         # Off by default: measured -5 % at 14B / 480p and neutral at 1.3B — two chip-filling kernels at once break the
         # XCD-local K/V and weight reuse of each other more than they fill each other's tail waves.
-        self.dual_stream = os.environ.get("ICV_DUAL_STREAM", "0") == "1" and self.plan.world == 1 and self._is_gpu()
+        self.dual_stream = os.environ.get("ICV_DUAL_STREAM", "0") == "1" and not self.sp_on and self._is_gpu()
         # ICV_NATIVE_FORWARD=1 / self.native_forward = True: one C call (icv_dit_forward) enqueues the whole forward instead of
-        # ~13 C-ABI calls per layer from Python — the same launchers in the same order, so bit-identical; available on the
-        # bf16 single-rank path.  Off by default: host issue time is 0.3 % of a 14B step either way.
+        # ~13 C-ABI calls per layer from Python — the same launchers in the same order, so bit-identical, in every mode (bf16 /
+        # e4m3, one rank / sequence-parallel with libicvideo's own RCCL communicator).  Off by default: host issue time is
+        # 0.3 % of a 14B step either way.
         self.native_forward = os.environ.get("ICV_NATIVE_FORWARD", "0") == "1"
         if getattr(self, "_native", None) is not None:      # a new workspace: the old context points at freed buffers
             self.ops.lib.icv_dit_destroy(self._native)
@@ -285,9 +289,9 @@ class WanDiT:
         # ICV_SHARE_STEM=0 switches off the sharing of the context-free stem between the two CFG forwards (A/B, tests)
         self.share_stem = os.environ.get("ICV_SHARE_STEM", "1") == "1"
         self._twin = None
-        if self.plan.world > 1:
+        if self.sp_on:
             self.kv_loc = a((n, 2 * d), BF16)                      # local k | v rows (one exchange moves both)
-            self.kv_full = a((S, 2 * d), BF16)                     # gathered rows (chunk-major, rank-major inside)
+            self.kv_full = a((self.plan.world * n, 2 * d), BF16)   # gathered rows (chunk-major, rank-major inside)
             self.sp_acc = a((n, d), F32)                           # carried O accumulator between key chunks
             self.sp_ml = a((n, cfg.num_heads, 2), F32)             # carried (running max, row sum)
             self.sp_bounds = chunk_bounds(n, sp_chunks)
@@ -316,14 +320,38 @@ class WanDiT:
             bind(name, getattr(self, name))
         bind("rope", self.rope.table)
         for i, lw in enumerate(self.layers):
-            for name in ("wqkv", "bqkv", "nq", "nk", "wo", "bo", "n3w", "n3b", "xq_w", "xq_b", "xnq", "xo_w", "xo_b", "f0_w", "f0_b", "f2_w", "f2_b"):
+            for name in ("bqkv", "nq", "nk", "bo", "n3w", "n3b", "xq_b", "xnq", "xo_b", "f0_b", "f2_b"):
                 bind(name, lw[name], i)
+            for name in self.FP8_WEIGHTS:          # bf16 rows, or e4m3 rows + per-output-row scales under "<name>_s"
+                w = lw[name]
+                if isinstance(w, tuple):
+                    bind(name, w[0], i)
+                    bind(name + "_s", w[1], i)
+                else:
+                    bind(name, w, i)
+        if self.fp8:
+            for name in ("h8", "h8s", "att8", "att8s", "ff8", "ff8s"):
+                bind(name, getattr(self, name))
+        if self.attn8_ws is not None:
+            for name, t in zip(("a8_qq", "a8_kq", "a8_vt", "a8_amax"), self.attn8_ws):
+                bind(name, t)
+            native.check(lib.icv_dit_set_fp8(h, 1), "icv_dit_set_fp8")
+        if self.sp_on:
+            from .seqpar import _NativeComm
+            kg = self.kv_gather
+            nc = getattr(kg, "_native", None)
+            if nc is None:     # the Python driver's exchange runs in torch.distributed: the C driver brings its own communicator
+                nc = _NativeComm.for_group(getattr(kg, "dist", None), kg.group, kg.peers, plan.rank, plan.world)
+            self._native_comm = nc                      # keep it (and its side stream) alive as long as the context
+            for name in ("kv_loc", "kv_full", "sp_acc", "sp_ml"):
+                bind(name, getattr(self, name))
+            b = (ctypes.c_int64 * len(self.sp_bounds))(*self.sp_bounds)
+            native.check(lib.icv_dit_set_seqpar(h, nc.handle, plan.world, len(self.sp_bounds) - 1, b, nc.stream.cuda_stream), "icv_dit_set_seqpar")
         self._native = h
         return h
 
     def _native_eligible(self) -> bool:
-        return (self.native_forward and self.plan.world == 1 and not self.fp8 and not self.attn_fp8 and self._is_gpu()
-                and hasattr(self.ops, "lib"))
+        return self.native_forward and self._is_gpu() and hasattr(self.ops, "lib") and (not self.sp_on or isinstance(self.kv_gather, KVGather))
 
     def native_profile(self, enable: bool):
         """Time every self-attention launch of the native forward with HIP events on the launch stream (bench.py)."""
@@ -550,7 +578,7 @@ class WanDiT:
             # --- self-attention ---
             if i == 0 and stem == "load":
                 pass                                                                        # taken from the cond forward
-            elif plan.world > 1:
+            elif self.sp_on:
                 h = self._norm(lw["wqkv"], shift=sh1, scale=sc1, eps=eps)                   # K3
                 # K and V first, so their all-gather (K13) is already moving while Q is projected
                 self._mm(h, lw["wqkv"], lw["bqkv"], self.kv_loc, EPI_BF16, rows=slice(d, 3 * d))            # K4 (k | v rows)

@@ -129,6 +129,8 @@ class KVGather:
             raise ValueError(f"K/V exchange mode must be one of {self.MODES}, got {self.mode!r}")
         self.timing = None          # bench: a list -> (event before wait, event after wait) per chunk = exposed transfer time
         self.n_collectives = 0
+        self._native = None
+        self.dist, self.peers = None, [0]
         if plan.world > 1:
             import torch.distributed as dist
             if not dist.is_initialized():
@@ -138,17 +140,17 @@ class KVGather:
             self.peers = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
             if len(self.peers) != plan.world:
                 raise ValueError(f"K/V exchange group has {len(self.peers)} ranks, the shard plan {plan.world}")
-            self._native = None
-            if self.mode == "native":
-                self._native = _NativeComm.for_group(dist, group, self.peers, plan.rank, plan.world)
+        if self.mode == "native":
+            self._native = _NativeComm.for_group(self.dist, group, self.peers, plan.rank, plan.world)
 
     def start(self, rows: torch.Tensor, out: torch.Tensor):
-        if self.plan.world == 1:
-            raise RuntimeError("KVGather used with world == 1 (attend over the local buffers directly)")
         assert rows.is_contiguous() and out.is_contiguous() and out.shape[0] == self.plan.world * rows.shape[0]
         self.n_collectives += 1
         if self.mode == "native":
             return (self._native.allgather(rows, out),)
+        if self.plan.world == 1:          # the one-rank rehearsal of the schedule (WanDiT.prepare(force_sp=True)): a local copy
+            out.copy_(rows)
+            return ()
         if self.mode == "allgather":
             return (self.dist.all_gather_into_tensor(out, rows, group=self.group, async_op=True),)
         m, dist = rows.shape[0], self.dist
@@ -197,11 +199,12 @@ class _NativeComm:
         idbuf = ctypes.create_string_buffer(native.COMM_ID_BYTES)
         if rank == 0:
             native.check(self.lib.icv_comm_unique_id(idbuf), "icv_comm_unique_id")
-        # ship the id through the existing process group (nccl groups move device tensors, gloo host tensors)
-        on_dev = dist.get_backend(group) == "nccl"
         t = torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8).clone()
-        t = t.to(dev) if on_dev else t
-        dist.broadcast(t, src=peers[0], group=group)
+        if world > 1:
+            # ship the id through the existing process group (nccl groups move device tensors, gloo host tensors)
+            on_dev = dist.get_backend(group) == "nccl"
+            t = t.to(dev) if on_dev else t
+            dist.broadcast(t, src=peers[0], group=group)
         h = ctypes.c_void_p()
         native.check(self.lib.icv_comm_create(bytes(t.cpu().tolist()), rank, world, ctypes.byref(h)), "icv_comm_create")
         self.handle = h

@@ -9,8 +9,30 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+EXPERIMENT_KERNELS = (1, 3, 4, 5, 6, 9)   # attention families under csrc/experiments/ (not in the shipped library)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "experiments: exercises only the A/B kernels under csrc/experiments/ (collected with ICV_EXPERIMENTS=1)")
+    config.addinivalue_line("markers", "experiment_kernels: parametrised over attention families; the experiments' cases are collected with ICV_EXPERIMENTS=1")
+
+
+def pytest_collection_modifyitems(config, items):
+    """The measured-slower A/B kernels are compiled only by `ICV_EXPERIMENTS=1 csrc/build.sh`; their tests are part of the
+    collection only under the same switch (ICV_EXPERIMENTS=1 ICV_LIB_PATH=.../libicvideo_experiments.so pytest -m gpu),
+    instead of showing up as dozens of skips in the default suite."""
+    if os.environ.get("ICV_EXPERIMENTS", "0") == "1":
+        return
+    keep, drop = [], []
+    for it in items:
+        exp = it.get_closest_marker("experiments") is not None
+        if it.get_closest_marker("experiment_kernels") is not None and hasattr(it, "callspec"):
+            exp = exp or it.callspec.params.get("kernel") in EXPERIMENT_KERNELS
+        (drop if exp else keep).append(it)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
 
 
 @pytest.fixture(scope="session")

@@ -441,11 +441,17 @@ def test_generator_end_to_end_on_gpu(tmp_path, monkeypatch):
     assert not np.array_equal(a1, a3), "guidance buffers must condition the output"
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny-i2v"])
-def test_native_forward_matches_python_driver(hip_ops, name):
+@pytest.mark.parametrize("name,mode", [("tiny", "bf16"), ("tiny-i2v", "bf16"), ("tiny", "fp8"), ("tiny-i2v", "fp8"),
+                                       ("tiny", "sp"), ("tiny", "sp-torch"), ("tiny-i2v", "sp+fp8")])
+def test_native_forward_matches_python_driver(hip_ops, name, mode):
     """icv_dit_create / icv_dit_bind / icv_dit_forward (the whole forward enqueued by ONE C call) against the per-op
     driver in dit.py: the same launchers in the same order, so the velocity tokens and a whole CFG denoise loop are
-    bit-identical, with and without the shared stem; binding errors are reported through the ABI."""
+    bit-identical, with and without the shared stem; binding errors are reported through the ABI.
+    Modes: bf16; fp8 = e4m3 projections (icv_dit_bind "<name>_s") + e4m3 self-attention (icv_dit_set_fp8); sp = the
+    sequence-parallel schedule (icv_dit_set_seqpar: K|V rows through icv_allgather_kv on libicvideo's own RCCL
+    communicator and side stream) rehearsed on ONE rank — the only RCCL world a 1-GPU box can build; the N-rank form runs
+    in tests/test_multigpu_rccl.py when the box has the GPUs; sp-torch = the Python arm exchanges through its local-copy
+    path while the C arm uses RCCL."""
     import ctypes
     from infinicube_amd import native
     cfg, grid = preset(name), TokenGrid(9, 64, 96)
@@ -454,11 +460,14 @@ def test_native_forward_matches_python_driver(hip_ops, name):
     bl = syn.make_buffer_latents(cfg, grid)
     clip = syn.make_clip_features(cfg) if cfg.has_image_input else None
     y = syn.make_cond_latents(cfg, grid) if cfg.has_image_input else None
+    fp8, sp = "fp8" in mode, mode.startswith("sp")
+    kw = dict(gemm_dtype="fp8", attn_dtype="fp8") if fp8 else {}
     outs = {}
     for native_on in (False, True):
-        m = WanDiT(cfg, sd, hip_ops, bsd).prepare(grid, graphs=False)
+        m = WanDiT(cfg, sd, hip_ops, bsd, **kw).prepare(grid, graphs=False, force_sp=sp, sp_chunks=3,
+                                                       kv_exchange=("allgather" if mode == "sp-torch" else "native") if sp else None)
         m.native_forward = native_on
-        assert m._native_eligible() == native_on
+        assert m._native_eligible() == native_on and m.sp_on == sp
         ck, cu = m.encode_context(c1, clip), m.encode_context(c2, clip)
         add = m.embed_buffers(bl)
         if y is not None:
@@ -470,7 +479,9 @@ def test_native_forward_matches_python_driver(hip_ops, name):
         m.denoise(lat, ck, cu, add, FlowMatchScheduler(3), 5.0)          # stem shared between the CFG forwards
         torch.cuda.synchronize()
         outs[native_on] = (one.cpu(), lat.cpu())
-        if native_on:
+        if sp and not native_on:
+            assert m.kv_gather.n_collectives > 0
+        if native_on and mode == "bf16":
             h = m._native_ctx()
             m.native_profile(True)                   # event pairs around the self-attention launches, read back as (ms, count)
             m.forward_tokens(lat, ck, 500.0, add, m.head_out[0])
@@ -481,8 +492,15 @@ def test_native_forward_matches_python_driver(hip_ops, name):
             assert hip_ops.lib.icv_dit_bind(h, b"no_such_tensor", -1, lat.data_ptr()) != 0
             assert b"unknown tensor" in hip_ops.lib.icv_last_error()
             assert hip_ops.lib.icv_dit_bind(h, b"wqkv", cfg.num_layers, lat.data_ptr()) != 0
+    assert torch.isfinite(outs[True][1]).all()
     assert torch.equal(outs[True][0], outs[False][0]), "icv_dit_forward differs from the per-op driver (one forward)"
     assert torch.equal(outs[True][1], outs[False][1]), "icv_dit_forward differs from the per-op driver (CFG loop, shared stem)"
+    if sp and not fp8:     # the rehearsed schedule against the plain single-rank one: chunked softmax merge order only
+        m = WanDiT(cfg, sd, hip_ops, bsd).prepare(grid, graphs=False)
+        lat = noise.clone().to("cuda:0")
+        m.denoise(lat, m.encode_context(c1, clip), m.encode_context(c2, clip), m.embed_buffers(bl), FlowMatchScheduler(3), 5.0)
+        ref = lat.cpu()
+        assert float((outs[True][1] - ref).norm() / ref.norm()) < 2e-3
     bad = native.DitConfig(dim=100, ffn_dim=64, heads=1, layers=1, n_tok=4, tok0=0, T=1, Hp=2, Wp=2, k_patch=64, out_cols=64, eps=1e-6)
     hh = ctypes.c_void_p()
     assert hip_ops.lib.icv_dit_create(ctypes.byref(bad), ctypes.byref(hh)) != 0

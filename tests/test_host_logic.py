@@ -223,6 +223,22 @@ def test_inprocess_two_shards_equal_unsharded(chunks, model, gemm_dtype):
     assert float((got - want).norm() / want.norm()) < (6e-2 if attn_dtype == "fp8" else 2e-3)
 
 
+def test_one_rank_rehearsal_of_the_sequence_parallel_schedule():
+    """prepare(force_sp=True): K|V into the [n, 2d] row matrix, a one-rank exchange, chunked attention with carried state —
+    the N-rank code path on one rank; equals the plain path to rounding (only the softmax merge order differs)."""
+    sd, bsd, noise, c1, c2, bl = _inputs()
+    lats = []
+    for force in (False, True):
+        m = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID, force_sp=force, sp_chunks=3)
+        assert m.sp_on == force and (m.kv_gather is not None) == force
+        lat = noise.clone()
+        m.denoise(lat, m.encode_context(c1), m.encode_context(c2), m.embed_buffers(bl), FlowMatchScheduler(3), 5.0)
+        lats.append(lat)
+        if force:
+            assert m.kv_gather.n_collectives == 3 * (2 * CFG.num_layers - 1) * 3   # 3 chunks x (2L - 1 shared-stem) layer passes x 3 steps
+    assert float((lats[0] - lats[1]).norm() / lats[0].norm()) < 1e-5
+
+
 def _sp_worker(rank, world, port, q, kv_exchange="allgather"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

@@ -259,6 +259,7 @@ def test_attention(hip_ops, Sq, Skv, H):
     assert_bf16_close(o, ref, f"attention Sq={Sq} Skv={Skv} H={H}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, 7])
 @pytest.mark.parametrize("thr", [0, 8])
 def test_attention_variants(hip_ops, variant, thr):
@@ -324,7 +325,7 @@ def test_attention2_variants(hip_ops, variant):
         hip_ops.lib.icv_set_option(b"attn2_variant", 12); hip_ops.lib.icv_set_option(b"attn_kernel", ATTN_DEFAULT)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 4, 5, 6, 7, 8, 32, 128])
+@pytest.mark.parametrize("variant", [0, 1, 4, 5, 6, 7, 8, 32, 128, 132])
 def test_attention7_variants(hip_ops, variant):
     """attn7.hip (LDS-DMA ring + lazy max + persistent reference vector) at the generic scale; the unit-scale route is
     covered by test_attention_unit_scale[kernel 7]."""
@@ -387,6 +388,7 @@ def test_attention7_short_key_shape(hip_ops, unit):
         hip_ops.lib.icv_set_option(b"attn7_short", -1)
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("variant", [0, 4])
 def test_attention9_variants(hip_ops, variant):
     """attn9.hip (QK^T of the next 32-key block in the same basic block as the softmax of the current one) at the
@@ -425,6 +427,7 @@ def test_attention9_variants(hip_ops, variant):
         hip_ops.lib.icv_set_option(b"attn_kernel", ATTN_DEFAULT); hip_ops.lib.icv_set_option(b"attn9_variant", 0)
 
 
+@pytest.mark.experiment_kernels
 @pytest.mark.parametrize("kernel,unit", [(2, 1), (2, 0), (7, 1), (7, 0), (9, 1), (9, 0)])
 def test_attention_unit_scale(hip_ops, kernel, unit):
     """scale * log2(e) == 1 (the DiT folds the softmax scale into K and calls with scale = ln 2): the kernel then
@@ -465,6 +468,7 @@ def test_attention_unit_scale(hip_ops, kernel, unit):
         hip_ops.lib.icv_set_option(b"attn_unit_scale", 1); hip_ops.lib.icv_set_option(b"attn_kernel", ATTN_DEFAULT)
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("variant", [0, 4])
 def test_attention3_variants(hip_ops, variant):
     """attn3.hip (one wave per SIMD, 64 query rows per wave, shared K/V fragments)."""
@@ -490,6 +494,7 @@ def test_attention3_variants(hip_ops, variant):
         hip_ops.lib.icv_set_option(b"attn3_variant", 0)
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("variant", [0, 1, 4, 5, 6, 7])
 def test_attention4_variants(hip_ops, variant):
     """attn4.hip (LDS-DMA staged 4-stage ring, counted vmcnt, optional stagger)."""
@@ -516,6 +521,7 @@ def test_attention4_variants(hip_ops, variant):
         hip_ops.lib.icv_set_option(b"attn4_variant", 4)
 
 
+@pytest.mark.experiments
 def test_attention5(hip_ops):
     """attn5.hip: one wave per SIMD, asm PV MFMAs with AGPR accumulators, asm LDS-DMA ring."""
     need_experiments(hip_ops)
@@ -539,6 +545,7 @@ def test_attention5(hip_ops):
         hip_ops.lib.icv_set_option(b"attn_kernel", ATTN_DEFAULT)
 
 
+@pytest.mark.experiment_kernels
 @pytest.mark.parametrize("kernel", [2, 3, 4, 5, 6, 7, 9])
 @pytest.mark.parametrize("chunks", [[700], [128, 572], [300, 100, 300], [64, 64, 64, 508]])
 def test_attention_chunked_state(hip_ops, chunks, kernel):
@@ -661,6 +668,7 @@ def test_error_reporting(hip_ops):
 # ---------------------------------------------------------------------------------------------------
 # edge cases: minimum / ragged sizes through every kernel family (tails, clamps, masks)
 # ---------------------------------------------------------------------------------------------------
+@pytest.mark.experiments
 @pytest.mark.parametrize("variant", [0, 1, 4, 5])
 def test_attention6_pingpong(hip_ops, variant):
     """attn6.hip (PV pipelined one tile behind QK^T, wave groups one phase apart): parity incl. ragged tails."""
@@ -681,6 +689,7 @@ def test_attention6_pingpong(hip_ops, variant):
         hip_ops.lib.icv_set_option(b"attn_kernel", ATTN_DEFAULT); hip_ops.lib.icv_set_option(b"attn6_variant", 5)
 
 
+@pytest.mark.experiment_kernels
 @pytest.mark.parametrize("kernel", [1, 2, 3, 4, 5, 6, 7, 9])
 def test_attention_minimum_sizes(hip_ops, kernel):
     if kernel in EXPERIMENT_KERNELS:
@@ -870,6 +879,7 @@ def test_attention_add_into_output(hip_ops, Sq, Skv, H):
 
 @pytest.mark.parametrize("M,N,K,epi", [(256, 256, 64, "f32"), (300, 512, 192, "f32"), (1000, 768, 1536, "bf16"), (513, 1024, 512, "gelu"),
                                        (640, 512, 1280, "resid"), (515, 768, 384, "split")])
+@pytest.mark.experiments
 @pytest.mark.parametrize("kernel", [3, 4])
 def test_gemm_4wave_variant(hip_ops, M, N, K, epi, kernel):
     """gemm256w.hip (option gemm256 = 3): 4 waves x 128x128 wave tiles, accumulators pinned to AGPRs, fragments read one

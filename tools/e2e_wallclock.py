@@ -53,11 +53,48 @@ print(f"setup (random weights, not part of the metric): {time.perf_counter() - t
 sem, co = syn.make_dummy_buffers(grid)
 marks = {}
 
+# ---- stage breakdown (T5, VAE encode x2, DiT loop, VAE decode, mp4 mux): each stage bracketed by a device synchronize
+stages = {}
+
+
+def _wrap(obj, name, label):
+    fn = getattr(obj, name)
+
+    def timed_fn(*a, **k):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        r = fn(*a, **k)
+        torch.cuda.synchronize(); stages[label] = stages.get(label, 0.0) + time.perf_counter() - t
+        return r
+
+    setattr(obj, name, timed_fn)
+
+
+_wrap(gen.pipe.text_encoder, "encode", "umt5_encode_x2_s")
+_wrap(gen.pipe.vae, "encode", "vae_encode_buffers_x2_s")
+_wrap(gen.pipe.vae, "decode", "vae_decode_s")
+from infinicube_amd.videogen import inference as _inf   # noqa: E402
+_save = _inf.save_video
+
+
+def _timed_save(*a, **k):
+    t = time.perf_counter()
+    _save(*a, **k)
+    stages["mp4_mux_s"] = stages.get("mp4_mux_s", 0.0) + time.perf_counter() - t
+
+
+_inf.save_video = _timed_save
+out_mp4 = os.path.join(tempfile.mkdtemp(), "out.mp4")
+
 
 def timed(label, n_steps):
     gen.pipe.num_inference_steps = n_steps
+    stages.clear()
+    eng = gen.pipe._get_engine()
+    if not getattr(eng, "_e2e_wrapped", False):
+        _wrap(eng, "denoise", "dit_loop_s")
+        eng._e2e_wrapped = True
     torch.cuda.synchronize(); t = time.perf_counter()
-    frames = gen.generate(semantic_buffer=sem, coordinate_buffer=co, seed=0, tiled=True)
+    frames = gen.generate(semantic_buffer=sem, coordinate_buffer=co, seed=0, tiled=True, output_path=out_mp4)
     torch.cuda.synchronize(); marks[label] = time.perf_counter() - t
     assert len(frames) == grid.num_frames and frames[0].size == (grid.width, grid.height)
     print(f"{label}: {marks[label]:.1f} s", flush=True)
@@ -69,5 +106,7 @@ out = {"model": cfg.name, "gemm_dtype": os.environ.get("GEMM", "bf16"), "frames"
        "steps": steps, "generate_wallclock_s": marks[f"generate() {steps} steps"],
        "first_call_2_steps_s": marks["first call, 2 steps (MIOpen search + first-use costs)"],
        "reference_published": "about 20 minutes on 1x A100, Wan2.1-14B, weight loading excluded [R README.md:65]",
-       "peak_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30}
+       "peak_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
+       "stages_s": dict(stages, other_host_s=marks[f"generate() {steps} steps"] - sum(stages.values())),
+       "mp4_bytes": os.path.getsize(out_mp4)}
 print(json.dumps(out))
