@@ -123,7 +123,8 @@ def read_tar_sample(path: Union[str, Path]) -> Dict:
 def write_video_file(frames, output_file: Union[str, Path], fps: int = 30, use_jiahui_params: bool = True) -> None:
     """frames: list of [H,W,3] uint8 | [N,H,W,3] array | dict index -> frame (or PNG bytes).  libx264 with the
     reference's parameter set through imageio's FFMPEG plugin when imageio is installed (the reference's
-    environment); otherwise the built-in Motion-JPEG muxer, announced on stdout (videogen/mp4mux.py)."""
+    environment); otherwise the built-in H.264 writer (videogen/h264pcm.py: same codec and container, intra PCM) or,
+    with ICV_MP4_CODEC=mjpeg, the Motion-JPEG muxer — announced on stdout (videogen/io.py write_video_without_ffmpeg)."""
     output_file = Path(output_file).as_posix()
     Path(output_file).parent.mkdir(parents=True, exist_ok=True)
     if not output_file.endswith(".mp4"):
@@ -138,10 +139,9 @@ def write_video_file(frames, output_file: Union[str, Path], fps: int = 30, use_j
     try:
         import imageio.v3 as iio
     except ImportError:
-        from ..videogen.mp4mux import write_mjpeg_mp4
-        print(f"  (imageio not installed: writing {output_file} as Motion-JPEG mp4 instead of libx264)")
+        from ..videogen.io import write_video_without_ffmpeg
         from PIL import Image
-        write_mjpeg_mp4([Image.fromarray(np.ascontiguousarray(f)).convert("RGB") for f in frames], output_file, fps=fps, quality=8)
+        write_video_without_ffmpeg([Image.fromarray(np.ascontiguousarray(f)).convert("RGB") for f in frames], output_file, fps=fps, quality=8)
         return
     iio.imwrite(output_file, frames, plugin="FFMPEG", fps=fps, codec="libx264",
                 output_params=X264_PARAMS if use_jiahui_params else [])

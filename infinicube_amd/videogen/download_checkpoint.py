@@ -1,12 +1,14 @@
-"""Checkpoint inventory for the video-generation stage (counterpart of the reference's download script).
+"""Checkpoint download + inventory for the video-generation stage (counterpart of the reference's download script).
 
 The reference instantiates a pipeline once so that diffsynth downloads six files into ``models/<model_id>/``
-[R infinicube/videogen/download_checkpoint.py:19-31; R README.md:33].  This build never downloads (the pipeline's
-``from_pretrained`` loads local files or raises), so the counterpart is an inventory: it lists the same six
-(model_id, file pattern) pairs, says which are present under the models root, and — for DiT shards that are
-present — which architecture their tensor shapes imply.
+[R infinicube/videogen/download_checkpoint.py:19-31; R README.md:33].  Run as a script this does the same: every
+one of the six (model_id, file pattern) pairs that is missing under the models root is fetched into that layout
+(``ModelConfig.download``: ModelScope when installed, as diffsynth defaults to, else the Hugging Face hub), then the
+inventory is printed — which entries are present and, with ``--inspect``, which architecture the DiT shards'
+tensor shapes imply.  ``--no-download`` prints the inventory only.  (The generator itself always passes
+``skip_download=True`` [R infinicube/videogen/inference.py:67-69] and never touches the network.)
 
-    python -m infinicube_amd.videogen.download_checkpoint [--models-root models] [--inspect]
+    python -m infinicube_amd.videogen.download_checkpoint [--models-root models] [--no-download] [--inspect]
 """
 
 from __future__ import annotations
@@ -44,7 +46,16 @@ def main(argv=None) -> int:
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("--models-root", default=os.environ.get("ICV_MODEL_ROOT", "models"))
     ap.add_argument("--inspect", action="store_true", help="read DiT shard headers and print the implied architecture")
+    ap.add_argument("--no-download", action="store_true", help="inventory only: do not fetch missing files")
     args = ap.parse_args(argv)
+    if not args.no_download:
+        for model_id, pattern, what in REQUIRED:
+            mc = ModelConfig(model_id=model_id, origin_file_pattern=pattern, local_model_path=args.models_root)
+            if not mc.present():
+                try:
+                    mc.download()
+                except Exception as e:   # no network / hub package: report and go on to the inventory
+                    print(f"  could not download {model_id}/{pattern} ({what}): {type(e).__name__}: {str(e).splitlines()[0] if str(e) else ''}")
     missing = 0
     for mc, what, files in inventory(args.models_root):
         mark = "ok     " if files else "MISSING"
@@ -58,8 +69,8 @@ def main(argv=None) -> int:
             print(f"          -> {cfg.name}: dim {cfg.dim}, ffn {cfg.ffn_dim}, {cfg.num_layers} layers, in_dim {cfg.in_dim}"
                   + (f", image branch ({cfg.img_dim})" if cfg.has_image_input else ""))
     if missing:
-        print(f"{missing} of {len(REQUIRED)} entries missing under {os.path.abspath(args.models_root)!r}. This build does not download: "
-              f"fetch them with the reference's script or `huggingface-cli download <model_id>` into that layout.")
+        print(f"{missing} of {len(REQUIRED)} entries missing under {os.path.abspath(args.models_root)!r}"
+              + (" (--no-download: nothing was fetched)." if args.no_download else "."))
     return 1 if missing else 0
 
 

@@ -55,15 +55,15 @@ def describe_checkpoint(path: str) -> Dict[str, Dict[str, tuple]]:
 def save_video(frames: List, save_path: str, fps: int = 10, quality: int = 8) -> None:
     """mp4 at ``save_path`` (stage 3 reads it back [R infinicube/inference/scene_gaussian_generation.py:290-293]).
     With imageio installed — it is part of the reference's environment — this is libx264 through imageio-ffmpeg,
-    like diffsynth's save_video.  Without it the file is written by the built-in Motion-JPEG muxer
-    (``mp4mux.write_mjpeg_mp4``: same container, fps and frame count, intra-only codec) and a line says so."""
+    like diffsynth's save_video.  Without it the file is written by the built-in H.264 writer (``h264pcm``: the same
+    codec and container, Constrained-Baseline IDR pictures of I_PCM macroblocks — lossless in 4:2:0, so ``quality`` has
+    nothing to act on and the file is large) and a line says so; ``ICV_MP4_CODEC=mjpeg`` selects the smaller
+    Motion-JPEG file of ``mp4mux`` instead."""
     os.makedirs(os.path.dirname(os.path.abspath(save_path)), exist_ok=True)
     try:
         import imageio
     except ImportError:
-        from .mp4mux import write_mjpeg_mp4
-        print(f"  (imageio not installed: writing {save_path} as Motion-JPEG mp4 instead of libx264)")
-        write_mjpeg_mp4(frames, save_path, fps=fps, quality=quality)
+        write_video_without_ffmpeg(frames, save_path, fps=fps, quality=quality)
         return
     import numpy as np
     writer = imageio.get_writer(save_path, fps=fps, quality=quality)
@@ -72,3 +72,19 @@ def save_video(frames: List, save_path: str, fps: int = 10, quality: int = 8) ->
             writer.append_data(np.asarray(fr))
     finally:
         writer.close()
+
+
+def write_video_without_ffmpeg(frames: List, save_path: str, fps: float = 10, quality: int = 8) -> str:
+    """The in-tree mp4 writers: H.264 (I_PCM, default) or Motion-JPEG (ICV_MP4_CODEC=mjpeg).  Returns the codec used."""
+    codec = os.environ.get("ICV_MP4_CODEC", "h264").lower()
+    if codec not in ("h264", "mjpeg"):
+        raise ValueError(f"ICV_MP4_CODEC must be 'h264' or 'mjpeg', got {codec!r}")
+    if codec == "mjpeg":
+        from .mp4mux import write_mjpeg_mp4
+        print(f"  (imageio not installed: writing {save_path} as Motion-JPEG mp4 instead of libx264)")
+        write_mjpeg_mp4(frames, save_path, fps=fps, quality=quality)
+    else:
+        from .h264pcm import write_h264_mp4
+        print(f"  (imageio not installed: writing {save_path} with the built-in H.264 writer (intra PCM, lossless 4:2:0) instead of libx264)")
+        write_h264_mp4(frames, save_path, fps=fps)
+    return codec

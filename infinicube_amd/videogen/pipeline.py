@@ -37,8 +37,11 @@ _IncompatibleKeys = namedtuple("_IncompatibleKeys", ["missing_keys", "unexpected
 
 class ModelConfig:
     """Where a model file lives: ``models/<model_id>/<origin_file_pattern>`` (diffsynth's layout,
-    [R README.md:33]) or an explicit ``path``.  ``skip_download`` is accepted and always honoured:
-    this implementation never downloads."""
+    [R README.md:33]) or an explicit ``path``.  ``skip_download=True`` (what the generator passes
+    [R infinicube/videogen/inference.py:67-69]) never touches the network; with ``skip_download=False`` (the
+    reference's download script [R infinicube/videogen/download_checkpoint.py:19-31]) a file that is missing locally is
+    fetched into that layout first (``download()``: ModelScope when importable, like diffsynth's default, else the
+    Hugging Face hub)."""
 
     def __init__(self, path=None, model_id: Optional[str] = None, origin_file_pattern: Optional[str] = None,
                  skip_download: bool = False, offload_device=None, offload_dtype=None, local_model_path: Optional[str] = None,
@@ -56,6 +59,36 @@ class ModelConfig:
             return self.path if isinstance(self.path, str) else self.path[0]
         root = self.local_model_path or os.environ.get("ICV_MODEL_ROOT", "models")
         return os.path.join(root, self.model_id or "", self.origin_file_pattern or "")
+
+    def present(self) -> bool:
+        import glob
+        return bool(glob.glob(self.resolve()))
+
+    def download(self) -> str:
+        """Fetch ``origin_file_pattern`` of ``model_id`` into ``<root>/<model_id>/`` (no-op when present or when the
+        config is an explicit path).  Raises with the hub's own error when the network or the hub package is missing."""
+        if self.path is not None or self.present():
+            return self.resolve()
+        root = self.local_model_path or os.environ.get("ICV_MODEL_ROOT", "models")
+        target = os.path.join(root, self.model_id)
+        os.makedirs(target, exist_ok=True)
+        source = os.environ.get("ICV_DOWNLOAD_SOURCE", "auto").lower()
+        fetch = None
+        if source in ("auto", "modelscope"):
+            try:
+                from modelscope import snapshot_download as ms_fetch
+                fetch = lambda: ms_fetch(self.model_id, allow_file_pattern=self.origin_file_pattern, local_dir=target)   # noqa: E731
+            except ImportError:
+                if source == "modelscope":
+                    raise
+        if fetch is None:
+            from huggingface_hub import snapshot_download as hf_fetch
+            fetch = lambda: hf_fetch(repo_id=self.model_id, allow_patterns=[self.origin_file_pattern], local_dir=target)   # noqa: E731
+        print(f"Downloading {self.model_id}/{self.origin_file_pattern} -> {target}")
+        fetch()
+        if not self.present():
+            raise FileNotFoundError(f"download of {self.model_id} finished but nothing matches {self.resolve()!r}")
+        return self.resolve()
 
     def __repr__(self):
         return f"ModelConfig(model_id={self.model_id!r}, origin_file_pattern={self.origin_file_pattern!r})"
@@ -193,8 +226,12 @@ class WanVideoPipeline:
     @classmethod
     def from_pretrained(cls, torch_dtype=torch.bfloat16, device="cuda", model_configs: Sequence[ModelConfig] = (),
                         tokenizer_config: Optional[ModelConfig] = None, **unused) -> "WanVideoPipeline":
-        """Load DiT / UMT5 / Wan-VAE from local files (never downloads).  Files are recognised by
-        name, like the reference's three patterns [R infinicube/videogen/inference.py:67-69]."""
+        """Load DiT / UMT5 / Wan-VAE from local files; a config built WITHOUT skip_download=True whose file is missing is
+        downloaded first (ModelConfig.download), as diffsynth does for the reference's download script.  Files are
+        recognised by name, like the reference's three patterns [R infinicube/videogen/inference.py:67-69]."""
+        for mc in model_configs:
+            if not getattr(mc, "skip_download", True) and mc.model_id and not mc.present():
+                mc.download()
         pipe = cls(device=device, torch_dtype=torch_dtype)
         # torch_dtype=float8_e4m3fn selects the DiT's fp8 MFMA mode only; the encoders outside the loop are stock
         # torch modules that cannot run on unscaled e4m3 weights, so they load in bf16

@@ -4,6 +4,7 @@ UMT5 / VAE components.  Checks the drop-in's observable behaviour: frame count/s
 determinism, that prompt / seed / buffers each change the result, checkpoint overlay semantics."""
 import contextlib
 import io
+import os
 import re
 
 import numpy as np
@@ -226,7 +227,45 @@ def test_checkpoint_inventory(tmp_path, capsys):
     keys = sorted(sd)
     save_file({k: sd[k].contiguous() for k in keys[: len(keys) // 2]}, str(d / "diffusion_pytorch_model-00001-of-00002.safetensors"))
     save_file({k: sd[k].contiguous() for k in keys[len(keys) // 2:]}, str(d / "diffusion_pytorch_model-00002-of-00002.safetensors"))
-    rc = dc.main(["--models-root", str(root), "--inspect"])
+    rc = dc.main(["--models-root", str(root), "--inspect", "--no-download"])
     out = capsys.readouterr().out
     assert rc == 1 and out.count("MISSING") == 5 and "2 file(s)" in out
     assert "in_dim 36, image branch (64)" in out
+
+
+def test_checkpoint_download_behaviour(tmp_path, capsys, monkeypatch):
+    """The reference's download script fetches what is missing [R infinicube/videogen/download_checkpoint.py:19-31]: missing
+    entries go through the hub's snapshot_download into models/<model_id>/ with the entry's file pattern; present ones are
+    left alone; a hub failure (no network) is reported and the inventory still printed; skip_download=True never fetches."""
+    import huggingface_hub
+    from infinicube_amd.videogen import download_checkpoint as dc
+    from infinicube_amd.videogen.pipeline import ModelConfig
+    monkeypatch.setenv("ICV_DOWNLOAD_SOURCE", "huggingface")
+    root = tmp_path / "models"
+    have = root / "Wan-AI" / "Wan2.1-T2V-14B"
+    have.mkdir(parents=True)
+    (have / "Wan2.1_VAE.pth").write_bytes(b"x")
+    calls = []
+
+    def fake(repo_id, allow_patterns, local_dir):
+        calls.append((repo_id, tuple(allow_patterns)))
+        if "I2V" in repo_id:
+            raise ConnectionError("no route to the hub")
+        os.makedirs(local_dir, exist_ok=True)
+        open(os.path.join(local_dir, allow_patterns[0].replace("*", "-00001-of-00001")), "wb").write(b"x")
+        return local_dir
+
+    monkeypatch.setattr(huggingface_hub, "snapshot_download", fake)
+    rc = dc.main(["--models-root", str(root)])
+    out = capsys.readouterr().out
+    assert ("Wan-AI/Wan2.1-T2V-14B", ("Wan2.1_VAE.pth",)) not in calls and len(calls) == 5
+    assert ("Wan-AI/Wan2.1-T2V-1.3B", ("diffusion_pytorch_model*.safetensors",)) in calls
+    assert out.count("could not download") == 2 and out.count("MISSING") == 2 and rc == 1
+    assert os.path.exists(root / "Wan-AI" / "Wan2.1-T2V-1.3B" / "diffusion_pytorch_model-00001-of-00001.safetensors")
+    calls.clear()
+    mc = ModelConfig(model_id="Wan-AI/Wan2.1-I2V-14B-480P", origin_file_pattern="diffusion_pytorch_model*.safetensors", skip_download=True,
+                     local_model_path=str(root))
+    with pytest.raises(FileNotFoundError):
+        from infinicube_amd.videogen.pipeline import WanVideoPipeline
+        WanVideoPipeline.from_pretrained(device="cpu", model_configs=[mc])
+    assert calls == []
