@@ -41,12 +41,19 @@ int icv_attn4_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, c
 // Kernel family selection (icv_set_option("attn_kernel", n)): 7 = attn7.hip (default: LDS-DMA ring + lazy max + unit
 // scale), 2 = attn2.hip, 3..6 = the experiments kept for A/B, 1 = experiments/attn1.hip (icv_attention_fwd only).
 constexpr int ATTN_KERNEL_DEFAULT = 7;
+constexpr int ATTN7_VARIANT_DEFAULT = 132;
 static int attn_route(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
                       int64_t ldo, float* acc, int64_t ldacc, float* ml, int state_in, int state_out, int64_t Sq,
                       int64_t Skv, int64_t heads, float scale, hipStream_t st) {
 #define ATT_ARGS q, ldq, k, ldk, v, ldv, o, ldo, acc, ldacc, ml, state_in, state_out, Sq, Skv, heads, scale
   switch (icv_get_option_int("attn_kernel", ATTN_KERNEL_DEFAULT)) {
-    case 7: return icv_attn7_dispatch(ATT_ARGS, icv_get_option_int("attn7_variant", 0), st);
+    case 7: {
+      // default variant 132 = 128-key publish (one vmcnt(0) + barrier per TWO key tiles) + s_setprio around the MFMA
+      // clusters: +1.4 % on the 37 440-key self-attention of both model sizes, neutral on the sequence-parallel shard
+      // shapes (same-process A/B, profiles/r03/attention_variants.md); a negative option value = this default
+      const int var7 = icv_get_option_int("attn7_variant", -1);
+      return icv_attn7_dispatch(ATT_ARGS, var7 < 0 ? ATTN7_VARIANT_DEFAULT : var7, st);
+    }
 #ifdef ICV_EXPERIMENTS
     case 9: return icv_attn9_dispatch(ATT_ARGS, icv_get_option_int("attn9_variant", 0), st);
     case 6: return icv_attn6_dispatch(ATT_ARGS, icv_get_option_int("attn6_variant", 5), st);

@@ -58,11 +58,19 @@ class ContextKV:
 
 class WanDiT:
     FP8_WEIGHTS = ("wqkv", "wo", "xq_w", "xo_w", "f0_w", "f2_w")
-    # Default e4m3 set of the fp8 mode: everything but FFN2.  Measured at the real 1.3B depth (config #1, 10 steps, vs the
-    # bf16 path; tools/fp8_subset_study.py): each FFN GEMM alone costs 43.3 dB, every other projection 52-57 dB; all six
-    # 39.8 dB (under the 40 dB bar), all but FFN2 42.6 dB.  FFN2 is the one to leave in bf16: its A operand (the GELU
-    # output, [S, ffn]) would need a separate quantise pass, FFN1's comes out of the LayerNorm kernel already in e4m3.
-    FP8_DEFAULT = ("wqkv", "wo", "xq_w", "xo_w", "f0_w")
+    # Default e4m3 set of the fp8 mode.  Every quantised GEMM adds ~3-5 % relative noise to its output (e4m3 has 3 mantissa
+    # bits), and which projections can afford it was measured at the REAL depths against the bf16 path (random-init weights,
+    # CFG 5; tools/fp8_subset_study.py):
+    #   1.3B (30 layers, 10 steps, profiles/r02/fp8_projection_subsets_psnr.txt): each FFN GEMM alone 43.3 dB, every other
+    #        projection 52-57 dB, all six 39.8 dB, all but FFN2 42.6 dB;
+    #   14B (40 layers, d = 5120, S = 37 440, 4-step loop, profiles/r03/fp8_projection_subsets_psnr_14b_depth.txt): e4m3
+    #        self-attention alone 47.1 dB, cross-q 46.4, cross-o 43.9, QKV 42.8 - but O 34.0, FFN1 30.8, FFN2 31.0 (their
+    #        outputs are added straight onto the residual stream, 40 layers deep), round 2's set (all but FFN2) 28.9 dB.
+    # The bar is >= 40 dB at the depth of the model that is run, so the default is the QKV projection (26 % of the GEMM flops)
+    # plus e4m3 self-attention (57 % of a bf16 step): asserted against the fp32 oracle at both depths
+    # (test_config1_*: 1.3B; test_config3_*_four_step_loop_full_depth: 14B).  ICV_FP8_WEIGHTS / fp8_weights= selects any other
+    # subset for a caller whose checkpoint tolerates more.
+    FP8_DEFAULT = ("wqkv",)
 
     def __init__(self, cfg: WanDiTConfig, state_dict: Dict[str, torch.Tensor], ops,
                  buffer_embedder_sd: Optional[Dict[str, torch.Tensor]] = None, gemm_dtype: str = "bf16",

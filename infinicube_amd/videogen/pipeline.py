@@ -195,8 +195,8 @@ class WanVideoPipeline:
         # projections (BASELINE.json config #5).  Anything else = bf16, the reference's setting
         # [R infinicube/inference/guidance_buffer_generation.py:762].
         self.gemm_dtype = "fp8" if torch_dtype == torch.float8_e4m3fn else "bf16"
-        # the fp8 mode also runs self-attention in e4m3 (no measurable accuracy cost: 60.1 dB alone) and quantises
-        # dit.WanDiT.FP8_DEFAULT = every projection but FFN2: 42.6 dB at the real 1.3B depth (all six: 39.8 dB, under the bar)
+        # the fp8 mode also runs self-attention in e4m3 (60.1 dB alone at 1.3B depth, 47.1 dB at 14B depth) and quantises
+        # dit.WanDiT.FP8_DEFAULT = the QKV projection: the largest set that stays >= 40 dB at the real 14B depth (see there)
         self.attn_dtype = self.gemm_dtype
         # multi-GPU layout when torch.distributed is initialised (seqpar.ParallelLayout): "auto" | "sp" | "cfg+sp"
         self.parallelism = os.environ.get("ICV_PARALLELISM", "auto")

@@ -171,7 +171,7 @@ def _lin(sd, name, x, dtype):
 # ---- fp8 GEMM mode of the build (BASELINE.json config #5 "fp8 MFMA weights"; not a behaviour of the reference) ----
 FP8_MAX = 448.0   # largest finite OCP e4m3 value
 FP8_ALL = ("wqkv", "wo", "xq_w", "xo_w", "f0_w", "f2_w")
-FP8_DEFAULT = ("wqkv", "wo", "xq_w", "xo_w", "f0_w")   # the build's default e4m3 set (FFN2 stays bf16)
+FP8_DEFAULT = ("wqkv",)   # the build's default e4m3 set (dit.WanDiT.FP8_DEFAULT: the QKV projection; the other five stay bf16)
 
 
 def quantize_rows_fp8(x: Tensor) -> Tuple[Tensor, Tensor]:

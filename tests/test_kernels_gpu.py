@@ -345,7 +345,7 @@ def test_attention7_variants(hip_ops, variant):
             assert torch.equal(o, o2), "non-deterministic attention output (LDS-DMA ring race?)"
             assert_bf16_close(o, ref, f"attn7 variant {variant} Sq={Sq} Skv={Skv}", abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
     finally:
-        hip_ops.lib.icv_set_option(b"attn_kernel", ATTN_DEFAULT); hip_ops.lib.icv_set_option(b"attn7_variant", 0)
+        hip_ops.lib.icv_set_option(b"attn_kernel", ATTN_DEFAULT); hip_ops.lib.icv_set_option(b"attn7_variant", -1)
 
 
 @pytest.mark.parametrize("unit", [0, 1])

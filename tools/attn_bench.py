@@ -76,7 +76,7 @@ for name, Sq, Skv, H in cases:
     print(f"{name:10s} Sq={Sq} Skv={Skv} H={H}: " + " | ".join(
         f"v{vv}: {fl / sorted(best[vv])[len(best[vv]) // 2] / 1e9:6.1f} TF (min {min(best[vv]):.3f} ms)" for vv in variants))
 ops.lib.icv_set_option(b"attn_variant", 5); ops.lib.icv_set_option(b"attn_kernel", 7); ops.lib.icv_set_option(b"attn2_variant", 12)
-ops.lib.icv_set_option(b"attn7_short", -1); ops.lib.icv_set_option(b"attn7_variant", 0)
+ops.lib.icv_set_option(b"attn7_short", -1); ops.lib.icv_set_option(b"attn7_variant", -1)
 
 # cost of splitting one self-attention over C key chunks with carried state (sequence-parallel path)
 if os.environ.get("ATTN_CHUNKS"):
