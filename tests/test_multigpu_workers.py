@@ -63,6 +63,21 @@ def test_generator_spawns_workers_and_matches_single_process(tmp_path, monkeypat
             d = np.abs(a.astype(np.int16) - b.astype(np.int16))
             assert d.max() <= 2 and (d > 0).mean() < 0.02, f"N-rank frames differ from the single-process frames: max {d.max()}, {100 * (d > 0).mean():.2f} % pixels"
         assert not np.array_equal(got1, got2), "the seed of the second request must reach every rank"
+        # a SECOND generator built with the same arguments reuses the live pool (its workers sit in their serve loop: the
+        # constructor must not issue a barrier they would never answer) and serves requests like the first
+        import mgpu_factory as F
+        from infinicube.videogen import WanVideoGenerator
+        from infinicube_amd.videogen import synthetic as syn
+        with contextlib.redirect_stdout(io.StringIO()):
+            g2 = WanVideoGenerator(path, device="cpu", use_wan_1pt3b=True, pipeline_factory=F.factory)
+            assert g2._pool is g._pool
+            sem, co = syn.make_dummy_buffers(F.GRID)
+            co[:, :, : F.GRID.width // 2] //= 2
+            again = np.stack([np.asarray(f) for f in g2.generate(sem, co, seed=3)])
+            unseeded = [np.stack([np.asarray(f) for f in g2.generate(sem, co, seed=None)]) for _ in range(2)]
+        assert np.array_equal(again, got1), "the reused pool must reproduce the first generator's frames for the same request"
+        # seed=None: ONE drawn seed for all ranks (shards of one latent) - finite frames, and a different video per call
+        assert all(u.shape == got1.shape for u in unseeded) and not np.array_equal(unseeded[0], unseeded[1])
     finally:
         if g is not None and g._pool is not None:
             g._pool.close()
