@@ -24,6 +24,8 @@ import time
 
 # the host driver only supports dmabuf IPC: without this RCCL peer access fails with hipIpcGetMemHandle errors
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    os.environ.setdefault("NCCL_DEBUG", "WARN")   # RCCL problems of a first multi-GPU contact surface on stderr
 
 import torch  # noqa: E402
 
@@ -112,6 +114,7 @@ def self_launch(n: int) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", "4")
+        env.setdefault("NCCL_DEBUG", "WARN")          # RCCL problems of a first multi-GPU contact surface on stderr
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else sys.stderr, stdin=subprocess.DEVNULL))
     rc = 0

@@ -339,7 +339,17 @@ def round_state_dict_to_bf16(sd: Dict[str, Tensor]) -> Dict[str, Tensor]:
 
 
 def psnr(a: Tensor, b: Tensor) -> float:
+    """LATENT PSNR: peak = max |reference latent| (a latent has no fixed dynamic range; this is the convention of every
+    "latent PSNR" figure in this repo).  The north star's ">= 40 dB" is stated on FRAMES: tests/psnr_util.frame_psnr (uint8,
+    peak 255, same decoder on both arms) is reported next to it everywhere; snr_db below is the range-free companion."""
     a, b = a.double(), b.double()
     mse = float(((a - b) ** 2).mean())
     peak = float(b.abs().max())
     return float("inf") if mse == 0 else 10.0 * math.log10(peak * peak / mse)
+
+
+def snr_db(a: Tensor, b: Tensor) -> float:
+    """Signal-to-noise ratio 10 log10(mean ref^2 / mean err^2): no peak convention involved."""
+    a, b = a.double(), b.double()
+    mse = float(((a - b) ** 2).mean())
+    return float("inf") if mse == 0 else 10.0 * math.log10(float((b ** 2).mean()) / mse)

@@ -418,7 +418,8 @@ def test_config3_wan_14b_four_step_loop_full_depth(hip_ops):
     for mode, (lat, t_hip) in got.items():
         p = R.psnr(lat, ref)
         pf = frame_psnr(lat, ref, PoolVAE())
-        lines.append(f"config #3, {steps}-step loop at full depth, product {mode}: HIP {t_hip:.1f}s, fp32 torch oracle on GPU {t_ref:.1f}s; latent PSNR {p:.1f} dB, frame PSNR {pf:.1f} dB")
+        lines.append(f"config #3, {steps}-step loop at full depth, product {mode}: HIP {t_hip:.1f}s, fp32 torch oracle on GPU {t_ref:.1f}s; latent PSNR {p:.1f} dB "
+                     f"(SNR {R.snr_db(lat, ref):.1f} dB), frame PSNR {pf:.1f} dB")
         print(lines[-1])
         assert torch.isfinite(lat).all() and p >= 40.0 and pf >= 40.0, f"config #3 {steps}-step loop ({mode}): latent PSNR {p:.1f} dB, frame PSNR {pf:.1f} dB"
     os.makedirs("gpurun_out", exist_ok=True)
