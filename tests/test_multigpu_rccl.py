@@ -193,6 +193,9 @@ def test_worker_pool_on_rccl(tmp_path, monkeypatch):
     import mgpu_factory as F
     from infinicube.videogen import WanVideoGenerator
     from infinicube_amd.videogen import synthetic as syn
+    import torch.distributed as dist
+    if dist.is_initialized():          # e.g. the one-rank group tests/test_dit_gpu.py leaves behind in this session:
+        dist.destroy_process_group()   # with a foreign group alive ICV_WORLD stands down (multigpu.requested_world)
     n = max(w for w in (2, 4, 8) if w <= _n_gpus())
     path = str(tmp_path / "step-1.safetensors")
     save_file({"buffer_embedder." + k: v for k, v in syn.make_buffer_embedder_state_dict(F.CFG).items()}, path)
