@@ -45,11 +45,12 @@ def main() -> int:
     ap.add_argument("--sp-chunks", type=int, default=3)
     ap.add_argument("--gemm-dtype", default="bf16")
     ap.add_argument("--attn-dtype", default="bf16")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (gloo backend): the multi-process path on a 1-GPU box")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
 
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    local = 0 if a.share_gpu else int(os.environ.get("LOCAL_RANK", str(rank)))
     import torch.distributed as dist
     if a.ops == "hip":
         from infinicube_amd.videogen.ops import HipOps
@@ -101,7 +102,7 @@ def main() -> int:
         assert torch.isfinite(res).all(), "non-finite result"
         if world > 1:
             # every rank must end with the same full result
-            mine_sum = res.double().sum().reshape(1).to(dev)
+            mine_sum = res.double().sum().reshape(1).to("cpu" if a.backend == "gloo" else dev)
             sums = [torch.empty_like(mine_sum) for _ in range(world)]
             dist.all_gather(sums, mine_sum)
             assert all(float(s) == float(sums[0]) for s in sums), f"ranks disagree on the gathered result: {[float(s) for s in sums]}"

@@ -118,6 +118,19 @@ def gpu_single(tmp_path_factory):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,parallelism", [(2, "sp"), (4, "cfg+sp")])
+def test_shared_gpu_gloo_ranks_equal_single_gpu(tmp_path, gpu_single, world, parallelism):
+    """What a ONE-GPU box can run of the multi-process path: N real processes, each with the PRODUCT operator set (HIP
+    kernels through the C ABI) on the one GPU they share, exchanging their K|V rows / velocity tokens / latents through a real
+    process group (gloo: RCCL refuses two ranks on one device).  Everything of configs #4 / #5 except the RCCL transport
+    itself: shard plans, RoPE offsets, chunked carried-state attention, the cfg+sp velocity swap, the final latent gather."""
+    args = ["--backend", "gloo", "--share-gpu"] + GPU_TINY[2:] + ["--scenario", "loop", "--parallelism", parallelism, "--kv-exchange", "allgather"]
+    got = run_ranks(world, str(tmp_path / "multi.pt"), args)
+    assert got["info"]["world"] == world and got["info"]["backend"] == "gloo"
+    _close(got, gpu_single["loop"], f"gloo x{world} on one GPU, {parallelism}")
+
+
+@pytest.mark.gpu
 @needs_gpus(2)
 @pytest.mark.parametrize("world,parallelism,kv_exchange", [
     (2, "sp", "allgather"), (2, "sp", "p2p"), (2, "sp", "native"), (2, "cfg+sp", "allgather"),
