@@ -30,8 +30,10 @@ def failing_factory(torch_dtype, device, model_configs):
 
 def gpu_factory(torch_dtype, device, model_configs):
     """The same tiny pipeline with the PRODUCT operator set on this rank's GPU (tests/test_multigpu_rccl.py: real RCCL ranks)."""
+    import os
     from infinicube_amd.videogen.ops import HipOps
-    dev = WanVideoPipeline.resolve_device(device)
+    # ICV_TEST_SHARE_GPU=1: every rank on cuda:0 (a 1-GPU box, gloo backend) instead of cuda:LOCAL_RANK
+    dev = "cuda:0" if os.environ.get("ICV_TEST_SHARE_GPU") == "1" else WanVideoPipeline.resolve_device(device)
     pipe = WanVideoPipeline(dev, torch_dtype, DiTHolder(syn.make_dit_state_dict(CFG), CFG), HashTextEncoder(CFG), PoolVAE(), ops=HipOps(dev))
     pipe.num_inference_steps = 2
     return pipe

@@ -194,25 +194,23 @@ def test_bench_line_for_n_gpus(launcher):
     assert d["scaling"] == "strong" and d["value"] > 0
 
 
-@pytest.mark.gpu
-@needs_gpus(2)
-def test_worker_pool_on_rccl(tmp_path, monkeypatch):
-    """ICV_WORLD=N behind the unchanged single-process caller, on real GPUs: this process is rank 0 on cuda:0, the
-    workers take cuda:1.., the process group is RCCL; frames against the single-GPU generator."""
+def _pool_frames(tmp_path, monkeypatch, n, backend, share):
+    """Frames of the single-GPU generator and of the same generator behind an n-rank worker pool (ICV_WORLD=n)."""
     import contextlib
     import io
     import numpy as np
     from safetensors.torch import save_file
     import mgpu_factory as F
+    import torch.distributed as dist
     from infinicube.videogen import WanVideoGenerator
     from infinicube_amd.videogen import synthetic as syn
-    import torch.distributed as dist
     if dist.is_initialized():          # e.g. the one-rank group tests/test_dit_gpu.py leaves behind in this session:
         dist.destroy_process_group()   # with a foreign group alive ICV_WORLD stands down (multigpu.requested_world)
-    n = max(w for w in (2, 4, 8) if w <= _n_gpus())
     path = str(tmp_path / "step-1.safetensors")
     save_file({"buffer_embedder." + k: v for k, v in syn.make_buffer_embedder_state_dict(F.CFG).items()}, path)
     sem, co = syn.make_dummy_buffers(F.GRID)
+    if share:
+        monkeypatch.setenv("ICV_TEST_SHARE_GPU", "1")
 
     def run():
         with contextlib.redirect_stdout(io.StringIO()):
@@ -222,16 +220,33 @@ def test_worker_pool_on_rccl(tmp_path, monkeypatch):
 
     _, ref = run()
     monkeypatch.setenv("ICV_WORLD", str(n))
+    monkeypatch.setenv("ICV_DIST_BACKEND", backend)
     monkeypatch.setenv("ICV_WORKER_FACTORY", "mgpu_factory:gpu_factory")
     monkeypatch.setenv("ICV_WORLD_TIMEOUT_S", "600")
     monkeypatch.setenv("PYTHONPATH", os.pathsep.join([ROOT, HERE, os.environ.get("PYTHONPATH", "")]))
     g = None
     try:
         g, got = run()
-        import torch.distributed as dist
-        assert dist.is_initialized() and dist.get_world_size() == n and dist.get_backend() == "nccl"
+        assert dist.is_initialized() and dist.get_world_size() == n and dist.get_backend() == backend and g._pool is not None
         d = np.abs(ref.astype(np.int16) - got.astype(np.int16))
-        assert d.max() <= 2 and (d > 0).mean() < 0.02, f"N-GPU frames differ: max {d.max()}, {100 * (d > 0).mean():.2f} % pixels"
+        assert d.max() <= 2 and (d > 0).mean() < 0.02, f"{n}-rank frames differ from the single-GPU frames: max {d.max()}, {100 * (d > 0).mean():.2f} % pixels"
     finally:
         if g is not None and g._pool is not None:
             g._pool.close()
+    assert not dist.is_initialized()
+
+
+@pytest.mark.gpu
+def test_worker_pool_two_processes_sharing_the_gpu(tmp_path, monkeypatch):
+    """ICV_WORLD=2 behind the unchanged single-process caller with the PRODUCT operator set in both processes, on a 1-GPU
+    box: the caller's process and one worker share cuda:0 and talk over gloo (request broadcast, velocity swap, latent
+    gather) — the worker-pool path end to end on HIP kernels, minus the RCCL transport."""
+    _pool_frames(tmp_path, monkeypatch, 2, "gloo", share=True)
+
+
+@pytest.mark.gpu
+@needs_gpus(2)
+def test_worker_pool_on_rccl(tmp_path, monkeypatch):
+    """ICV_WORLD=N behind the unchanged single-process caller, on real GPUs: this process is rank 0 on cuda:0, the
+    workers take cuda:1.., the process group is RCCL; frames against the single-GPU generator."""
+    _pool_frames(tmp_path, monkeypatch, max(w for w in (2, 4, 8) if w <= _n_gpus()), "nccl", share=False)
