@@ -225,9 +225,9 @@ int mm(icv_dit& D, const Act& a, const Wt& W, int64_t r0, int64_t N, int64_t K, 
   const int64_t n = D.cfg.n_tok;
   ICV_REQUIRE((a.s != nullptr) == (W.s != nullptr), "icv_dit_forward: operand / weight dtype mismatch");
   if (W.s)
-    return icv_gemm_fp8(a.p, K, a.s, (const char*)W.w + r0 * K, K, W.s + r0, bias + r0, n, N, K, epi, out, ldo, nsplit, sstride, resid,
+    return icv_gemm_fp8(a.p, K, a.s, (const char*)W.w + r0 * K, K, W.s + r0, bias ? bias + r0 : nullptr, n, N, K, epi, out, ldo, nsplit, sstride, resid,
                         D.cfg.dim, gate, stream);
-  return icv_gemm_bf16(a.p, K, (const bf16_t*)W.w + r0 * K, K, bias + r0, n, N, K, epi, out, ldo, nsplit, sstride, resid, D.cfg.dim, gate, stream);
+  return icv_gemm_bf16(a.p, K, (const bf16_t*)W.w + r0 * K, K, bias ? bias + r0 : nullptr, n, N, K, epi, out, ldo, nsplit, sstride, resid, D.cfg.dim, gate, stream);
 }
 
 }  // namespace

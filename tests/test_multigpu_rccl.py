@@ -38,7 +38,7 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def run_ranks(n, out, args, timeout=900, extra_env=None):
+def run_ranks(n, out, args, timeout=420, extra_env=None):
     """Start n copies of the worker (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run sets them), wait,
     fail with the failing rank's output; returns the dict rank 0 saved."""
     port = _free_port()
@@ -153,8 +153,8 @@ def test_rccl_14b_layer_full_S_ranks_equal_single_gpu(tmp_path, kv_exchange):
     n = max(w for w in (2, 4, 8) if w <= _n_gpus())
     big = ["--backend", "nccl", "--ops", "hip", "--model", "14b", "--frames", 93, "--height", 480, "--width", 832, "--scenario", "layer",
            "--sp-chunks", 4]
-    ref = run_ranks(1, str(tmp_path / "single.pt"), big)
-    got = run_ranks(n, str(tmp_path / "multi.pt"), big + ["--kv-exchange", kv_exchange])
+    ref = run_ranks(1, str(tmp_path / "single.pt"), big, timeout=900)
+    got = run_ranks(n, str(tmp_path / "multi.pt"), big + ["--kv-exchange", kv_exchange], timeout=900)
     assert got["info"]["sp_world"] == n and got["info"]["kv_collectives"] == 4
     _close(got, ref, f"RCCL x{n} 14B block S=37440 {kv_exchange}")
 
@@ -222,7 +222,7 @@ def _pool_frames(tmp_path, monkeypatch, n, backend, share):
     monkeypatch.setenv("ICV_WORLD", str(n))
     monkeypatch.setenv("ICV_DIST_BACKEND", backend)
     monkeypatch.setenv("ICV_WORKER_FACTORY", "mgpu_factory:gpu_factory")
-    monkeypatch.setenv("ICV_WORLD_TIMEOUT_S", "600")
+    monkeypatch.setenv("ICV_WORLD_TIMEOUT_S", "240")
     monkeypatch.setenv("PYTHONPATH", os.pathsep.join([ROOT, HERE, os.environ.get("PYTHONPATH", "")]))
     g = None
     try:
