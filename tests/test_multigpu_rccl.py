@@ -100,6 +100,14 @@ def test_twin_layer_ranks_equal_single(tmp_path, cpu_single):
     _close(got, cpu_single["layer"], "gloo x3 one block")
 
 
+def test_twin_fp8_mode_ranks_equal_single(tmp_path):
+    """The e4m3 mode on the sharded path (every gathered K|V chunk quantised on its own): e4m3-level agreement."""
+    args = CPU + ["--scenario", "loop", "--gemm-dtype", "fp8", "--attn-dtype", "fp8"]
+    ref = run_ranks(1, str(tmp_path / "single.pt"), args)
+    got = run_ranks(2, str(tmp_path / "multi.pt"), args + ["--parallelism", "sp"])
+    _close(got, ref, "gloo x2 fp8 mode", rel_bound=6e-2, psnr_bound=30.0)
+
+
 def test_twin_failing_rank_is_reported(tmp_path):
     with pytest.raises(AssertionError, match="rank . of 2 failed"):
         run_ranks(2, str(tmp_path / "x.pt"), CPU + ["--scenario", "loop", "--parallelism", "tp"])

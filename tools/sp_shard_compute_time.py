@@ -1,0 +1,93 @@
+"""Compute-only projection of the N-GPU step time from ONE GPU (run on the GPU box).
+
+A rank of an N-GPU run does, per layer, exactly the kernels of `WanDiT._forward_body` on its token shard with the K|V rows of
+the other ranks arriving from the exchange.  Everything except the exchange can be timed on one GPU: this tool builds a
+few Wan2.1-14B layers at S = 37 440, runs the sequence-parallel schedule of one rank of a `world`-rank group with the
+exchange SERVED from local memory (a device copy of random rows stands in for the arrived peers' rows; no transfer time),
+and reports ms per layer-forward -> the step time a rank would need if every transfer hid completely under compute:
+
+    layout at N GPUs        forwards per rank per step     shard
+    cfg+sp  N = 2           1                              world 1 (no exchange at all)
+    cfg+sp  N = 4           1                              world 2
+    cfg+sp  N = 8           1                              world 4
+    sp      N = 8           2                              world 8
+
+It is a LOWER bound on the step time and an upper bound on the scaling: RCCL's kernels take CUs while they run and whatever
+part of a transfer is not hidden adds to it.  The first real measurement is the driver's 8-GPU run; `bench.py --gpus N` reports
+`exposed_kv_wait_ms_per_step` to compare with this table.
+"""
+import dataclasses
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from infinicube_amd.videogen import synthetic as syn
+from infinicube_amd.videogen.config import GRID_480P, preset
+from infinicube_amd.videogen.dit import WanDiT
+from infinicube_amd.videogen.ops import HipOps
+from infinicube_amd.videogen.seqpar import ShardPlan
+
+DEV = "cuda:0"
+LAYERS = int(os.environ.get("LAYERS", "4"))
+ops = HipOps(DEV)
+cfg_full = preset("14b")
+cfg, grid = dataclasses.replace(cfg_full, num_layers=LAYERS), GRID_480P
+sd = syn.make_dit_state_dict(cfg, seed=0, device=DEV, dtype=torch.bfloat16)
+bsd = syn.make_buffer_embedder_state_dict(cfg, device=DEV, dtype=torch.bfloat16)
+noise, ctx, bl = syn.make_latent_noise(grid).to(DEV), syn.make_text_context(cfg, 1), syn.make_buffer_latents(cfg, grid)
+peers = torch.randn((grid.S, 2 * cfg.dim), device=DEV).to(torch.bfloat16) * 0.3      # stand-in for the arrived K|V rows
+
+
+class ServedGather:
+    """seqpar.KVGather's interface; the peers' rows are a device copy (what is left of an exchange once it has landed)."""
+    timing, n_collectives = None, 0
+
+    def __init__(self, world):
+        self.world = world
+
+    def start(self, rows, out):
+        m = rows.shape[0]
+        out.copy_(peers[: self.world * m])
+        out[:m].copy_(rows)
+        return ()
+
+    def wait(self, handle):
+        pass
+
+
+def time_forward(world, chunks, iters=3):
+    plan = ShardPlan.make(grid.S, world, 0)
+    m = WanDiT(cfg, sd, ops, bsd).prepare(grid, plan, kv_gather=ServedGather(world) if world > 1 else None, sp_chunks=chunks, graphs=False)
+    ck, bt = m.encode_context(ctx), m.embed_buffers(bl)
+    m.forward_tokens(noise, ck, 500.0, bt, m.head_out[0])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        m.forward_tokens(noise, ck, 500.0, bt, m.head_out[0])
+    e1.record()
+    torch.cuda.synchronize()
+    del m
+    torch.cuda.empty_cache()
+    return e0.elapsed_time(e1) / iters / LAYERS          # ms per layer-forward (patch embed + head amortised: < 0.1 %)
+
+
+rows = []
+base = time_forward(1, 1)
+L = cfg_full.num_layers
+one_gpu_step = 2 * L * base
+print(f"1 GPU: {base:.2f} ms per layer-forward -> {one_gpu_step:.0f} ms per step (2 forwards x {L} layers)")
+for n_gpus, layout, world, fwd in ((2, "cfg+sp", 1, 1), (4, "cfg+sp", 2, 1), (8, "cfg+sp (auto)", 4, 1), (8, "sp", 8, 2), (4, "sp", 4, 2), (2, "sp", 2, 2)):
+    for chunks in ((1,) if world == 1 else (4, 2)):
+        t = base if world == 1 else time_forward(world, chunks)
+        step = fwd * L * t
+        rows.append(dict(n_gpus=n_gpus, layout=layout, sp_world=world, sp_chunks=chunks, ms_per_layer_forward=t, compute_only_ms_per_step=step,
+                         compute_only_steps_per_s=1e3 / step, compute_only_scaling=one_gpu_step / step))
+        print(f"N = {n_gpus} {layout:14s} shard 1/{world} chunks {chunks}: {t:6.2f} ms per layer-forward -> {step:7.1f} ms per step, "
+              f"{1e3 / step:.3f} steps/s, x{one_gpu_step / step:.2f} of one GPU (compute only, exchange fully hidden)")
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(dict(model="wan2.1-t2v-14b", S=grid.S, layers_timed=LAYERS, one_gpu_ms_per_step=one_gpu_step, rows=rows), open("gpurun_out/sp_compute_only_projection.json", "w"), indent=1)
