@@ -184,6 +184,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         args.gpus = world        # the launcher's world size is authoritative
+    # stdout carries ONE JSON line and nothing else: native libraries write there too (RCCL's version banner and NCCL_DEBUG
+    # output, gloo's "[Gloo] Rank ..." lines), so file descriptor 1 points at stderr for the whole run and is restored for
+    # the final print
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     # one process per GPU.  ICV_BENCH_SHARE_GPU=1 (+ ICV_DIST_BACKEND=gloo) lets several ranks share the only GPU of a
     # development box so the N>1 code path can be exercised there; it is never a measurement mode.
     share = os.environ.get("ICV_BENCH_SHARE_GPU", "0") == "1"
@@ -325,7 +331,7 @@ def main():
         exposed_ms = sum(a.elapsed_time(b) for a, b in waits)
         tt = torch.tensor([exposed_ms, float(len(waits)), float(n_coll)], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        comm = {"rccl_ranks": world, "kv_exchange": args.kv_exchange, "sp_chunks": args.sp_chunks,
+        comm = {"rccl_ranks": world, "backend": dist.get_backend(), "kv_exchange": args.kv_exchange, "sp_chunks": args.sp_chunks,
                 "kv_group_ranks": layout.sp_world,
                 "kv_exchanges_per_step_per_rank": tt[2].item() / args.steps,
                 "kv_bytes_sent_per_exchange_layer": 2 * 2 * plan.n_tok * cfg.dim if layout.sp_world > 1 else 0,
@@ -409,7 +415,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or min(os.cpu_count() or 1, 32)  # >32 threads oversubscribes these GEMM sizes
             out["cpu_baseline"] = cpu_baseline(cfg, grid, threads)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)            # the real stdout back, for the one line
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if world > 1:
         dist.destroy_process_group()
 

@@ -183,6 +183,32 @@ def test_rccl_fp8_mode_ranks_equal_single_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,launcher", [(1, "plain"), (2, "self"), (4, "torchrun")])
+def test_bench_stdout_is_one_json_line_on_one_gpu(n, launcher):
+    """The bench contract on a 1-GPU box: stdout is ONE JSON line and nothing else (native libraries print there too: gloo's
+    "[Gloo] Rank ..." lines, RCCL's banner), for the plain N = 1 form and — N ranks sharing the one GPU over gloo, a code-path
+    check, never a measurement — for the self-launching and the torch.distributed.run forms, with the layout `auto` builds."""
+    tail = ["bench.py", "--gpus", str(n), "--model", "small", "--frames", "17", "--height", "256", "--width", "448", "--steps", "2", "--warmup", "1",
+            "--no-cpu-baseline"]
+    cmd = [sys.executable] + tail if launcher != "torchrun" else [
+        sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port",
+        str(_free_port())] + tail
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    if n > 1:
+        env.update(ICV_BENCH_SHARE_GPU="1", ICV_DIST_BACKEND="gloo")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), f"stdout must be ONE JSON line and nothing else, got {len(lines)} lines: {r.stdout[:400]!r}"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["unit"] == "denoise steps/s"
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+    if n > 1:
+        assert d["multi_gpu"]["rccl_ranks"] == n and d["multi_gpu"]["backend"] == "gloo" and "exposed_kv_wait_ms_per_step" in d["multi_gpu"]
+        assert ("cfg2 x sp" in d["config"]["parallelism"]) and d["scaling"] == "strong"
+
+
+@pytest.mark.gpu
 @needs_gpus(2)
 @pytest.mark.parametrize("launcher", ["self", "torchrun"])
 def test_bench_line_for_n_gpus(launcher):
@@ -198,8 +224,8 @@ def test_bench_line_for_n_gpus(launcher):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, f"expected ONE JSON line, got {len(lines)}"
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), f"stdout must be ONE JSON line and nothing else, got {len(lines)} lines: {r.stdout[:400]!r}"
     d = json.loads(lines[0])
     assert d["n_gpus"] == n and d["multi_gpu"]["rccl_ranks"] == n and "exposed_kv_wait_ms_per_step" in d["multi_gpu"]
     assert d["scaling"] == "strong" and d["value"] > 0
