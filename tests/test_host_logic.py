@@ -346,3 +346,21 @@ def test_gloo_cfg_branch_parallel_equals_single(world, mode, kv_exchange):
     with pytest.raises(ValueError, match="exactly one"):
         single.denoise(ref, single.encode_context(c1), single.encode_context(c2), single.embed_buffers(bl), FlowMatchScheduler(1), 5.0,
                        branch_exchange=lambda a, b: None)
+
+
+def test_bench_fails_loudly_without_a_gpu():
+    """bench.py measures the HIP path or nothing: on a box without a GPU the plain form and the self-launching N-rank form
+    exit non-zero within seconds, print no JSON line (there is no CPU fallback to time), and the launcher names the rank
+    that failed and stops the others."""
+    import subprocess
+    if torch.cuda.is_available():
+        pytest.skip("needs a box WITHOUT a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "bench.py", "--model", "tiny", "--steps", "1", "--warmup", "0"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--model", "tiny"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "only 0 GPU(s) visible" in r.stderr and r.stdout.strip() == ""
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--model", "tiny"], cwd=root, env=dict(env, ICV_BENCH_SHARE_GPU="1", ICV_DIST_BACKEND="gloo"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "exited with code" in r.stderr and r.stdout.strip() == ""
