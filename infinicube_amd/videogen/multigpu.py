@@ -51,6 +51,11 @@ def pool_for(world: int, ctor_kwargs: dict) -> "WorkerPool":
     return _ACTIVE_POOL
 
 
+def layout_cache():
+    """The live pool's parallel-layout cache (process groups are a resource of the pool's process group), or None."""
+    return _ACTIVE_POOL.layouts if (_ACTIVE_POOL is not None and not _ACTIVE_POOL._closed) else None
+
+
 def requested_world() -> int:
     """ICV_WORLD = N | auto (= every visible GPU).  1 inside a worker, when unset, or when the process already is a
     rank of somebody else's job (torch.distributed initialised / launched by torch.distributed.run)."""
@@ -87,6 +92,7 @@ class WorkerPool:
         self.world, self.dist, self.ctor_kwargs = world, dist, dict(ctor_kwargs)
         self._closed = True
         self._ready = False          # set by the first wait_ready(): the workers then sit in their serve loop
+        self.layouts = {}            # seqpar.ParallelLayout per (world, rank, mode, cfg): shared by every pipeline of this process
         self.backend = backend or os.environ.get("ICV_DIST_BACKEND", "nccl")
         self.timeout_s = float(os.environ.get("ICV_WORLD_TIMEOUT_S", "3600"))
         port = _free_port()
@@ -189,6 +195,7 @@ class WorkerPool:
                     pass
         finally:
             self._kill()
+            self.layouts.clear()     # the sub-groups go with the process group
             try:
                 if self.dist.is_initialized():
                     self.dist.destroy_process_group()

@@ -337,9 +337,16 @@ class WanVideoPipeline:
         except Exception:  # pragma: no cover
             pass
         lkey = (world, rank, self.parallelism, cfg_scale != 1.0)
-        if lkey not in self._layouts:   # process groups are created once per (world, mode)
-            self._layouts[lkey] = ParallelLayout.make(world, rank, self.parallelism, use_cfg=cfg_scale != 1.0)
-        layout = self._layouts[lkey]
+        # process groups are created once per (world, mode).  Behind a worker pool the cache belongs to the POOL, not to this
+        # pipeline object: a second generator on the same pool gives rank 0 a new pipeline while the workers keep theirs, and
+        # creating groups is a collective they would never join
+        from . import multigpu
+        layouts = multigpu.layout_cache()
+        if layouts is None:
+            layouts = self._layouts
+        if lkey not in layouts:
+            layouts[lkey] = ParallelLayout.make(world, rank, self.parallelism, use_cfg=cfg_scale != 1.0)
+        layout = layouts[lkey]
         plan = layout.shard_plan(grid.S)
         engine.prepare(grid, plan, group=layout.sp_group, sp_chunks=self.sp_chunks, kv_exchange=self.kv_exchange)
         self.scheduler = FlowMatchScheduler(num_inference_steps, sigma_shift, self.reference_rounding)

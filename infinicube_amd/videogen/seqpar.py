@@ -59,10 +59,12 @@ class ParallelLayout:
     sp_group: object = None   # process group of the ranks sharing this rank's branch (None = default group)
     pair_group: object = None  # cfg+sp: (cond rank, uncond rank) owning the same token shard
 
-    _cache = {}   # (world, rank, mode) -> (default process group it was built in, layout): groups are process-wide resources
-
     @staticmethod
     def make(world: int = 1, rank: int = 0, mode: str = "auto", use_cfg: bool = True, init_groups: bool = True) -> "ParallelLayout":
+        """Creating the groups is a COLLECTIVE of the whole world: every rank must call this the same number of times, in
+        the same order.  A caller that builds pipelines asymmetrically (a second WanVideoGenerator on a live worker pool:
+        only rank 0 gets a new pipeline object) must reuse the first layout — WanVideoPipeline keeps its layouts in the
+        pool's cache for exactly that (multigpu.WorkerPool.layouts)."""
         if mode not in ("auto", "sp", "cfg+sp"):
             raise ValueError(f"parallelism must be 'auto', 'sp' or 'cfg+sp', got {mode!r}")
         if mode == "auto":
@@ -75,18 +77,10 @@ class ParallelLayout:
         lay = ParallelLayout(world, rank, "cfg+sp", half, rank % half, rank // half)
         if init_groups:
             import torch.distributed as dist
-            # Creating a group is a COLLECTIVE of the whole world: it must happen the same number of times on every rank.
-            # A second pipeline object in one process (a second WanVideoGenerator on a live worker pool) must therefore
-            # reuse the groups the first one made instead of calling new_group alone — cached per default process group.
-            default_pg = dist.distributed_c10d._get_default_group()
-            hit = ParallelLayout._cache.get((world, rank, mode))
-            if hit is not None and hit[0] is default_pg:
-                return hit[1]
             # every rank must create every group, in the same order
             sp_groups = [dist.new_group(list(range(b * half, (b + 1) * half))) for b in range(2)]
             pair_groups = [dist.new_group([i, i + half]) for i in range(half)]
             lay.sp_group, lay.pair_group = sp_groups[lay.branch], pair_groups[lay.sp_rank]
-            ParallelLayout._cache[(world, rank, mode)] = (default_pg, lay)
         return lay
 
     def shard_plan(self, S: int) -> "ShardPlan":

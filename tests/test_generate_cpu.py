@@ -152,7 +152,8 @@ def test_fp8_torch_dtype_selects_fp8_projections():
     kw = dict(prompt="a street", negative_prompt="bad", height=GRID.height, width=GRID.width, num_frames=GRID.num_frames,
               seed=0, num_inference_steps=2, return_latents=True)
     l8 = pipe(**kw)
-    assert pipe._engine.fp8 and pipe._engine.layers[0]["f0_w"][0].dtype == torch.float8_e4m3fn
+    assert pipe._engine.fp8 and pipe._engine.fp8_set == ("wqkv",)          # the default e4m3 set: the QKV projection (dit.WanDiT.FP8_DEFAULT)
+    assert pipe._engine.layers[0]["wqkv"][0].dtype == torch.float8_e4m3fn and pipe._engine.layers[0]["f0_w"].dtype == torch.bfloat16
     pipe.gemm_dtype = pipe.attn_dtype = "bf16"    # engine is rebuilt when the mode changes
     l16 = pipe(**kw)
     assert not pipe._engine.fp8
