@@ -43,7 +43,9 @@ int icv_device_info(int device, int64_t out[4]);
  * "gemm_fp8_sched" = 3 (default) | 0 (round 1's four-phase loop), "attn_kernel" = 7 (attn7.hip, default) | 2 (attn2.hip);
  * attention families 1, 3..6, 9 and "gemm256" = 3 | 4 (the two 4-wave GEMMs) are the measured-slower experiments under
  * csrc/experiments/, present only in a library built with ICV_EXPERIMENTS=1 ("require_experiments" returns 0 exactly then),
- * "attn<N>_variant" (bit flags, see each file), "attn_defer_max_log2" (rescale threshold, default 8), "attn_unit_scale" = 0 | 1,
+ * "attn<N>_variant" (bit flags, see each file; "attn7_variant": default 132 = 128-key publish + s_setprio, negative = default),
+ * "attn7_short" (largest key count that takes attn7's 4-wave / two-stage launch shape: default 1024 = the cross-attention calls,
+ * 0 = never, negative = default), "attn_defer_max_log2" (rescale threshold, default 8), "attn_unit_scale" = 0 | 1,
  * "ln_waves_per_row" = 0 | 1 | 2 | 4.  TIMING ABLATIONS that make results WRONG on purpose (tools/ only): "gemm256_ablate",
  * "gemm256x_ablate", "attn7_ablate".  The Python host also reads options from the environment:
  * ICV_OPTIONS="name=value,name=value". */
