@@ -79,7 +79,11 @@ def sps_rbsp(width: int, height: int, fps: float) -> bytes:
     b = _Bits()
     b.u(8, 66)                 # profile_idc: Baseline
     b.u(8, 0xC0)               # constraint_set0_flag, constraint_set1_flag (Constrained Baseline), rest 0
-    b.u(8, 51)                 # level_idc 5.1: raw samples at 10 fps exceed the bit rates of the lower levels
+    # level: raw samples exceed the bit rates of the lower levels, and Annex A.3.1 bounds the bytes of one access unit by
+    # 384 * max(PicSizeInMbs, MaxMBPS / 172) / MinCR: an all-PCM picture (384 B per macroblock + the slice header) fits under
+    # level 5.1 (MaxMBPS 983 040 -> 1.10 MB) up to ~2800 macroblocks (93 x 480 x 832: 1560) and under 5.2 (2.31 MB) beyond
+    # (720 x 1280: 3600)
+    b.u(8, 51 if mbw * mbh <= 2800 else 52)
     b.ue(0)                    # seq_parameter_set_id
     b.ue(0)                    # log2_max_frame_num_minus4
     b.ue(2)                    # pic_order_cnt_type 2: output order = decoding order

@@ -117,6 +117,14 @@ def test_h264_emulation_prevention_and_bit_writer():
         h264pcm.encode_h264_pcm(_frames(1, 17, 32), 10)
 
 
+def test_h264_level_follows_the_picture_size():
+    import h264_subset_decoder as H
+    from infinicube_amd.videogen import h264pcm
+    assert H.parse_sps(h264pcm.sps_rbsp(832, 480, 10))["level_idc"] == 51
+    big = H.parse_sps(h264pcm.sps_rbsp(1280, 720, 10))
+    assert big["level_idc"] == 52 and (big["width"], big["height"]) == (1280, 720) and big["mb_w"] * big["mb_h"] == 3600
+
+
 def test_unknown_codec_is_refused(tmp_path, monkeypatch):
     monkeypatch.setenv("ICV_MP4_CODEC", "vp9")
     with pytest.raises(ValueError, match="ICV_MP4_CODEC"):
