@@ -479,6 +479,54 @@ def test_configs_2_and_3_at_50_steps(hip_ops, model, need):
         assert torch.isfinite(lat).all() and R.psnr(lat, ref) >= 40.0 and frame_psnr(lat, ref, PoolVAE()) >= 40.0, f"50 steps ({mode}) under the 40 dB bar: {lines}"
 
 
+def test_config5_wan_14b_i2v_720p_loop_full_depth(hip_ops):
+    """Config #5's LOOP on one GPU at full depth and size: Wan2.1-14B image-to-video (CLIP cross-attention branch, 36 input
+    channels), 93 frames 720x1280 (S = 86 400), a complete 3-step CFG-5 flow-match schedule from noise to sigma 0 (6 forwards of
+    40 layers), bf16 product and the e4m3 mode against oracle/wan_ref.denoise_loop in fp32 by stock PyTorch on the GPU.
+    Opt-in (the checker needs ~17 GPU-minutes): ICV_SLOW_TESTS=2; recorded in profiles/r03/parity_config5_loop_full_depth.txt."""
+    if SLOW < 2:
+        pytest.skip("6 fp32 oracle forwards at S = 86 400 (~17 GPU-minutes): run with ICV_SLOW_TESTS=2 (recorded in profiles/r03/parity_config5_loop_full_depth.txt)")
+    from standins import PoolVAE
+    cfg, grid, steps = preset("14b-i2v"), GRID_720P, 3
+    sd = syn.make_dit_state_dict(cfg, seed=0, device=DEV, dtype=torch.bfloat16)
+    bsd = syn.make_buffer_embedder_state_dict(cfg, device=DEV, dtype=torch.bfloat16)
+    noise, c1, c2, bl = syn.make_latent_noise(grid), syn.make_text_context(cfg, 1), syn.make_text_context(cfg, 2), syn.make_buffer_latents(cfg, grid)
+    clip, y = syn.make_clip_features(cfg), syn.make_cond_latents(cfg, grid)
+    got = {}
+    for mode in ("bf16", "fp8"):
+        kw = {} if mode == "bf16" else dict(gemm_dtype="fp8", attn_dtype="fp8")
+        m = WanDiT(cfg, sd, hip_ops, bsd, **kw).prepare(grid, graphs=False)
+        ck, cu = m.encode_context(c1, clip), m.encode_context(c2, clip)
+        add = m.embed_cond_latents(y, add_to=m.embed_buffers(bl))
+        lat = noise.clone().to(DEV)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        m.denoise(lat, ck, cu, add, FlowMatchScheduler(steps), 5.0)
+        torch.cuda.synchronize()
+        got[mode] = (lat.cpu(), time.time() - t0)
+        del m, ck, cu, add, lat
+        torch.cuda.empty_cache()
+    sdr = {k: v.float() for k, v in sd.items()}
+    bsdr = {k: v.float() for k, v in bsd.items()}
+    del sd, bsd
+    torch.cuda.empty_cache()
+    t0 = time.time()
+    ref = R.denoise_loop(sdr, bsdr, cfg, noise.to(DEV), c1.to(DEV), c2.to(DEV), bl.to(DEV), num_steps=steps, clip_fea=clip.to(DEV), y=y.to(DEV)).cpu()
+    torch.cuda.synchronize()
+    t_ref = time.time() - t0
+    lines = []
+    for mode, (lat, t_hip) in got.items():
+        p, pf = R.psnr(lat, ref), frame_psnr(lat, ref, PoolVAE())
+        lines.append(f"config #5 on one GPU, Wan2.1-14B i2v 93f 720x1280 (S = {grid.S}), {steps}-step CFG-5 loop at full depth, product {mode}: HIP {t_hip:.1f}s, "
+                     f"fp32 torch oracle on GPU {t_ref:.1f}s; latent PSNR {p:.1f} dB (SNR {R.snr_db(lat, ref):.1f} dB), decoded-frame PSNR {pf:.1f} dB")
+        print(lines[-1])
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_config5_loop_full_depth.txt", "w") as f:
+        f.write("\n".join(lines) + "\n")
+    for mode, (lat, _) in got.items():
+        assert torch.isfinite(lat).all() and R.psnr(lat, ref) >= 40.0 and frame_psnr(lat, ref, PoolVAE()) >= 40.0, f"config #5 loop ({mode}) under the 40 dB bar: {lines}"
+
+
 def test_config5_wan_14b_i2v_720p_one_forward_full_depth(hip_ops):
     """Config #5 at FULL depth and size: Wan2.1-14B image-to-video (36 input channels, CLIP cross-attention branch), 93 frames
     720x1280 (S = 86 400), ONE conditional forward of all 40 layers; bf16 product and the e4m3 mode (torch_dtype =
