@@ -393,6 +393,9 @@ def main():
                     f"K/V all-gather in {args.sp_chunks} chunks inside a group; one velocity swap per step between the groups)"),
                 "wallclock_50_steps_s": 50.0 * elapsed / args.steps,
                 "cfg_stem_shared": bool(args.share_stem),
+                # the two forwards of a step issued as ONE batch of 2n rows through the token-local kernels (WanDiT.forward_pair;
+                # bit-identical to two sequential forwards, ICV_CFG_BATCH=0 switches it off): same work, better tile quantisation
+                "cfg_forwards_batched": bool(world == 1 and model._pair_ok()),
                 "c_abi_calls_per_forward": abi_calls / (args.steps * (1 if layout.mode == "cfg+sp" else 2)),
                 "host_enqueue_ms_per_step": 1e3 * t_issue_one,       # one extra step issued on a drained queue (untimed for the metric)
                 "host_ms_in_timed_loop_per_step": 1e3 * t_in_loop / args.steps,   # includes blocking inside launches once the HIP queue is full: NOT issue cost

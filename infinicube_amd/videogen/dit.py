@@ -169,21 +169,23 @@ class WanDiT:
 
     # GEMM operands are either a bf16 tensor or an (e4m3 rows, f32 row scales) pair; these three helpers keep
     # forward_tokens identical for both GEMM dtypes.
-    def _norm(self, w, **kw):
+    def _norm(self, w, rows: Optional[slice] = None, **kw):
         """K3 / K8: LayerNorm(+affine)(+modulate) of the residual stream into the A operand of the GEMM with weight
-        ``w`` (e4m3 rows + scales when that weight is quantised, bf16 otherwise)."""
+        ``w`` (e4m3 rows + scales when that weight is quantised, bf16 otherwise); ``rows``: a row range of the workspace."""
+        r = slice(None) if rows is None else rows
         if isinstance(w, tuple):
-            self.ops.ln_modulate_fp8(self.x, self.h8, self.h8s, **kw)
-            return (self.h8, self.h8s)
-        self.ops.ln_modulate(self.x, self.h, **kw)
-        return self.h
+            self.ops.ln_modulate_fp8(self.x[r], self.h8[r], self.h8s[r], **kw)
+            return (self.h8[r], self.h8s[r])
+        self.ops.ln_modulate(self.x[r], self.h[r], **kw)
+        return self.h[r]
 
-    def _operand(self, t: torch.Tensor, q8: Optional[torch.Tensor], s8: Optional[torch.Tensor], w):
+    def _operand(self, t: torch.Tensor, q8: Optional[torch.Tensor], s8: Optional[torch.Tensor], w, rows: Optional[slice] = None):
         """bf16 activation produced by attention / the GELU epilogue -> A operand of the GEMM with weight ``w``."""
+        r = slice(None) if rows is None else rows
         if isinstance(w, tuple):
-            self.ops.quantize_rows(t, q8, s8)
-            return (q8, s8)
-        return t
+            self.ops.quantize_rows(t[r], q8[r], s8[r])
+            return (q8[r], s8[r])
+        return t[r]
 
     def _mm(self, a, w, bias, out, epi, rows: Optional[slice] = None, **kw):
         """out = epilogue(a @ w[rows].T + bias[rows])."""
@@ -297,6 +299,10 @@ class WanDiT:
         # ICV_SHARE_STEM=0 switches off the sharing of the context-free stem between the two CFG forwards (A/B, tests)
         self.share_stem = os.environ.get("ICV_SHARE_STEM", "1") == "1"
         self._twin = None
+        # ICV_CFG_BATCH=0: run the two CFG forwards of a step one after the other instead of as one batch of 2n rows
+        # (forward_pair; bit-identical either way)
+        self.cfg_batch = os.environ.get("ICV_CFG_BATCH", "1") == "1"
+        self._pair = None
         if self.sp_on:
             self.kv_loc = a((n, 2 * d), BF16)                      # local k | v rows (one exchange moves both)
             self.kv_full = a((self.plan.world * n, 2 * d), BF16)   # gathered rows (chunk-major, rank-major inside)
@@ -627,6 +633,108 @@ class WanDiT:
         ops.gemm(self.h, self.head_w, self.head_b, head_out, EPI_F32)
 
     # ------------------------------------------------------------------------------------
+    # CFG-batched forward pair (single rank): the cond and uncond forwards of a step as ONE batch of 2n rows through every
+    # token-local kernel (LayerNorm, the six projections, the head), two launches only where the branches differ (self-attention:
+    # own K / V; RoPE offsets; cross-attention: own context).  Per row the arithmetic is unchanged - the same kernels, the same
+    # K order - so the pair is BIT-IDENTICAL to two sequential forwards (tests); what changes is tile quantisation: at
+    # S = 37 440 the four N = 5120 GEMMs of a layer are 2940 tiles = 11.48 rounds of 256 CUs (4.3 % of their time is an empty
+    # half round), as 2S rows they are 22.97 rounds, and each weight matrix is read once per step instead of twice.
+    PAIR_MAX_OPERAND_BYTES = (1 << 32) - 1     # the GEMM kernels keep 32-bit per-lane byte offsets from the operand base
+
+    def _pair_ok(self) -> bool:
+        n2 = 2 * self.plan.n_tok
+        return (self.cfg_batch and not self.sp_on and not self._graphs_on and not self._native_eligible() and not self.dual_stream
+                and n2 * max(self.cfg.dim, self.cfg.ffn_dim) * 2 <= self.PAIR_MAX_OPERAND_BYTES)
+
+    def _pair_engine(self):
+        """Twin of this engine whose workspace holds 2n rows (weights and caches by reference)."""
+        if getattr(self, "_pair", None) is None:
+            import copy
+            cfg, a, n2, d = self.cfg, self.ops.alloc, 2 * self.plan.n_tok, self.cfg.dim
+            t = copy.copy(self)
+            t._pair, t._twin, t._native, t._graphs, t._graphs_on, t.native_forward = None, None, None, {}, False, False
+            t.x, t.h, t.qkv = a((n2, d), F32), a((n2, d), BF16), a((3, n2, d), BF16)
+            t.att, t.ff = a((n2, d), BF16), a((n2, cfg.ffn_dim), BF16)
+            if self.fp8:
+                t.h8, t.h8s = a((n2, d), FP8), a((n2,), F32)
+                t.att8, t.att8s = a((n2, d), FP8), a((n2,), F32)
+                t.ff8, t.ff8s = a((n2, cfg.ffn_dim), FP8), a((n2,), F32)
+            self._pair = t
+        return self._pair
+
+    def forward_pair(self, latent: torch.Tensor, ctx_c: ContextKV, ctx_u: ContextKV, timestep: float,
+                     buf_tokens: Optional[torch.Tensor], head_out2: torch.Tensor, share_stem: bool = False):
+        """Both CFG forwards of a step: head_out2 f32 [2, n, out_dim*4] (slot 0 = cond, 1 = uncond).  ``share_stem``: layer 0's
+        self-attention block is computed once on n rows (it sees nothing of the context) and duplicated, as
+        forward_tokens(stem="save" / "load") does for sequential forwards."""
+        cfg, ops, plan = self.cfg, self.ops, self.plan
+        d, H, n, eps, scale = cfg.dim, cfg.num_heads, plan.n_tok, cfg.eps, self.attn_scale
+        if (self.cond_w is not None) and buf_tokens is None:
+            raise ValueError("i2v DiT: pass the cached embed_cond_latents(y) tokens as buf_tokens")
+        for ctx in (ctx_c, ctx_u):
+            if cfg.has_image_input != (ctx.k_img is not None):
+                raise ValueError("context was encoded without/with CLIP features but the DiT is/isn't i2v")
+        self._time_state(timestep)
+        t = self._pair_engine()
+        t.mod, t.hmod = self.mod, self.hmod
+        halves = (slice(0, n), slice(n, 2 * n))
+        # K1 once: both branches start from the same tokens
+        ops.patchify(latent, self.patches, plan.tok0, n)
+        if buf_tokens is not None:
+            ops.gemm(self.patches, self.patch_w, self.patch_b, t.x[halves[0]], EPI_RESID_F32, resid=buf_tokens)
+        else:
+            ops.gemm(self.patches, self.patch_w, self.patch_b, t.x[halves[0]], EPI_F32)
+        q, k, v = t.qkv[0], t.qkv[1], t.qkv[2]
+
+        def self_attention_block(lw, sh1, sc1, g1, rows_list, rows_all):
+            h = t._norm(lw["wqkv"], rows=rows_all, shift=sh1, scale=sc1, eps=eps)                       # K3
+            if rows_all is None:
+                t._mm(h, lw["wqkv"], lw["bqkv"], t.qkv, EPI_BF16, nsplit=d)                             # K4, 2n rows
+            else:   # n rows into the first half of each plane: three plain GEMMs keep the [3, 2n, d] plane layout
+                for j in range(3):
+                    t._mm(h, lw["wqkv"], lw["bqkv"], t.qkv[j][rows_all], EPI_BF16, rows=slice(j * d, (j + 1) * d))
+            for r in rows_list:
+                ops.rmsnorm_rope(q[r], lw["nq"], k[r], lw["nk"], eps=eps, rope=self.rope, tok0=plan.tok0)   # K5
+                if self.attn8_ws is not None:
+                    ops.attention_fp8(q[r], k[r], v[r], t.att[r], H, self.attn8_ws)                     # K6 (e4m3)
+                else:
+                    ops.attention(q[r], k[r], v[r], t.att[r], H, scale)                                 # K6
+            a = t._operand(t.att, t.att8, t.att8s, lw["wo"], rows=rows_all)
+            xr = t.x if rows_all is None else t.x[rows_all]
+            t._mm(a, lw["wo"], lw["bo"], xr, EPI_RESID_F32, resid=xr, gate=g1)                          # K7
+
+        for i in range(cfg.num_layers):
+            lw = self.layers[i]
+            m = self.mod[i]
+            sh1, sc1, g1 = m[0:d], m[d:2 * d], m[2 * d:3 * d]
+            sh2, sc2, g2 = m[3 * d:4 * d], m[4 * d:5 * d], m[5 * d:6 * d]
+            if i == 0 and share_stem:
+                self_attention_block(lw, sh1, sc1, g1, [halves[0]], halves[0])
+                t.x[halves[1]].copy_(t.x[halves[0]])
+            else:
+                if i == 0:
+                    t.x[halves[1]].copy_(t.x[halves[0]])
+                self_attention_block(lw, sh1, sc1, g1, halves, None)
+            # --- cross-attention: one projection over 2n rows, each half against its own context ---
+            h = t._norm(lw["xq_w"], weight=lw["n3w"], bias=lw["n3b"], eps=eps)                          # K8
+            t._mm(h, lw["xq_w"], lw["xq_b"], q, EPI_BF16)                                               # K9
+            ops.rmsnorm_rope(q, lw["xnq"], eps=eps)
+            for r, ctx in zip(halves, (ctx_c, ctx_u)):
+                ops.attention(q[r], ctx.k[i], ctx.v[i], t.att[r], H, scale)
+                if ctx.k_img is not None:
+                    ops.attention_add(q[r], ctx.k_img[i], ctx.v_img[i], t.att[r], H, scale)
+            a = t._operand(t.att, t.att8, t.att8s, lw["xo_w"])
+            t._mm(a, lw["xo_w"], lw["xo_b"], t.x, EPI_RESID_F32, resid=t.x)
+            # --- FFN over 2n rows ---
+            h = t._norm(lw["f0_w"], shift=sh2, scale=sc2, eps=eps)                                      # K3
+            t._mm(h, lw["f0_w"], lw["f0_b"], t.ff, EPI_GELU_BF16)                                       # K10
+            a = t._operand(t.ff, t.ff8, t.ff8s, lw["f2_w"])
+            t._mm(a, lw["f2_w"], lw["f2_b"], t.x, EPI_RESID_F32, resid=t.x, gate=g2)
+        # K11: head over 2n rows
+        ops.ln_modulate(t.x, t.h, shift=self.hmod[0], scale=self.hmod[1], eps=eps)
+        ops.gemm(t.h, self.head_w, self.head_b, head_out2.view(2 * n, -1), EPI_F32)
+
+    # ------------------------------------------------------------------------------------
     def _cfg_twin(self):
         """Second engine for the dual-stream CFG mode: shares every weight tensor, owns a workspace and a stream."""
         if getattr(self, "_twin", None) is None:
@@ -676,6 +784,8 @@ class WanDiT:
                     twin.forward_tokens(latent, ctx_uncond, ts, buf_tokens, self.head_out[1])
                 self.forward_tokens(latent, ctx_cond, ts, buf_tokens, self.head_out[0])
                 main.wait_stream(side)
+            elif use_cfg and self._pair_ok():
+                self.forward_pair(latent, ctx_cond, ctx_uncond, ts, buf_tokens, self.head_out, share_stem=self.share_stem)
             else:
                 share = use_cfg and self.share_stem
                 self.forward_tokens(latent, ctx_cond, ts, buf_tokens, self.head_out[0], stem="save" if share else None)

@@ -516,6 +516,36 @@ def test_native_forward_matches_python_driver(hip_ops, name, mode):
     assert hip_ops.lib.icv_dit_create(ctypes.byref(bad), ctypes.byref(hh)) != 0
 
 
+@pytest.mark.parametrize("name,mode", [("tiny", "bf16"), ("small", "bf16"), ("tiny-i2v", "bf16"), ("tiny", "fp8"), ("tiny-i2v", "fp8")])
+def test_cfg_batched_forward_pair_is_bit_identical(hip_ops, name, mode):
+    """The two CFG forwards of a step as ONE batch of 2n rows (WanDiT.forward_pair, the single-rank default) against two
+    sequential forwards on the HIP kernels: every token-local kernel computes a row independently of the row count and the
+    branch-specific launches (RoPE, self-attention, cross-attention) see the same operands, so a whole CFG loop is
+    bit-identical — with and without the shared stem."""
+    cfg, grid = preset(name), (TokenGrid(17, 128, 160) if name == "small" else TokenGrid(9, 64, 96))
+    sd, bsd = syn.make_dit_state_dict(cfg), syn.make_buffer_embedder_state_dict(cfg)
+    noise, c1, c2, bl = syn.make_latent_noise(grid), syn.make_text_context(cfg, 1), syn.make_text_context(cfg, 2), syn.make_buffer_latents(cfg, grid)
+    clip = syn.make_clip_features(cfg) if cfg.has_image_input else None
+    y = syn.make_cond_latents(cfg, grid) if cfg.has_image_input else None
+    kw = dict(gemm_dtype="fp8", attn_dtype="fp8", fp8_weights=WanDiT.FP8_WEIGHTS) if mode == "fp8" else {}
+    res = {}
+    for batch in (False, True):
+        for share in (False, True):
+            m = WanDiT(cfg, sd, hip_ops, bsd, **kw).prepare(grid, graphs=False)
+            m.cfg_batch, m.share_stem = batch, share
+            add = m.embed_buffers(bl)
+            if y is not None:
+                add = m.embed_cond_latents(y, add_to=add)
+            lat = noise.clone().to("cuda:0")
+            m.denoise(lat, m.encode_context(c1, clip), m.encode_context(c2, clip), add, FlowMatchScheduler(3), 5.0)
+            torch.cuda.synchronize()
+            assert (m._pair is not None) == batch
+            res[(batch, share)] = lat.cpu()
+    assert torch.isfinite(res[(True, False)]).all()
+    for k, v in res.items():
+        assert torch.equal(v, res[(False, False)]), f"cfg_batch / share_stem = {k} changes the result"
+
+
 def test_native_forward_under_graph_replay(hip_ops):
     """icv_dit_forward inside hipGraph capture (graphs=True: every forward after the first is a replay): the C driver only
     enqueues on the capture stream, so the replayed loop equals the eager per-op loop bit for bit."""

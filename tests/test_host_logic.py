@@ -348,6 +348,34 @@ def test_gloo_cfg_branch_parallel_equals_single(world, mode, kv_exchange):
                        branch_exchange=lambda a, b: None)
 
 
+@pytest.mark.parametrize("name,kw", [("tiny", {}), ("tiny-i2v", {}), ("tiny", dict(gemm_dtype="fp8", attn_dtype="fp8", fp8_weights=WanDiT.FP8_WEIGHTS))])
+def test_cfg_batched_forward_pair_equals_sequential_forwards(name, kw):
+    """WanDiT.forward_pair (the two CFG forwards of a step as one batch of 2n rows through every token-local op) against two
+    sequential forwards, with and without the shared stem: same per-row arithmetic, so the latents of a loop are identical."""
+    cfg = preset(name)
+    sd, bsd = syn.make_dit_state_dict(cfg), syn.make_buffer_embedder_state_dict(cfg)
+    noise, c1, c2, bl = syn.make_latent_noise(GRID), syn.make_text_context(cfg, 1), syn.make_text_context(cfg, 2), syn.make_buffer_latents(cfg, GRID)
+    clip = syn.make_clip_features(cfg) if cfg.has_image_input else None
+    y = syn.make_cond_latents(cfg, GRID) if cfg.has_image_input else None
+    res = {}
+    for batch in (False, True):
+        for share in (False, True):
+            m = WanDiT(cfg, sd, OracleOps(), bsd, **kw).prepare(GRID)
+            m.cfg_batch, m.share_stem = batch, share
+            add = m.embed_buffers(bl)
+            if y is not None:
+                add = m.embed_cond_latents(y, add_to=add)
+            lat = noise.clone()
+            m.denoise(lat, m.encode_context(c1, clip), m.encode_context(c2, clip), add, FlowMatchScheduler(3), 5.0)
+            assert (m._pair is not None) == batch, "forward_pair must be the path taken exactly when cfg_batch is on"
+            res[(batch, share)] = lat
+    for k, v in res.items():
+        assert torch.equal(v, res[(False, False)]), f"cfg_batch / share_stem = {k} changes the result"
+    m = WanDiT(cfg, sd, OracleOps(), bsd, **kw).prepare(GRID)
+    m.PAIR_MAX_OPERAND_BYTES = 1000                      # a workload whose 2n-row operands would pass the 4 GiB offset limit
+    assert not m._pair_ok()
+
+
 def test_bench_fails_loudly_without_a_gpu():
     """bench.py measures the HIP path or nothing: on a box without a GPU the plain form and the self-launching N-rank form
     exit non-zero within seconds, print no JSON line (there is no CPU fallback to time), and the launcher names the rank
