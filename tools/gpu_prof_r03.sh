@@ -30,15 +30,18 @@ def label(name, grid, dur_us):
         return "self-attention (K6)" if dur_us > 3000 else "cross-attention (K9)"
     if "gemm256" in name and DIMS:
         d, f, _ = DIMS
-        tiles_m = (S + 255) // 256
         epi = re.search(r"gemm256_kernel<(\d)", name)
         epi = int(epi.group(1)) if epi else -1
-        n_tiles = grid // 512 // tiles_m if grid % (512 * tiles_m) == 0 else None
-        N = n_tiles * 256 if n_tiles else None
-        if epi == 0 and N == 3 * d: return f"QKV GEMM [S,{d}]x[{3*d},{d}] (K4)"
-        if epi == 0 and N == d: return f"cross-q GEMM [S,{d}]x[{d},{d}] (K9)"
-        if epi == 1: return f"FFN1 GEMM + GELU [S,{d}]x[{f},{d}] (K10)"
-        if epi == 2 and N == d: return f"O / cross-O / FFN2 GEMM + gated residual, N={d} (K7/K9/K10)"
+        N, rows = None, "S"
+        for mult, tag in ((2, "2S"), (1, "S")):        # 2S rows = the CFG-batched forward pair (the single-rank default)
+            tiles_m = (mult * S + 255) // 256
+            if grid % (512 * tiles_m) == 0 and (grid // 512 // tiles_m) * 256 in (d, 3 * d, f):
+                N, rows = (grid // 512 // tiles_m) * 256, tag
+                break
+        if epi == 0 and N == 3 * d: return f"QKV GEMM [{rows},{d}]x[{3*d},{d}] (K4)"
+        if epi == 0 and N == d: return f"cross-q GEMM [{rows},{d}]x[{d},{d}] (K9)"
+        if epi == 1: return f"FFN1 GEMM + GELU [{rows},{d}]x[{f},{d}] (K10)"
+        if epi == 2 and N == d: return f"O / cross-O / FFN2 GEMM + gated residual, {rows} rows, N={d} (K7/K9/K10)"
         return f"gemm256 epi {epi} N={N}"
     return name
 def groups(path_glob, with_counters=False):
@@ -92,9 +95,10 @@ for key, v in sorted(st.items(), key=lambda kv: -sum(kv[1]["dur"])):
     if DIMS:
         d, ffn, _ = DIMS
         fl = {"self-attention (K6)": 4.0 * S * S * d, "cross-attention (K9)": 4.0 * S * 512 * d}.get(key[1])
-        if "QKV GEMM" in key[1]: fl = 6.0 * S * d * d
-        if "cross-q GEMM" in key[1]: fl = 2.0 * S * d * d
-        if "FFN1" in key[1]: fl = 2.0 * S * d * ffn
+        rows_mult = 2.0 if "[2S," in key[1] else 1.0
+        if "QKV GEMM" in key[1]: fl = 6.0 * S * d * d * rows_mult
+        if "cross-q GEMM" in key[1]: fl = 2.0 * S * d * d * rows_mult
+        if "FFN1" in key[1]: fl = 2.0 * S * d * ffn * rows_mult
         if fl: r["algorithmic_tflops"] = fl / (r["avg_us"] * 1e-6) / 1e12
     rows.append(r)
 out = {"model": model, "command": f"python bench.py --model {model} --steps 1 --warmup 1 --no-cpu-baseline (2 denoise steps incl. warm-up)",
