@@ -39,7 +39,8 @@ int icv_device_info(int device, int64_t out[4]);
 
 /* Kernel-variant switches for A/B measurement; defaults = shipped configuration.  "gemm256" = 0 | 1 | 2 (heuristic),
  * "gemm256_mfma" = 16 | 32, "gemm256_sched" = bit 0: two 32-MFMA phases per K-tile, bit 1: batched residual loads (default 3;
- * 7 = + B1 requested a full tile ahead, 11 = + serpentine MFMA order: both measured ties), "gemm256_gm" (tile-group size),
+ * 7 = + B1 requested a full tile ahead, 11 = + serpentine MFMA order: both measured ties; + 16 / + 32 = non-temporal DMA of the
+ * activation / weight stream: measured losses, profiles/r03/gemm_cache_policy_ab.txt), "gemm256_gm" (tile-group size),
  * "gemm_fp8_sched" = 3 (default) | 0 (round 1's four-phase loop), "attn_kernel" = 7 (attn7.hip, default) | 2 (attn2.hip);
  * attention families 1, 3..6, 9 and "gemm256" = 3 | 4 (the two 4-wave GEMMs) are the measured-slower experiments under
  * csrc/experiments/, present only in a library built with ICV_EXPERIMENTS=1 ("require_experiments" returns 0 exactly then),

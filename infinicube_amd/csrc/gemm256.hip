@@ -63,13 +63,15 @@ typedef const __attribute__((address_space(1))) void gbl_void;
   } while (0)
 #define G256_VMCNT8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 
+// AUX = cache policy bits of the DMA load (0 = default; 2 = nt: do not retain in L2 - round 3's A/B, SCH bits 16 / 32)
+template <int AUX = 0>
 __device__ __forceinline__ void dma_unit(const char* __restrict__ base, const unsigned (&off)[2],
                                          int64_t kbyte, char* lds_unit, int wave) {
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const char* src = base + (int64_t)off[q] + kbyte;
     char* dst = lds_unit + q * 8192 + wave * 1024;  // wave-uniform; HW adds lane*16
-    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, AUX);
   }
 }
 
@@ -83,6 +85,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
   constexpr bool SERP = (SCH & 8) != 0;       // MFMA order inside a phase: serpentine over the (a, b) fragment grid
   constexpr bool EARLY_B1 = (SCH & 4) != 0;   // two-phase only: B1 of the next tile is requested with A0/B0 (a full tile ahead), not half a tile
   static_assert(!EARLY_B1 || TWO_PHASE, "EARLY_B1 is a variant of the two-phase schedule");
+  // round 3 A/B (profiles/r03/gemm_cache_policy_ab.txt): non-temporal DMA loads of the activation (bit 16) / weight (bit 32) stream
+  constexpr int AUX_A = (SCH & 16) ? 2 : 0, AUX_B = (SCH & 32) ? 2 : 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -162,13 +166,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
   constexpr int NAF = (MF == 16) ? 4 : 2, NBF = (MF == 16) ? 2 : 1, FROWS = MF * 128;  // frags per half, bytes per frag row block
 
   // ---- prologue: tile 0 complete + A0,B0 of tile 1 ----
-  dma_unit(Ab, offA[0], kbyte(0), smem + U_A0 * UNIT_BYTES, wave);
-  dma_unit(Wb, offB[0], kbyte(0), smem + U_B0 * UNIT_BYTES, wave);
-  dma_unit(Wb, offB[1], kbyte(0), smem + U_B1 * UNIT_BYTES, wave);
-  dma_unit(Ab, offA[1], kbyte(0), smem + U_A1 * UNIT_BYTES, wave);
-  dma_unit(Ab, offA[0], kbyte(1), smem + STAGE_BYTES + U_A0 * UNIT_BYTES, wave);
-  dma_unit(Wb, offB[0], kbyte(1), smem + STAGE_BYTES + U_B0 * UNIT_BYTES, wave);
-  if (EARLY_B1) dma_unit(Wb, offB[1], kbyte(1), smem + STAGE_BYTES + U_B1 * UNIT_BYTES, wave);
+  dma_unit<AUX_A>(Ab, offA[0], kbyte(0), smem + U_A0 * UNIT_BYTES, wave);
+  dma_unit<AUX_B>(Wb, offB[0], kbyte(0), smem + U_B0 * UNIT_BYTES, wave);
+  dma_unit<AUX_B>(Wb, offB[1], kbyte(0), smem + U_B1 * UNIT_BYTES, wave);
+  dma_unit<AUX_A>(Ab, offA[1], kbyte(0), smem + U_A1 * UNIT_BYTES, wave);
+  dma_unit<AUX_A>(Ab, offA[0], kbyte(1), smem + STAGE_BYTES + U_A0 * UNIT_BYTES, wave);
+  dma_unit<AUX_B>(Wb, offB[0], kbyte(1), smem + STAGE_BYTES + U_B0 * UNIT_BYTES, wave);
+  if (EARLY_B1) dma_unit<AUX_B>(Wb, offB[1], kbyte(1), smem + STAGE_BYTES + U_B1 * UNIT_BYTES, wave);
   if (EARLY_B1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // A0(0), B0(0), B1(0) landed (4 younger units in flight)
   else if (TWO_PHASE) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // A0(0), B0(0), B1(0) landed (3 younger units in flight)
   else G256_VMCNT8();     // A0(0), B0(0) landed (4 younger units in flight)
@@ -221,8 +225,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
         for (int i = 0; i < NAF; ++i)
           af[i][ks] = *reinterpret_cast<const bf16x8*>(cur + U_A0 * UNIT_BYTES + a_off[ks] + i * FROWS);
       }
-      if (!EARLY_B1 && !(p.ablate & 1)) dma_unit(Wb, offB[1], kbyte(t + 1), oth + U_B1 * UNIT_BYTES, wave);
-      if (!(p.ablate & 1)) dma_unit(Ab, offA[1], kbyte(t + 1), oth + U_A1 * UNIT_BYTES, wave);
+      if (!EARLY_B1 && !(p.ablate & 1)) dma_unit<AUX_B>(Wb, offB[1], kbyte(t + 1), oth + U_B1 * UNIT_BYTES, wave);
+      if (!(p.ablate & 1)) dma_unit<AUX_A>(Ab, offA[1], kbyte(t + 1), oth + U_A1 * UNIT_BYTES, wave);
       // A1(t) must have landed.  Younger: A0,B0(t+1) + this phase's B1,A1(t+1) = 8 instructions; EARLY_B1: A0,B0,B1(t+1) + A1(t+1) = 8
       asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
       G256_BARRIER();
@@ -235,12 +239,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
 #pragma unroll
         for (int i = 0; i < NAF; ++i)
           af[i][ks] = *reinterpret_cast<const bf16x8*>(cur + U_A1 * UNIT_BYTES + a_off[ks] + i * FROWS);
-      if (!(p.ablate & 1)) dma_unit(Ab, offA[0], kbyte(t + 2), cur + U_A0 * UNIT_BYTES, wave);
-      if (!(p.ablate & 1)) dma_unit(Wb, offB[0], kbyte(t + 2), cur + U_B0 * UNIT_BYTES, wave);
+      if (!(p.ablate & 1)) dma_unit<AUX_A>(Ab, offA[0], kbyte(t + 2), cur + U_A0 * UNIT_BYTES, wave);
+      if (!(p.ablate & 1)) dma_unit<AUX_B>(Wb, offB[0], kbyte(t + 2), cur + U_B0 * UNIT_BYTES, wave);
       if (EARLY_B1) {
         // B1 of this stage was last read in P1(t): re-stage it now, a full tile before P1(t+2) reads it.  A0,B0,B1(t+1)
         // must have landed; younger: A1(t+1) + A0,B0,B1(t+2) = 8 instructions
-        if (!(p.ablate & 1)) dma_unit(Wb, offB[1], kbyte(t + 2), cur + U_B1 * UNIT_BYTES, wave);
+        if (!(p.ablate & 1)) dma_unit<AUX_B>(Wb, offB[1], kbyte(t + 2), cur + U_B1 * UNIT_BYTES, wave);
         asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
       } else
       asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
       for (int i = 0; i < NAF; ++i)
         af[i][ks] = *reinterpret_cast<const bf16x8*>(cur + U_A0 * UNIT_BYTES + a_off[ks] + i * FROWS);
     }
-    dma_unit(Wb, offB[1], kbyte(t + 1), oth + U_B1 * UNIT_BYTES, wave);
+    dma_unit<AUX_B>(Wb, offB[1], kbyte(t + 1), oth + U_B1 * UNIT_BYTES, wave);
     G256_VMCNT8();
     G256_BARRIER();
     G256_MFMA(0, b0f, 0);
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
 #pragma unroll
       for (int j = 0; j < NBF; ++j)
         b1f[j][ks] = *reinterpret_cast<const bf16x8*>(cur + U_B1 * UNIT_BYTES + b_off[ks] + j * FROWS);
-    dma_unit(Ab, offA[1], kbyte(t + 1), oth + U_A1 * UNIT_BYTES, wave);
+    dma_unit<AUX_A>(Ab, offA[1], kbyte(t + 1), oth + U_A1 * UNIT_BYTES, wave);
     G256_VMCNT8();
     G256_BARRIER();
     G256_MFMA(0, b1f, 1);
@@ -285,12 +289,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
 #pragma unroll
       for (int i = 0; i < NAF; ++i)
         af[i][ks] = *reinterpret_cast<const bf16x8*>(cur + U_A1 * UNIT_BYTES + a_off[ks] + i * FROWS);
-    dma_unit(Ab, offA[0], kbyte(t + 2), cur + U_A0 * UNIT_BYTES, wave);
+    dma_unit<AUX_A>(Ab, offA[0], kbyte(t + 2), cur + U_A0 * UNIT_BYTES, wave);
     G256_BARRIER();
     G256_MFMA(1, b1f, 1);
     G256_BARRIER();
     // ---------------- phase 4: a1 x b0 ----------------
-    dma_unit(Wb, offB[0], kbyte(t + 2), cur + U_B0 * UNIT_BYTES, wave);
+    dma_unit<AUX_B>(Wb, offB[0], kbyte(t + 2), cur + U_B0 * UNIT_BYTES, wave);
     G256_VMCNT8();
     G256_BARRIER();
     G256_MFMA(1, b0f, 0);
@@ -417,7 +421,7 @@ int icv_gemm256_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw,
   const bool m32 = icv_get_option_int("gemm256_mfma", 16) == 32;
   // schedule variant (A/B switch "gemm256_sched"): bit 0 = two 32-MFMA phases per K-tile, bit 1 = batched residual loads,
   // bit 2 (with both: 7) = B1 of the next tile requested a full tile ahead
-  const int sch = icv_get_option_int("gemm256_sched", G256_SCHED_DEFAULT) & 15;
+  const int sch = icv_get_option_int("gemm256_sched", G256_SCHED_DEFAULT) & 63;
 #define G256_CASE(E_)                                                                              \
   case E_:                                                                                         \
     if (m32) return (sch & 1) ? g256::launch<E_, 32, 1>(p, st) : g256::launch<E_, 32, 0>(p, st);   \
@@ -427,6 +431,9 @@ int icv_gemm256_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw,
       case 2: return g256::launch<E_, 16, 2>(p, st);                                               \
       case 7: return g256::launch<E_, 16, 7>(p, st);                                               \
       case 11: return g256::launch<E_, 16, 11>(p, st);                                             \
+      case 19: return g256::launch<E_, 16, 19>(p, st);                                             \
+      case 35: return g256::launch<E_, 16, 35>(p, st);                                             \
+      case 51: return g256::launch<E_, 16, 51>(p, st);                                             \
       default: return g256::launch<E_, 16, 3>(p, st);                                              \
     }
   switch (epilogue) {
