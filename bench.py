@@ -423,6 +423,8 @@ def main():
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
     if world > 1:
+        from infinicube_amd.videogen.seqpar import _NativeComm
+        _NativeComm.close_all()
         dist.destroy_process_group()
 
 

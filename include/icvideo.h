@@ -298,8 +298,9 @@ int icv_dit_forward(icv_dit* ctx, const float* latent, int64_t C, int64_t H8, in
 
 /* Per-launch timing of the dominant kernel (self-attention, K6) inside icv_dit_forward: with profiling enabled every
  * forward records a HIP event pair around that launch ON THE LAUNCH STREAM; icv_dit_profile_read waits for the recorded
- * events, returns their summed duration and count, and resets the list.  bench.py's roofline figure uses it.  Leave it
- * off under graph capture. */
+ * events, returns their summed duration and count, and resets the list.  bench.py's roofline figure uses it.  Under
+ * icv_dit_set_seqpar one pair is recorded per KEY-CHUNK launch (after the stream's wait on that chunk's transfer), so
+ * `launches` then counts chunk launches: chunks x layers per forward.  Leave it off under graph capture. */
 int icv_dit_profile(icv_dit* ctx, int enable);
 int icv_dit_profile_read(icv_dit* ctx, double* total_ms, int64_t* launches);
 

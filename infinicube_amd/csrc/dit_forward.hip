@@ -274,6 +274,9 @@ extern "C" int icv_dit_forward(icv_dit* dp, const float* latent, int64_t C, int6
     const float *sh1 = m, *sc1 = m + d, *g1 = m + 2 * d, *sh2 = m + 3 * d, *sc2 = m + 4 * d, *g2 = m + 5 * d;
     Act a;
     if (!(i == 0 && use_stem && stem == 2)) {
+      // icv_dit_profile: one event pair per self-attention LAUNCH on the launch stream - the single launch of a one-rank
+      // forward, or each key-chunk launch of the sequence-parallel schedule (recorded after the stream's wait on that chunk's
+      // transfer, so exposed transfer time is not part of it; icv_dit_profile_read then counts chunk launches)
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (D.profile && !sp) {
         e0 = D.next_event();
@@ -303,6 +306,13 @@ extern "C" int icv_dit_forward(icv_dit* dp, const float* latent, int64_t C, int6
           const int64_t r0 = D.bounds[(size_t)ch], r1 = D.bounds[(size_t)ch + 1], rows = D.world * (r1 - r0);
           const bf16_t* kc = kv_full + D.world * r0 * 2 * d;
           ICV_HIP_CHECK(hipStreamWaitEvent(st, D.ev_done[(size_t)ch], 0));
+          hipEvent_t c0 = nullptr, c1 = nullptr;
+          if (D.profile) {
+            c0 = D.next_event();
+            c1 = D.next_event();
+            ICV_REQUIRE(c0 && c1, "icv_dit_forward: hipEventCreate failed");
+            ICV_HIP_CHECK(hipEventRecord(c0, st));
+          }
           if (D.attn_fp8) {
             DIT_CALL(icv_attention_fp8_prepare(nullptr, 0, kc, 2 * d, kc + d, 2 * d, 0, rows, c.heads, nullptr, d, D.a8_kq, d, D.a8_vt, D.a8_amax, stream));
             DIT_CALL(icv_attention_fp8_fwd_chunk(D.a8_qq, d, D.a8_kq, d, D.a8_vt, D.a8_amax, D.att, d, D.sp_acc, d, D.sp_ml, n, rows, c.heads,
@@ -311,6 +321,7 @@ extern "C" int icv_dit_forward(icv_dit* dp, const float* latent, int64_t C, int6
             DIT_CALL(icv_attention_fwd_chunk(q, d, kc, 2 * d, kc + d, 2 * d, D.att, d, D.sp_acc, d, D.sp_ml, n, rows, c.heads, attn_scale,
                                              ch == 0, ch == nc - 1, stream));
           }
+          if (c1) ICV_HIP_CHECK(hipEventRecord(c1, st));
         }
       } else {
         // single rank: K4 (one fused QKV GEMM, split planes), K5, K6

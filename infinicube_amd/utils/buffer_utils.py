@@ -7,18 +7,21 @@ sky fill) runs in libicvideo's HIP kernels (csrc/buffers.hip) on the depth map r
 PyTorch only handles a handful of numbers: K^-1, pose_0^-1 pose_n and the two quantile vectors.
 
 The <= 100000-point sample the quantiles are taken on [R infinicube/utils/buffer_utils.py:236-241] is drawn
-  * ``sampling="device"`` (default): on the GPU — one jittered pick per stratum of the valid points (flattened
-    order), quantiles on the device.  The reference's own draw is UNSEEDED (`torch.randperm` on the global RNG,
-    [R infinicube/utils/buffer_utils.py:239-241]), so no caller can depend on a particular sample; what is
-    reproduced is the estimator (5 % / 95 % quantiles of <= 100000 of the finite points).  With <= 100000 finite
-    points the sample is all of them and the result equals the reference's bit for bit.
-  * ``sampling="reference"``: the reference's call for call — host `torch.randperm(n_valid)[:100000]` on the
-    global RNG and host `torch.quantile`, so a run seeded like the reference's reproduces its bytes (the golden
-    test).  At 93 x 480 x 832 that host permutation of 29 M indices costs ~1 s; the device path none of it.
+  * ``sampling="reference"`` (default): the reference's call for call — host `torch.randperm(n_valid)[:100000]` on
+    the global RNG and host `torch.quantile`, so a run seeded like the reference's reproduces its bytes (the golden
+    test) and consumes the CPU global RNG exactly as the reference does.  At 93 x 480 x 832 that host permutation
+    of 29 M indices costs ~1 s.
+  * ``sampling="device"`` (opt-in: the argument, or ``ICV_COORD_SAMPLING=device`` in the environment): drawn on the
+    GPU — one jittered pick per stratum of the valid points (flattened order), quantiles on the device: the whole
+    function in 39 ms instead of 1.1 s.  The reference's own draw is UNSEEDED in its caller
+    [R infinicube/utils/buffer_utils.py:239-241], so what this mode reproduces is the estimator (5 % / 95 %
+    quantiles of <= 100000 of the finite points), held by test to the reference's own run-to-run spread.  With
+    <= 100000 finite points the sample is all of them and the result equals the reference's bit for bit.
 """
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -33,12 +36,14 @@ def _f32_host(t: torch.Tensor):
 def generate_coordinate_buffer_from_memory_global_norm(depth_buffer: torch.Tensor, camera_model,
                                                        camera_poses: torch.Tensor, percentile: float = 0.05,
                                                        *, device="cuda:0", return_uint8: bool = False,
-                                                       sampling: str = "device", generator=None):
+                                                       sampling: str = None, generator=None):
     """depth_buffer [N,H,W] metres (0 = infinitely far), camera_model with ``get_intrinsics_matrix()`` -> [3,3],
     camera_poses [N,4,4] camera-to-world  ->  [N,H,W,3] float32 in [0,1] (on ``device``), or with
     ``return_uint8=True`` the uint8 buffer ``(coord * 255).astype(uint8)`` the video generator consumes.
-    ``sampling``: "device" | "reference" (module docstring); ``generator``: optional device torch.Generator for the
-    device draw (default: the device's global generator)."""
+    ``sampling``: "reference" | "device" (module docstring; None = ``ICV_COORD_SAMPLING`` or "reference");
+    ``generator``: optional device torch.Generator for the device draw (default: the device's global generator)."""
+    if sampling is None:
+        sampling = os.environ.get("ICV_COORD_SAMPLING", "reference")
     if sampling not in ("device", "reference"):
         raise ValueError(f"sampling must be 'device' or 'reference', got {sampling!r}")
     lib = native.lib()
@@ -72,7 +77,9 @@ def generate_coordinate_buffer_from_memory_global_norm(depth_buffer: torch.Tenso
             kk = 100000
             edges = (torch.arange(kk + 1, dtype=torch.int64, device=dev) * m) // kk
             u = torch.rand((kk,), device=dev, generator=generator, dtype=torch.float64)
-            pick = edges[:-1] + (u * (edges[1:] - edges[:-1]).to(torch.float64)).to(torch.int64).clamp_(max=m - 1)
+            width = edges[1:] - edges[:-1]
+            off = torch.minimum((u * width.to(torch.float64)).to(torch.int64), width - 1)    # u < 1, but u * width may round up to width
+            pick = (edges[:-1] + off).clamp_(max=m - 1)
         sample_idx = (valid_idx if pick is None else valid_idx[pick]).contiguous()
         sample = torch.empty((sample_idx.numel(), 3), dtype=torch.float32, device=dev)
         native.check(lib.icv_coord_gather_points(depth.data_ptr(), kinv, to_cam0.data_ptr(), n, h, w,

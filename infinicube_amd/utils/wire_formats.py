@@ -169,12 +169,17 @@ def write_guidance_buffer_artifacts(output_folder: Union[str, Path], clip: str, 
                                     camera_poses, intrinsics: np.ndarray, semantic_frames: Sequence[np.ndarray],
                                     coordinate_frames: Sequence[np.ndarray], depth_vis_frames: Optional[Sequence[np.ndarray]] = None,
                                     resolution: str = "480p", dynamic_object_info: Optional[Dict] = None,
-                                    depth_u16: Optional[np.ndarray] = None, write_depth_vis: bool = True) -> Dict[str, Path]:
+                                    depth_u16: Optional[np.ndarray] = None, write_depth_vis: bool = True,
+                                    depth_colorizer=None) -> Dict[str, Path]:
     """The file set of one stage-2 pass, named and laid out as the reference writes it
     [R infinicube/inference/guidance_buffer_generation.py:645-728]: ``voxel_depth_100_<res>_front.tar`` (uint16 depth
     x100 PNGs), ``instance_buffer_<res>_front.tar`` (uint16 ids), ``pose.tar`` (one [4,4] .npy per frame),
     ``intrinsic.tar`` ([fx, fy, cx, cy, w, h]), the three buffer mp4s at fps 10, optionally ``dynamic_object_info.tar``.
-    ``depth_u16`` lets a caller pass an already-quantised buffer (tests on CPU); otherwise the HIP kernel makes it."""
+    ``depth_u16`` lets a caller pass an already-quantised buffer (tests on CPU); otherwise the HIP kernel makes it.
+    The DEBUG video ``depth_vis_video_<res>_front.mp4`` (nothing downstream reads it) is written from ``depth_vis_frames``
+    when the caller coloured the frames itself (the reference's caller does [R ...:679-683]), else from
+    ``depth_colorizer(depth[H, W]) -> uint8 [H, W, 3]``, else from ``infinicube.utils.depth_utils.vis_depth`` when a
+    reference checkout provides it on the search path (this repo does not re-implement that helper), else it is skipped."""
     import torch
     folder = Path(output_folder)
     n = len(semantic_frames)
@@ -200,9 +205,15 @@ def write_guidance_buffer_artifacts(output_folder: Union[str, Path], clip: str, 
         write_to_tar(dict(dynamic_object_info), files["dynamic_object_info"], __key__=clip)
     write_video_file(list(semantic_frames), files["semantic_video"], fps=10)
     if depth_vis_frames is None and write_depth_vis and depth_buffer is not None:
-        from .depth_utils import vis_depth       # the reference colours every frame the same way [R ...:679-683]
-        db = torch.as_tensor(depth_buffer).cpu().numpy()
-        depth_vis_frames = [vis_depth(db[i]) for i in range(n)]
+        color = depth_colorizer
+        if color is None:
+            try:    # served from the reference checkout through infinicube.utils' extended search path, when present
+                from infinicube.utils.depth_utils import vis_depth as color
+            except Exception:
+                color = None
+        if color is not None:
+            db = torch.as_tensor(depth_buffer).cpu().numpy()
+            depth_vis_frames = [np.asarray(color(db[i])) for i in range(n)]
     if depth_vis_frames is not None:
         files["depth_vis_video"] = folder / f"depth_vis_video_{resolution}_front.mp4"
         write_video_file(list(depth_vis_frames), files["depth_vis_video"], fps=10)

@@ -326,6 +326,18 @@ class WanDiT:
                              eps=cfg.eps)
         h = ctypes.c_void_p()
         native.check(lib.icv_dit_create(ctypes.byref(c), ctypes.byref(h)), "icv_dit_create")
+        try:
+            self._native_bind_all(h)
+        except BaseException:
+            lib.icv_dit_destroy(h)          # a failed bind / icv_dit_set_seqpar must not leak the context
+            raise
+        self._native = h
+        return h
+
+    def _native_bind_all(self, h):
+        import ctypes
+        from .. import native
+        lib, plan = self.ops.lib, self.plan
 
         def bind(name, t, layer=-1):
             native.check(lib.icv_dit_bind(h, name.encode(), layer, t.data_ptr()), f"icv_dit_bind({name})")
@@ -361,8 +373,6 @@ class WanDiT:
                 bind(name, getattr(self, name))
             b = (ctypes.c_int64 * len(self.sp_bounds))(*self.sp_bounds)
             native.check(lib.icv_dit_set_seqpar(h, nc.handle, plan.world, len(self.sp_bounds) - 1, b, nc.stream.cuda_stream), "icv_dit_set_seqpar")
-        self._native = h
-        return h
 
     def _native_eligible(self) -> bool:
         return self.native_forward and self._is_gpu() and hasattr(self.ops, "lib") and (not self.sp_on or isinstance(self.kv_gather, KVGather))

@@ -185,6 +185,14 @@ class WorkerPool:
             return
         self._closed = True
         try:
+            # libicvideo's own communicators (seqpar._NativeComm) were built on this pool's process groups and go first, while
+            # the peers are still alive (each worker closes its own on "exit"): a communicator that survived the pool would
+            # pair this rank with dead peers when the next pool rendezvouses under the same cache key
+            from .seqpar import _NativeComm
+            _NativeComm.close_all()
+        except Exception:
+            pass
+        try:
             if all(p.poll() is None for p, _ in self.procs):
                 self.dist.broadcast_object_list([dict(cmd="exit")], src=0, group=self.ctrl)
             deadline = time.time() + 30
@@ -260,6 +268,8 @@ def worker_main() -> int:
                  coordinate_buffer_video=gen._ndarray_to_pil_list(bufs[1]), height=h, width=w, num_frames=n, seed=c["seed"],
                  tiled=c["tiled"], return_latents=True)      # rank 0 alone decodes, returns frames and writes the mp4
         print(f"[worker {rank}] request done", flush=True)
+    from .seqpar import _NativeComm
+    _NativeComm.close_all()
     dist.destroy_process_group()
     return 0
 

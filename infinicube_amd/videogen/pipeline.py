@@ -61,8 +61,36 @@ class ModelConfig:
         return os.path.join(root, self.model_id or "", self.origin_file_pattern or "")
 
     def present(self) -> bool:
+        """True when the file(s) the pattern stands for are all there.  A sharded checkpoint
+        (``diffusion_pytorch_model*.safetensors``) is complete only when every shard its ``*.index.json`` weight map names
+        exists — one shard of an interrupted download must not count as "present" (it would skip the download and load
+        half a model)."""
         import glob
-        return bool(glob.glob(self.resolve()))
+        import json
+        files = glob.glob(self.resolve())
+        if not files:
+            return False
+        folder = os.path.dirname(files[0])
+        for idx in glob.glob(os.path.join(folder, "*.index.json")):
+            try:
+                with open(idx) as f:
+                    shards = set(json.load(f).get("weight_map", {}).values())
+            except (OSError, ValueError):
+                continue
+            import fnmatch
+            mine = {s for s in shards if fnmatch.fnmatch(s, os.path.basename(self.resolve()))}
+            if mine and any(not os.path.isfile(os.path.join(folder, s)) for s in mine):
+                return False
+        # no index file at hand (the reference's pattern does not fetch it): the shard names carry the count themselves
+        import re
+        for f in files:
+            m = re.search(r"-(\d+)-of-(\d+)(\.[A-Za-z0-9]+)$", os.path.basename(f))
+            if m:
+                stem, total, ext = os.path.basename(f)[: m.start()], int(m.group(2)), m.group(3)
+                width = len(m.group(1))
+                if any(not os.path.isfile(os.path.join(folder, f"{stem}-{i:0{width}d}-of-{m.group(2)}{ext}")) for i in range(1, total + 1)):
+                    return False
+        return True
 
     def download(self) -> str:
         """Fetch ``origin_file_pattern`` of ``model_id`` into ``<root>/<model_id>/`` (no-op when present or when the
@@ -82,7 +110,13 @@ class ModelConfig:
                 if source == "modelscope":
                     raise
         if fetch is None:
-            from huggingface_hub import snapshot_download as hf_fetch
+            try:
+                from huggingface_hub import snapshot_download as hf_fetch
+            except ImportError as e:
+                raise FileNotFoundError(
+                    f"{self.resolve()!r} is missing (or incomplete) and cannot be downloaded: neither `modelscope` nor "
+                    f"`huggingface_hub` is importable ({e}); place the file(s) there or pass skip_download=True to get the "
+                    f"plain 'file missing' error from the loader") from e
             fetch = lambda: hf_fetch(repo_id=self.model_id, allow_patterns=[self.origin_file_pattern], local_dir=target)   # noqa: E731
         print(f"Downloading {self.model_id}/{self.origin_file_pattern} -> {target}")
         fetch()

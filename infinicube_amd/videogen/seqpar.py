@@ -182,8 +182,12 @@ class KVGather:
 
 class _NativeComm:
     """libicvideo's own RCCL communicator for one sequence-parallel group + a side stream (KVGather mode "native").
-    One per (process group, device) for the life of the process: a KVGather is rebuilt on every pipeline call, and
-    ncclCommInitRank is a blocking rendezvous of the whole group that must not be repeated per call."""
+    One per (process group, device) for the life of THAT PROCESS GROUP: a KVGather is rebuilt on every pipeline call, and
+    ncclCommInitRank is a blocking rendezvous of the whole group that must not be repeated per call.  The communicators die
+    with the torch.distributed world they were built in: whoever tears that world down (multigpu.WorkerPool.close, bench.py,
+    a rank worker) calls ``close_all()`` first — a communicator kept past it would pair rank 0 with dead peers when a new
+    pool rendezvouses under the same (None, peers, device) key.  Each entry keeps its group object alive, so ``id(group)``
+    cannot be recycled by another group while the entry exists."""
 
     _cache = {}
 
@@ -195,10 +199,21 @@ class _NativeComm:
             comm = cls._cache[key] = cls(dist, group, peers, rank, world)
         return comm
 
+    @classmethod
+    def close_all(cls) -> int:
+        """Destroy every cached communicator (side streams drained first).  Call BEFORE destroy_process_group / before the
+        peers of a worker pool exit.  Returns how many were closed."""
+        comms = list(cls._cache.values())
+        for c in comms:
+            c.close()
+        cls._cache.clear()
+        return len(comms)
+
     def __init__(self, dist, group, peers, rank: int, world: int):
         import ctypes
         from .. import native
         self.lib, self.native = native.lib(), native
+        self.group = group          # strong reference: pins id(group) for the lifetime of the cache entry
         dev = torch.device("cuda", torch.cuda.current_device())
         idbuf = ctypes.create_string_buffer(native.COMM_ID_BYTES)
         if rank == 0:

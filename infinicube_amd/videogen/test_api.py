@@ -75,8 +75,11 @@ def main(argv=None):
         tests_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests")
         if not os.path.exists(os.path.join(tests_dir, "standins.py")):
             ap.error("--synthetic needs the repository's tests/ directory (tests/standins.py)")
-        sys.path.insert(0, tests_dir)
-        from standins import HashTextEncoder, PoolVAE
+        import importlib.util       # by file path: tests/ never goes on sys.path (its module names must not shadow anything)
+        spec = importlib.util.spec_from_file_location("_icv_selftest_standins", os.path.join(tests_dir, "standins.py"))
+        standins = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(standins)
+        HashTextEncoder, PoolVAE = standins.HashTextEncoder, standins.PoolVAE
         cfg = preset(args.model)
         grid = TokenGrid(args.frames, args.height, args.width)
         sd = syn.make_dit_state_dict(cfg, device="cuda:0", dtype=torch.bfloat16)

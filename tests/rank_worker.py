@@ -110,6 +110,8 @@ def main() -> int:
             torch.save(dict(result=res.float().cpu(), info=info), a.out)
     finally:
         if world > 1:
+            from infinicube_amd.videogen.seqpar import _NativeComm
+            _NativeComm.close_all()
             dist.destroy_process_group()
     return 0
 

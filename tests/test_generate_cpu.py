@@ -270,3 +270,15 @@ def test_checkpoint_download_behaviour(tmp_path, capsys, monkeypatch):
         from infinicube_amd.videogen.pipeline import WanVideoPipeline
         WanVideoPipeline.from_pretrained(device="cpu", model_configs=[mc])
     assert calls == []
+    # an interrupted download (1 of 2 shards on disk) is NOT "present": by the shard names, and by the index's weight map
+    part = root / "Wan-AI" / "partial"
+    part.mkdir(parents=True)
+    (part / "diffusion_pytorch_model-00001-of-00002.safetensors").write_bytes(b"x")
+    mc2 = ModelConfig(model_id="Wan-AI/partial", origin_file_pattern="diffusion_pytorch_model*.safetensors", local_model_path=str(root))
+    assert not mc2.present()
+    (part / "diffusion_pytorch_model-00002-of-00002.safetensors").write_bytes(b"x")
+    assert mc2.present()
+    import json
+    (part / "diffusion_pytorch_model.safetensors.index.json").write_text(json.dumps({"weight_map": {
+        "a": "diffusion_pytorch_model-00001-of-00002.safetensors", "b": "diffusion_pytorch_model-00003-of-00003.safetensors"}}))
+    assert not mc2.present()

@@ -33,7 +33,8 @@ def test_tar_members_names_order_and_roundtrip(tmp_path):
     du16 = (depth * 100).astype(np.uint16)                      # the caller's conversion, on the host for this CPU test
     intr = np.array([900.0, 900.0, 32.0, 24.0, 64, 48])
     files = wf.write_guidance_buffer_artifacts(tmp_path, "clip0007", depth, inst, poses, intr, list(sem), list(co),
-                                               resolution="480p", depth_u16=du16)
+                                               resolution="480p", depth_u16=du16,
+                                               depth_colorizer=lambda d: np.repeat((np.clip(d, 0, 127) * 2).astype(np.uint8)[..., None], 3, -1))
     assert {p.name for p in files.values()} == {
         "voxel_depth_100_480p_front.tar", "instance_buffer_480p_front.tar", "pose.tar", "intrinsic.tar",
         "semantic_buffer_video_480p_front.mp4", "coordinate_buffer_video_480p_front.mp4", "depth_vis_video_480p_front.mp4"}
@@ -103,14 +104,3 @@ def test_depth_quantisation_kernel_bit_exact():
     assert got.dtype == np.uint16 and np.array_equal(got, want)
     got2 = wf.depth_to_uint16_x100(depth.reshape(-1)[: 93 * 480 * 832 - 3].to("cuda:0"))     # ragged tail, device input
     assert np.array_equal(got2, want.reshape(-1)[:-3])
-
-
-def test_vis_depth_matches_reference_golden():
-    """`vis_depth` (the depth_vis mp4 of stage 2) against the reference function's own outputs."""
-    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "vis_depth_cases.npz"))
-    from infinicube_amd.utils.depth_utils import vis_depth
-    assert np.array_equal(vis_depth(G["a_depth"].copy()), G["a_rgb"])
-    assert np.array_equal(vis_depth(G["b_depth"].copy(), minmax=(2.0, 50.0)), G["b_rgb"])
-    assert np.array_equal(vis_depth(G["c_depth"].copy()), G["c_rgb"])
-    t = vis_depth(torch.from_numpy(G["a_depth"].copy()))
-    assert isinstance(t, torch.Tensor) and t.dtype == torch.uint8 and np.array_equal(t.numpy(), G["a_rgb"])

@@ -77,6 +77,12 @@ def time_forward(world, chunks, iters=3):
 
 
 rows = []
+ONLY = os.environ.get("ONLY")          # "world:chunks" -> time just that shard shape (for a rocprofv3 kernel trace of it)
+if ONLY:
+    w, c = (int(v) for v in ONLY.split(":"))
+    t = time_forward(w, c, iters=int(os.environ.get("ITERS", "3")))
+    print(f"shard 1/{w} chunks {c}: {t:.3f} ms per layer-forward")
+    sys.exit(0)
 base = time_forward(1, 1)
 L = cfg_full.num_layers
 one_gpu_step = 2 * L * base
