@@ -11,7 +11,13 @@ named architecture, non-zero guidance-buffer tokens, inputs resident in HBM befo
            --master-port P bench.py --gpus N --steps K --warmup W
 
 N > 1 = token-sequence parallelism (strong scaling: the same 37,440-token video is split over the
-ranks; per-layer RCCL all-gather of K/V).  Rank 0 prints ONE JSON line.
+ranks; per-layer RCCL all-gather of K/V).  Rank 0 prints ONE JSON line — ALWAYS: for N > 1 every rank the
+launcher starts is a supervisor (infinicube_amd/videogen/launch_guard.py) that runs the real rank as a child,
+watches its phases (init / groups / setup / autotune / warmup / timed / report) against a budget, and on a raised
+error or a hung phase moves all ranks to the next plan:  requested layout + measured K|V transport  ->  the same
+layout with plain all_gather  ->  `sp` on the world group with all_gather (no sub-groups at all)  ->  a JSON line
+with "error", the plan / rank / phase that failed and the worker's message, exit code 1.  `multi_gpu` records which
+plan ran and what failed before it.
 """
 from __future__ import annotations
 
@@ -32,12 +38,13 @@ import torch  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from infinicube_amd.videogen import launch_guard as guard  # noqa: E402
 from infinicube_amd.videogen import synthetic as syn  # noqa: E402
 from infinicube_amd.videogen.config import GRID_480P, TokenGrid, dit_forward_flops, preset  # noqa: E402
 from infinicube_amd.videogen.dit import WanDiT  # noqa: E402
 from infinicube_amd.videogen.ops import HipOps  # noqa: E402
 from infinicube_amd.videogen.scheduler import FlowMatchScheduler  # noqa: E402
-from infinicube_amd.videogen.seqpar import BranchExchange, ParallelLayout  # noqa: E402
+from infinicube_amd.videogen.seqpar import BranchExchange, ParallelLayout, autotune_kv_exchange  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_FP8_TFLOPS = 5000.0    # dense fp8 (K=64/128 scaled) MFMA peak, same guide
@@ -140,7 +147,10 @@ def self_launch(n: int) -> int:
     return rc
 
 
-def main():
+METRIC = "denoise steps/sec, 93-frame 480p Wan2.1 buffer-conditioned DiT loop"
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -162,9 +172,13 @@ def main():
     ap.add_argument("--parallelism", default=os.environ.get("ICV_PARALLELISM", "auto"), choices=["auto", "sp", "cfg+sp"],
                     help="N>1: 'sp' = token shards over all N ranks, both CFG forwards on every rank; 'cfg+sp' = cond / "
                          "uncond forwards on two groups of N/2 ranks, token shards inside a group (auto when N is even)")
-    ap.add_argument("--kv-exchange", default=os.environ.get("ICV_KV_EXCHANGE", "allgather"), choices=["allgather", "p2p", "native"],
+    ap.add_argument("--kv-exchange", default=os.environ.get("ICV_KV_EXCHANGE", "auto"), choices=["auto", "allgather", "p2p", "native"],
                     help="N>1: K|V rows travel by all_gather_into_tensor (RCCL's schedule) or by grouped send/recv to every "
-                         "peer (the direct, fully-connected schedule), or by libicvideo's own RCCL communicator (icv_allgather_kv; seqpar.KVGather)")
+                         "peer (the direct, fully-connected schedule), or by libicvideo's own RCCL communicator (icv_allgather_kv; "
+                         "seqpar.KVGather); 'auto' (default) = a start-up autotune times two real layers with each transport x "
+                         "{4, 2} chunks on the ranks of the run and keeps the fastest (the table goes into multi_gpu.autotune)")
+    ap.add_argument("--no-fallback", action="store_true",
+                    help="N>1: run only the requested plan; a failure is reported instead of trying the simpler layouts")
     ap.add_argument("--native-forward", action="store_true",
                     help="drive each forward with ONE icv_dit_forward call (bf16, single GPU) instead of the per-op entry points; bit-identical")
     ap.add_argument("--share-stem", action="store_true",
@@ -173,42 +187,183 @@ def main():
                          "default: the metric's step is two FULL forwards")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def error_record(args, world, message, failed=None, phase=None):
+    """The line a run prints when it could not measure: same keys a reader expects, value null, the reason spelled out."""
+    return {"metric": METRIC, "value": None, "unit": "denoise steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Wan2.1-{args.model.upper()} DiT, {args.frames} frames {args.height}x{args.width}", "model": args.model},
+            "error": message, "failed_phase": phase, "failed_attempts": failed or []}
+
+
+def emit(obj, stdout_fd=None):
+    """THE one line on stdout (fd 1 may have been pointed at stderr for the run: see run_rank)."""
+    sys.stdout.flush()
+    if stdout_fd is not None:
+        os.dup2(stdout_fd, 1)
+    print(json.dumps(obj), flush=True)
+    if stdout_fd is not None:
+        os.dup2(2, 1)
+
+
+def plan_attempts(args, world):
+    """The staged fallback of an N-rank run, most capable plan first (launch_guard.Attempt list)."""
+    def resolved(mode):
+        return ("cfg+sp" if world % 2 == 0 else "sp") if mode == "auto" else mode
+    plans = [(resolved(args.parallelism), args.kv_exchange, args.sp_chunks)]
+    if not args.no_fallback:
+        if args.kv_exchange != "allgather":
+            plans.append((resolved(args.parallelism), "allgather", args.sp_chunks))
+        plans.append(("sp", "allgather", 4))          # no sub-groups, RCCL's own all-gather on the world group
+    seen, out = set(), []
+    for mode, kv, ch in plans:
+        if (mode, kv, ch) in seen:
+            continue
+        seen.add((mode, kv, ch))
+        out.append(guard.Attempt(f"{mode} / kv-exchange {kv} / {ch} chunks",
+                                 {"ICV_BENCH_PLAN": json.dumps(dict(parallelism=mode, kv_exchange=kv, sp_chunks=ch))}))
+    return out
+
+
+def supervise(args, world, rank):
+    """This process is one of the N the launcher started: run the real rank as a child under launch_guard, plan by plan."""
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)                       # nothing but rank 0's one line may reach stdout
+    printed = {"done": False}
+
+    def last_words():                   # the launcher is taking the ranks down (another rank's supervisor died)
+        if rank == 0 and not printed["done"]:
+            printed["done"] = True
+            emit(error_record(args, world, "terminated by the launcher (SIGTERM) before a result existed", phase="supervisor"), stdout_fd)
+
+    guard.install_sigterm(last_words)
+    # per-step bound for the timed / warm-up budgets: generous (a 14B step on ONE GPU is 3.4 s)
+    per_step = float(os.environ.get("ICV_BENCH_STEP_BUDGET_S", "30"))
+    budgets = {"warmup": 240.0 + per_step * args.warmup, "timed": 120.0 + per_step * (args.steps + 1)}
+    try:
+        sup = guard.Supervisor(rank, world, plan_attempts(args, world), [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], budgets=budgets)
+        res = sup.run()
+    except BaseException as e:  # noqa: BLE001 - whatever happens, rank 0 says so on stdout
+        if isinstance(e, SystemExit) and printed["done"]:
+            raise
+        if rank == 0 and not printed["done"]:
+            printed["done"] = True
+            emit(error_record(args, world, f"supervisor failed: {type(e).__name__}: {e}", phase="supervisor"), stdout_fd)
+        return 1
+    if rank == 0:
+        printed["done"] = True
+        if res["ok"]:
+            out = res["result"]
+            out.setdefault("multi_gpu", {})["plan"] = res["plan"]
+            out["multi_gpu"]["failed_attempts"] = res["failed"]      # what was tried before the plan that ran (empty = first plan)
+            emit(out, stdout_fd)
+        else:
+            last = res["failed"][-1] if res["failed"] else {}
+            emit(error_record(args, world, f"every plan failed; last: rank {last.get('rank')} in phase '{last.get('phase')}': {last.get('reason', '')[-600:]}",
+                              failed=res["failed"], phase=last.get("phase")), stdout_fd)
+    # rank 0's line first, THEN anybody leaves: a launcher that sees a rank exit non-zero takes the others down at once
+    try:
+        if rank == 0:
+            sup.store.set("printed", "1")
+        else:
+            t_end = time.time() + 30.0
+            while time.time() < t_end and not sup.store.check(["printed"]):
+                time.sleep(0.1)
+    except Exception:
+        pass
+    return 0 if res["ok"] else 1
+
+
+def main():
+    args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N` (no launcher): become the launcher — one rank per GPU, exactly the processes
         # torch.distributed.run would start — and hand rank 0's JSON line through
-        raise SystemExit(self_launch(args.gpus))
+        rc = self_launch(args.gpus)
+        if rc == 2 and torch.cuda.device_count() < args.gpus:
+            emit(error_record(args, args.gpus, f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) visible", phase="launch"))
+        raise SystemExit(rc)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not guard.supervised() and os.environ.get("ICV_BENCH_GUARD", "1") == "1":
+        raise SystemExit(supervise(args, world, rank))
     if world != args.gpus:
         args.gpus = world        # the launcher's world size is authoritative
+    plan_env = os.environ.get("ICV_BENCH_PLAN")
+    if plan_env:                 # the supervisor's plan for this attempt overrides the command line
+        for k, v in json.loads(plan_env).items():
+            setattr(args, k, v)
+    phase = guard.PhaseReporter(rank)
+    stdout_fd = None
+    try:
+        sys.stdout.flush()
+        stdout_fd = os.dup(1)
+        run_rank(args, world, rank, phase, stdout_fd)
+    except BaseException as e:  # noqa: BLE001
+        if guard.supervised() or isinstance(e, (SystemExit, KeyboardInterrupt)) and not isinstance(e, SystemExit):
+            raise                # under a supervisor the exit code + log ARE the report
+        if isinstance(e, SystemExit) and e.code in (0, None):
+            raise
+        import traceback
+        traceback.print_exc()
+        if rank == 0:
+            emit(error_record(args, world, f"{type(e).__name__}: {e}", phase=phase.current), stdout_fd)
+        raise SystemExit(1)
+
+
+def run_rank(args, world, rank, phase, stdout_fd):
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # stdout carries ONE JSON line and nothing else: native libraries write there too (RCCL's version banner and NCCL_DEBUG
     # output, gloo's "[Gloo] Rank ..." lines), so file descriptor 1 points at stderr for the whole run and is restored for
     # the final print
-    sys.stdout.flush()
-    stdout_fd = os.dup(1)
     os.dup2(2, 1)
+    if not torch.cuda.is_available():
+        raise RuntimeError("no GPU visible to PyTorch-ROCm: the denoising loop has no CPU path")
     # one process per GPU.  ICV_BENCH_SHARE_GPU=1 (+ ICV_DIST_BACKEND=gloo) lets several ranks share the only GPU of a
     # development box so the N>1 code path can be exercised there; it is never a measurement mode.
     share = os.environ.get("ICV_BENCH_SHARE_GPU", "0") == "1"
     dev_index = local_rank % torch.cuda.device_count() if share else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
+        phase("init")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("ICV_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm
+        # an explicit collective timeout: a wedged exchange must end THIS attempt (the supervisor then moves every rank to
+        # the next plan), not sit out torch's 10-minute default
+        dist_timeout = datetime.timedelta(seconds=float(os.environ.get("ICV_BENCH_DIST_TIMEOUT_S", "150")))
         # no device_id: communicators are created lazily on first use (the classic unique-id path).  With device_id
         # PyTorch initialises eagerly and builds the sub-groups of the cfg+sp layout with ncclCommSplit, which this
         # build could not exercise on RCCL; torch.cuda.set_device above already binds the rank to its GPU.
-        dist.init_process_group(backend=backend)
+        dist.init_process_group(backend=backend, timeout=dist_timeout)
+        on_dev = dist.get_backend() == "nccl"
+        one = torch.ones(1, device=device if on_dev else "cpu")
+        dist.all_reduce(one)                         # the world communicator exists (and works) before anything else is built
+        assert int(one.item()) == world
 
     cfg = preset(args.model)
     grid = TokenGrid(args.frames, args.height, args.width)
+    if world > 1:
+        phase("groups")
     layout = ParallelLayout.make(world, rank, args.parallelism, use_cfg=True)
     plan = layout.shard_plan(grid.S)
+    if world > 1:
+        # first collective on every group this rank will use, inside the watched phase: RCCL builds a communicator lazily
+        # at its first use, and that is where a first contact with a new node goes wrong
+        for g in (layout.sp_group, layout.pair_group):
+            if g is not None:
+                m = dist.get_world_size(g)
+                src = torch.full((4,), float(rank), device=device if on_dev else "cpu")
+                dst = torch.empty((4 * m,), device=src.device)
+                dist.all_gather_into_tensor(dst, src, group=g)
+                assert dst.view(m, 4)[:, 0].tolist() == [float(r) for r in dist.get_process_group_ranks(g)], "group smoke test: wrong ranks"
+        phase("setup")
     ops = HipOps(device)
 
     # ---- synthetic weights / inputs, resident in HBM before timing (SURVEY.md §8d recipe) ----
@@ -218,7 +373,9 @@ def main():
     del sd, bsd
     # graphs off: the bench times individual attention launches with events (at the metric's size the loop is GPU-bound
     # and "auto" would not capture anyway)
-    model.prepare(grid, plan, sp_chunks=args.sp_chunks, group=layout.sp_group, graphs=False, kv_exchange=args.kv_exchange)
+    kv_auto = args.kv_exchange == "auto"
+    model.prepare(grid, plan, sp_chunks=args.sp_chunks, group=layout.sp_group, graphs=False,
+                  kv_exchange="allgather" if kv_auto else args.kv_exchange)
     model.share_stem = bool(args.share_stem)
     if args.native_forward:   # one icv_dit_forward call per forward instead of ~530 per-op calls (bit-identical)
         model.native_forward = True
@@ -286,6 +443,34 @@ def main():
 
     xchg = BranchExchange(layout) if layout.mode == "cfg+sp" else None
 
+    # ---- N > 1: which K|V transport / chunking?  measured on these ranks, not assumed (seqpar.autotune_kv_exchange)
+    autotune = None
+    if world > 1 and kv_auto:
+        if layout.sp_world > 1:
+            phase("autotune")
+            own_ctx = ctx_u if layout.branch == 1 else ctx_c
+
+            def two_layers():
+                model.forward_tokens(latent, own_ctx, 500.0, buf, model.head_own, num_layers=min(2, cfg.num_layers))
+
+            def reduce_max(vals):
+                t = torch.tensor(vals, dtype=torch.float64, device=device if on_dev else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return t.tolist()
+
+            t_tune = time.perf_counter()
+            cands = [(m, c) for m in ("allgather", "p2p", "native") for c in sorted({args.sp_chunks, 2}, reverse=True)]
+            if share:      # several ranks on ONE GPU (development boxes): RCCL refuses duplicate devices in a communicator
+                cands = [mc for mc in cands if mc[0] != "native"]
+            (args.kv_exchange, args.sp_chunks), table = autotune_kv_exchange(
+                model, two_layers, sync, cands, reps=2, reduce_max=reduce_max,
+                log=(lambda m: print(f"[bench] {m}", file=sys.stderr, flush=True)) if rank == 0 else None)
+            autotune = {"seconds": time.perf_counter() - t_tune, "layers_timed": min(2, cfg.num_layers), "table": table,
+                        "chosen": {"kv_exchange": args.kv_exchange, "sp_chunks": args.sp_chunks}}
+        else:
+            args.kv_exchange = "allgather"          # cfg+sp at N = 2: no K|V exchange at all
+    phase("warmup")
+
     def run_steps(first, count):
         model.denoise(latent, ctx_c if layout.branch in (None, 0) else None, ctx_u if layout.branch in (None, 1) else None,
                       buf, sched, CFG_SCALE, steps=[(first + i) % total_steps for i in range(count)], branch_exchange=xchg)
@@ -293,6 +478,7 @@ def main():
     from infinicube_amd import native
     run_steps(0, args.warmup)
     sync()
+    phase("timed")
     record["on"] = True
     if args.native_forward:
         model.native_profile(True)
@@ -308,6 +494,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     record["on"] = False
+    phase("report")
     abi_calls = native.N_CALLS[0] - calls0
     kv_waits = list(model.kv_gather.timing or []) if model.kv_gather is not None else []
     n_coll = model.kv_gather.n_collectives if model.kv_gather is not None else 0
@@ -353,6 +540,8 @@ def main():
         attn_ms = sum(ms for ms, _ in reads) / max(n_timed, 1)
         attn_events = [None] * n_timed
         attn_flops = 4.0 * plan.n_tok * grid.S * cfg.dim
+        if model.sp_on:           # the C driver times each key-chunk launch: average flops of one chunk launch
+            attn_flops /= (len(model.sp_bounds) - 1)
     else:
         attn_ms = sum(a.elapsed_time(b) for a, b in attn_events) / max(len(attn_events), 1)
         attn_flops = 4.0 * plan.n_tok * grid.S * cfg.dim        # per launch on this rank (4 S^2 d)
@@ -370,7 +559,7 @@ def main():
         traffic, traffic_source = None, None
     if rank == 0:
         out = {
-            "metric": "denoise steps/sec, 93-frame 480p Wan2.1 buffer-conditioned DiT loop",
+            "metric": METRIC,
             "value": args.steps / elapsed,
             "unit": "denoise steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -414,14 +603,14 @@ def main():
             },
         }
         if comm is not None:
+            comm["autotune"] = autotune
+            comm["parallelism"] = layout.mode
             out["multi_gpu"] = comm
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or min(os.cpu_count() or 1, 32)  # >32 threads oversubscribes these GEMM sizes
             out["cpu_baseline"] = cpu_baseline(cfg, grid, threads)
-        sys.stdout.flush()
-        os.dup2(stdout_fd, 1)            # the real stdout back, for the one line
-        print(json.dumps(out), flush=True)
-        os.dup2(2, 1)
+        if not guard.write_result(out):      # under a supervisor ITS rank 0 prints the line (with the attempt history)
+            emit(out, stdout_fd)
     if world > 1:
         from infinicube_amd.videogen.seqpar import _NativeComm
         _NativeComm.close_all()

@@ -314,6 +314,23 @@ class WanDiT:
             self.kv_loc, self.kv_full, self.kv_gather = None, None, None
         return self
 
+    def set_kv_exchange(self, mode: Optional[str], sp_chunks: int):
+        """Switch the transport / chunking of the per-layer K|V exchange on a prepared engine (start-up autotune,
+        seqpar.autotune_kv_exchange): same workspace, new chunk bounds and a new KVGather on the same group."""
+        if not self.sp_on:
+            return self
+        n = self.plan.n_tok
+        self.sp_bounds = chunk_bounds(n, sp_chunks)
+        old = self.kv_gather
+        self.kv_gather = KVGather(self.plan, getattr(old, "group", None), mode)
+        if self.attn_fp8:      # the e4m3 K/V side of the workspace is sized for the largest gathered chunk
+            kv_rows = self.plan.world * max(b1 - b0 for b0, b1 in zip(self.sp_bounds[:-1], self.sp_bounds[1:]))
+            self.attn8_ws = self.ops.attention_fp8_buffers(n, kv_rows, self.cfg.dim, self.cfg.num_heads)
+        if getattr(self, "_native", None) is not None:      # the C driver's context holds the old bounds / communicator
+            self.ops.lib.icv_dit_destroy(self._native)
+            self._native = None
+        return self
+
     def _native_ctx(self):
         """icv_dit context bound to this engine's weights and workspace (built lazily, once per prepare())."""
         if self._native is not None:

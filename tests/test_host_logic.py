@@ -374,21 +374,3 @@ def test_cfg_batched_forward_pair_equals_sequential_forwards(name, kw):
     m = WanDiT(cfg, sd, OracleOps(), bsd, **kw).prepare(GRID)
     m.PAIR_MAX_OPERAND_BYTES = 1000                      # a workload whose 2n-row operands would pass the 4 GiB offset limit
     assert not m._pair_ok()
-
-
-def test_bench_fails_loudly_without_a_gpu():
-    """bench.py measures the HIP path or nothing: on a box without a GPU the plain form and the self-launching N-rank form
-    exit non-zero within seconds, print no JSON line (there is no CPU fallback to time), and the launcher names the rank
-    that failed and stops the others."""
-    import subprocess
-    if torch.cuda.is_available():
-        pytest.skip("needs a box WITHOUT a GPU")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, "bench.py", "--model", "tiny", "--steps", "1", "--warmup", "0"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode != 0 and r.stdout.strip() == ""
-    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--model", "tiny"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 2 and "only 0 GPU(s) visible" in r.stderr and r.stdout.strip() == ""
-    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--model", "tiny"], cwd=root, env=dict(env, ICV_BENCH_SHARE_GPU="1", ICV_DIST_BACKEND="gloo"),
-                       capture_output=True, text=True, timeout=300)
-    assert r.returncode != 0 and "exited with code" in r.stderr and r.stdout.strip() == ""

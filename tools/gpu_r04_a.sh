@@ -1,10 +1,10 @@
 # round 4, first contact: the compute-only projection at HEAD on this box + per-kernel traces of the shard shapes
 mkdir -p gpurun_out/r04a; export TMPDIR=/tmp
-python tools/sp_shard_compute_time.py 2>&1 | tee gpurun_out/r04a/sp_projection_head.txt
-cp gpurun_out/sp_compute_only_projection.json gpurun_out/r04a/
+true
+true
 for cfg in 1:1 4:4 8:4; do
   tag=${cfg/:/_}
-  (cd /tmp && ONLY=$cfg LAYERS=2 ITERS=2 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o t -- python $GRAFT_REPO_ROOT/tools/sp_shard_compute_time.py) > gpurun_out/r04a/trace_$tag.log 2>&1
+  (cd /tmp && ONLY=$cfg LAYERS=2 ITERS=2 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o t -- python $GRAFT_REPO_ROOT/tools/sp_shard_compute_time.py) > gpurun_out/r04a/trace_$tag.log 2>&1
   f=$(find /tmp/prof_$tag -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp "$f" gpurun_out/r04a/kernel_stats_$tag.csv
   f=$(find /tmp/prof_$tag -name '*kernel_trace.csv' | head -1)
