@@ -266,7 +266,8 @@ def worker_main() -> int:
         c = msg["call"]
         gen.pipe(prompt=c["prompt"], negative_prompt=c["negative_prompt"], semantic_buffer_video=gen._ndarray_to_pil_list(bufs[0]),
                  coordinate_buffer_video=gen._ndarray_to_pil_list(bufs[1]), height=h, width=w, num_frames=n, seed=c["seed"],
-                 tiled=c["tiled"], return_latents=True)      # rank 0 alone decodes, returns frames and writes the mp4
+                 tiled=c["tiled"], return_latents=True, join_decode=True)   # rank 0 alone blends the decoded tiles (this rank
+        #                                                             computes its share of them), returns frames, writes the mp4
         print(f"[worker {rank}] request done", flush=True)
     from .seqpar import _NativeComm
     _NativeComm.close_all()

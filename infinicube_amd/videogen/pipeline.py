@@ -214,6 +214,17 @@ def _video_to_tensor(frames: Sequence[Image.Image], height: int, width: int) -> 
     return (v * (2.0 / 255.0) - 1.0).permute(3, 0, 1, 2).contiguous()
 
 
+def _video_to_uint8(frames: Sequence[Image.Image], height: int, width: int) -> torch.Tensor:
+    """List[PIL RGB] -> uint8 [F, H, W, 3] (host): what a VAE with ``accepts_uint8`` normalises on the device — the same
+    numbers as ``_video_to_tensor`` without building a 4x larger float clip on the host."""
+    arrs = []
+    for im in frames:
+        if im.size != (width, height):
+            im = im.resize((width, height), Image.BILINEAR)
+        arrs.append(np.asarray(im.convert("RGB"), dtype=np.uint8))
+    return torch.from_numpy(np.stack(arrs, 0))
+
+
 def _tensor_to_video(video: torch.Tensor) -> List[Image.Image]:
     """f32 [3, F, H, W] in [-1, 1] -> List[PIL RGB] (diffsynth vae_output_to_video)."""
     v = ((video.float().clamp(-1, 1) + 1.0) * 127.5).round().to(torch.uint8).permute(1, 2, 3, 0).cpu().numpy()
@@ -354,7 +365,7 @@ class WanVideoPipeline:
                  seed: Optional[int] = None, tiled: bool = True, num_inference_steps: Optional[int] = None,
                  cfg_scale: Optional[float] = None, sigma_shift: Optional[float] = None, rand_device: str = "cpu",
                  tile_size=(30, 52), tile_stride=(15, 26), progress_bar_cmd=None, return_latents: bool = False,
-                 input_image=None, **unused):
+                 input_image=None, join_decode: bool = False, **unused):
         if self.text_encoder is None or self.vae is None:
             raise RuntimeError("WanVideoPipeline: text encoder / VAE not loaded")
         num_inference_steps = self.num_inference_steps if num_inference_steps is None else num_inference_steps
@@ -417,14 +428,22 @@ class WanVideoPipeline:
         latent = ops.to_device(latent, torch.float32)
         # guidance buffers -> VAE latents -> tokens (step-invariant)
         buf_tokens = None
+        # multi-rank run: the VAE's tiles are dealt to ALL ranks of the job (vae.TileShard; bit-identical result on every rank)
+        from .vae import TileShard
+        vshard = dict(shard=TileShard.current()) if (world > 1 and getattr(self.vae, "accepts_uint8", False)) else {}
         if self.buffer_embedder is not None and semantic_buffer_video is not None and coordinate_buffer_video is not None:
-            lats = []
-            for vid in (semantic_buffer_video, coordinate_buffer_video):
+            vids = (semantic_buffer_video, coordinate_buffer_video)
+            for vid in vids:
                 if len(vid) != num_frames:
                     raise ValueError(f"buffer video has {len(vid)} frames, num_frames={num_frames}")
-                lats.append(self.vae.encode(_video_to_tensor(vid, height, width), tiled=tiled,
-                                            tile_size=tile_size, tile_stride=tile_stride).to(torch.float32))
-            buf_tokens = engine.embed_buffers(torch.cat(lats, dim=0))
+            if hasattr(self.vae, "encode_many"):      # both clips in one pass over their tiles, bytes normalised on the device
+                to_clip = _video_to_uint8 if getattr(self.vae, "accepts_uint8", False) else _video_to_tensor
+                lats = self.vae.encode_many([to_clip(v, height, width) for v in vids], tiled=tiled, tile_size=tile_size,
+                                            tile_stride=tile_stride, **vshard)
+            else:
+                lats = [self.vae.encode(_video_to_tensor(v, height, width), tiled=tiled, tile_size=tile_size, tile_stride=tile_stride)
+                        for v in vids]
+            buf_tokens = engine.embed_buffers(torch.cat([x.to(torch.float32) for x in lats], dim=0))
         if i2v:
             y = self._image_cond_latents(input_image, grid, tiled, tile_size, tile_stride)
             buf_tokens = engine.embed_cond_latents(y, add_to=buf_tokens)
@@ -437,6 +456,10 @@ class WanVideoPipeline:
                        round_bf16=self.reference_rounding)
         latent = gather_latent(latent, plan, grid, group=layout.sp_group)
         if return_latents:
+            if join_decode and vshard.get("shard") is not None:
+                # a worker rank of multigpu.WorkerPool: it needs no frames, but its share of the decode tiles is part of
+                # the collective rank 0 is in (vae.WanVAE._run_tiles)
+                self.vae.decode(latent, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride, blend=False, **vshard)
             return latent
-        video = self.vae.decode(latent, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride)
+        video = self.vae.decode(latent, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride, **vshard)
         return _tensor_to_video(video)

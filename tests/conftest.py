@@ -22,6 +22,10 @@ def pytest_collection_modifyitems(config, items):
     """The measured-slower A/B kernels are compiled only by `ICV_EXPERIMENTS=1 csrc/build.sh`; their tests are part of the
     collection only under the same switch (ICV_EXPERIMENTS=1 ICV_LIB_PATH=.../libicvideo_experiments.so pytest -m gpu),
     instead of showing up as dozens of skips in the default suite."""
+    # the driver runs `pytest -x`: tests that need real multi-GPU RCCL ranks go LAST, so that a first-contact failure on a
+    # multi-GPU node cannot leave the single-GPU rows (buffers, voxels, wire formats, ...) unrun
+    last = ("test_multigpu_rccl.py",)
+    items.sort(key=lambda it: 1 if os.path.basename(str(it.fspath)) in last else 0)      # stable: order inside each class kept
     if os.environ.get("ICV_EXPERIMENTS", "0") == "1":
         return
     keep, drop = [], []

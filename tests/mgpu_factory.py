@@ -37,3 +37,19 @@ def gpu_factory(torch_dtype, device, model_configs):
     pipe = WanVideoPipeline(dev, torch_dtype, DiTHolder(syn.make_dit_state_dict(CFG), CFG), HashTextEncoder(CFG), PoolVAE(), ops=HipOps(dev))
     pipe.num_inference_steps = 2
     return pipe
+
+
+def small_wan_vae():
+    """The real WanVAE code (tiled, channels as in the public architecture but 8 base channels) with seeded random weights, fp32 on CPU."""
+    from infinicube_amd.videogen.vae import WanVAE, WanVAENet
+    torch.manual_seed(11)
+    return WanVAE(WanVAENet(dim=8), "cpu", torch.float32)
+
+
+def real_vae_factory(torch_dtype, device, model_configs):
+    """`factory` with the product's tiled Wan-VAE instead of the stand-in: in a multi-rank run its tiles are dealt to the ranks."""
+    torch.set_num_threads(2)
+    pipe = WanVideoPipeline(device, torch_dtype, DiTHolder(syn.make_dit_state_dict(CFG), CFG), HashTextEncoder(CFG), small_wan_vae(),
+                            ops=OracleOps())
+    pipe.num_inference_steps = 2
+    return pipe

@@ -206,6 +206,37 @@ def test_bench_stdout_is_one_json_line_on_one_gpu(n, launcher):
     if n > 1:
         assert d["multi_gpu"]["rccl_ranks"] == n and d["multi_gpu"]["backend"] == "gloo" and "exposed_kv_wait_ms_per_step" in d["multi_gpu"]
         assert ("cfg2 x sp" in d["config"]["parallelism"]) and d["scaling"] == "strong"
+        # the run went through the supervisors: which plan ran, nothing failed before it, and (sp groups of >= 2 ranks) the
+        # start-up autotune's table of transports x chunk counts with the choice that was timed
+        assert d["multi_gpu"]["plan"].startswith("cfg+sp / kv-exchange auto") and d["multi_gpu"]["failed_attempts"] == []
+        if n >= 4:
+            at = d["multi_gpu"]["autotune"]
+            assert {(r["kv_exchange"], r["sp_chunks"]) for r in at["table"]} >= {("allgather", 4), ("p2p", 4), ("allgather", 2)}
+            assert d["multi_gpu"]["kv_exchange"] == at["chosen"]["kv_exchange"] and any(r["ms"] for r in at["table"]) and at["seconds"] < 30
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("inject,plan_prefix,n_failed", [("0:1:groups:raise", "cfg+sp / kv-exchange allgather", 1),
+                                                        ("0:3:autotune:hang,1:0:warmup:raise", "sp / kv-exchange allgather", 2)])
+def test_bench_falls_back_and_says_so(inject, plan_prefix, n_failed):
+    """First-contact robustness on the real bench.py (4 ranks sharing the one GPU over gloo): a rank that RAISES while the groups
+    are built, and a rank that HANGS in the autotune followed by one that raises in the warm-up of the next plan - every rank moves
+    to the next plan together, the run still ends with a measured line, and `multi_gpu` names the plan that ran and what failed."""
+    cmd = [sys.executable, "bench.py", "--gpus", "4", "--model", "small", "--frames", "17", "--height", "256", "--width", "448", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(ICV_BENCH_SHARE_GPU="1", ICV_DIST_BACKEND="gloo", ICV_GUARD_INJECT=inject, ICV_GUARD_BUDGETS="autotune=25", ICV_BENCH_DIST_TIMEOUT_S="40")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[:400]
+    d = json.loads(lines[0])
+    mg = d["multi_gpu"]
+    assert d["value"] > 0 and mg["plan"].startswith(plan_prefix) and len(mg["failed_attempts"]) == n_failed, mg
+    first = mg["failed_attempts"][0]
+    assert first["plan"].startswith("cfg+sp / kv-exchange auto") and first["phase"] in ("groups", "autotune") and first["reason"]
+    if n_failed == 2:
+        assert mg["parallelism"] == "sp" and mg["kv_group_ranks"] == 4 and mg["failed_attempts"][1]["phase"] == "warmup"
 
 
 @pytest.mark.gpu
