@@ -185,6 +185,11 @@ def parse_args(argv=None):
                     help="let the uncond forward reuse the context-free stem (patch embed + layer 0's self-attention block) of the "
                          "cond forward, as the product pipeline does (bit-identical result, 1/80 less attention/QKV/O work). OFF by "
                          "default: the metric's step is two FULL forwards")
+    ap.add_argument("--e2e", type=int, nargs="?", const=50, default=0, metavar="STEPS",
+                    help="N=1: after the timed region ALSO run one whole WanVideoGenerator.generate() (93 frames 480p, tiled Wan-VAE, "
+                         "UMT5, mp4 written; random-init weights of the real architectures) with STEPS denoising steps (default 50) and "
+                         "add its wall-clock + stage table as `e2e` - the 'wall-clock' half of BASELINE.json's metric; ~3 min at 14B, so "
+                         "off unless asked for (tools/e2e_wallclock.py is the same measurement on its own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     return ap.parse_args(argv)
@@ -606,6 +611,16 @@ def run_rank(args, world, rank, phase, stdout_fd):
             comm["autotune"] = autotune
             comm["parallelism"] = layout.mode
             out["multi_gpu"] = comm
+        if world == 1 and args.e2e:
+            phase("e2e")
+            del model, ctx_c, ctx_u, buf
+            torch.cuda.empty_cache()
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("_icv_e2e", os.path.join(ROOT, "tools", "e2e_wallclock.py"))
+            e2e_mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(e2e_mod)
+            out["e2e"] = e2e_mod.run_e2e(args.model, args.e2e, args.gemm_dtype, str(device), log=lambda m: print(f"[e2e] {m}", file=sys.stderr, flush=True))
+            out["e2e"]["loop_only_50_steps_s"] = out["config"]["wallclock_50_steps_s"]
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or min(os.cpu_count() or 1, 32)  # >32 threads oversubscribes these GEMM sizes
             out["cpu_baseline"] = cpu_baseline(cfg, grid, threads)

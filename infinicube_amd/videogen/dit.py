@@ -68,7 +68,7 @@ class WanDiT:
     #        outputs are added straight onto the residual stream, 40 layers deep), round 2's set (all but FFN2) 28.9 dB.
     # The bar is >= 40 dB at the depth of the model that is run, so the default is the QKV projection (26 % of the GEMM flops)
     # plus e4m3 self-attention (57 % of a bf16 step): asserted against the fp32 oracle at both depths
-    # (test_config1_*: 1.3B; test_config3_*_four_step_loop_full_depth: 14B).  ICV_FP8_WEIGHTS / fp8_weights= selects any other
+    # (test_config1_*: 1.3B; test_config3_wan_14b_full_depth_forwards_and_loop: 14B).  ICV_FP8_WEIGHTS / fp8_weights= selects any other
     # subset for a caller whose checkpoint tolerates more.
     FP8_DEFAULT = ("wqkv",)
 
@@ -419,22 +419,25 @@ class WanDiT:
         dev = getattr(self.ops, "device", None)
         return dev is not None and torch.device(dev).type == "cuda"
 
-    def _sp_start_gather(self):
+    def _sp_start_gather(self, kv_loc=None, kv_full=None):
         """K13: enqueue the exchange of every K|V row-chunk (RCCL runs them back to back on its own
         stream; chunk c = rows [r0, r1) of EVERY rank's shard, rank-major)."""
         world, b, d = self.plan.world, self.sp_bounds, self.cfg.dim
+        kv_loc = self.kv_loc if kv_loc is None else kv_loc
+        kv_full = self.kv_full if kv_full is None else kv_full
         handles, bufs = [], []
         for c in range(len(b) - 1):
             r0, r1 = b[c], b[c + 1]
-            full = self.kv_full[world * r0: world * r1]
+            full = kv_full[world * r0: world * r1]
             bufs.append((full[:, :d], full[:, d:]))            # strided views: the kernels take a row stride
-            handles.append(self.kv_gather.start(self.kv_loc[r0:r1], full))
+            handles.append(self.kv_gather.start(kv_loc[r0:r1], full))
         return handles, bufs
 
-    def _sp_attention(self, q, handles, bufs, H, scale):
+    def _sp_attention(self, q, handles, bufs, H, scale, att=None):
         """K6 pipelined with K13: attention consumes chunk c as soon as it has landed, carrying the
         online-softmax state in fp32 between launches, while later chunks are still in flight."""
         ops = self.ops
+        att = self.att if att is None else att
         C = len(bufs)
         if self.attn8_ws is not None:
             ops.attention_fp8_prepare(self.attn8_ws, H, q=q)            # queries once per layer, under the first transfer
@@ -442,10 +445,10 @@ class WanDiT:
             self.kv_gather.wait(handles[c])
             if self.attn8_ws is not None:
                 ops.attention_fp8_prepare(self.attn8_ws, H, k=bufs[c][0], v=bufs[c][1])
-                ops.attention_fp8_chunk(self.attn8_ws, q.shape[0], bufs[c][0].shape[0], self.att, self.sp_acc, self.sp_ml, H,
+                ops.attention_fp8_chunk(self.attn8_ws, q.shape[0], bufs[c][0].shape[0], att, self.sp_acc, self.sp_ml, H,
                                         first=(c == 0), last=(c == C - 1))
             else:
-                ops.attention_chunk(q, bufs[c][0], bufs[c][1], self.att, self.sp_acc, self.sp_ml, H, scale,
+                ops.attention_chunk(q, bufs[c][0], bufs[c][1], att, self.sp_acc, self.sp_ml, H, scale,
                                     first=(c == 0), last=(c == C - 1))
 
     # ------------------------------------------------------------------------------------
@@ -670,7 +673,7 @@ class WanDiT:
 
     def _pair_ok(self) -> bool:
         n2 = 2 * self.plan.n_tok
-        return (self.cfg_batch and not self.sp_on and not self._graphs_on and not self._native_eligible() and not self.dual_stream
+        return (self.cfg_batch and not self._graphs_on and not self._native_eligible() and not self.dual_stream
                 and n2 * max(self.cfg.dim, self.cfg.ffn_dim) * 2 <= self.PAIR_MAX_OPERAND_BYTES)
 
     def _pair_engine(self):
@@ -686,6 +689,9 @@ class WanDiT:
                 t.h8, t.h8s = a((n2, d), FP8), a((n2,), F32)
                 t.att8, t.att8s = a((n2, d), FP8), a((n2,), F32)
                 t.ff8, t.ff8s = a((n2, cfg.ffn_dim), FP8), a((n2,), F32)
+            if self.sp_on:      # both branches' K|V rows: local [2n, 2d] (cond rows, then uncond rows), gathered [2, world*n, 2d]
+                t.kv_loc = a((n2, 2 * d), BF16)
+                t.kv_full = a((2, self.plan.world * self.plan.n_tok, 2 * d), BF16)
             self._pair = t
         return self._pair
 
@@ -715,6 +721,27 @@ class WanDiT:
 
         def self_attention_block(lw, sh1, sc1, g1, rows_list, rows_all):
             h = t._norm(lw["wqkv"], rows=rows_all, shift=sh1, scale=sc1, eps=eps)                       # K3
+            if self.sp_on:
+                # sequence parallel ("sp" layout: this rank runs BOTH forwards of a step on its token shard): the projections run
+                # once over the 2n rows of the pair - at n = 4 680 (sp8, 14B) the N = 5120 GEMMs go from 2 x 380 tiles = 2 x 1.48
+                # rounds of 256 CUs to 740 tiles = 2.89 rounds - while exchange and attention stay per branch: the uncond rows
+                # travel under the cond branch's attention
+                rs = slice(0, 2 * n) if rows_all is None else rows_all
+                t._mm(h, lw["wqkv"], lw["bqkv"], t.kv_loc[rs], EPI_BF16, rows=slice(d, 3 * d))            # K4 (k | v rows)
+                pend = []
+                for bi, r in enumerate(halves):
+                    if r not in rows_list:
+                        continue
+                    ops.rmsnorm_rope(t.kv_loc[r][:, :d], lw["nk"], eps=eps, rope=self.rope, tok0=plan.tok0)   # K5 (k)
+                    pend.append((r,) + self._sp_start_gather(t.kv_loc[r], t.kv_full[bi]))                  # K13
+                t._mm(h, lw["wqkv"], lw["bqkv"], q[rs], EPI_BF16, rows=slice(0, d))                       # K4 (q)
+                for r, handles, bufs in pend:
+                    ops.rmsnorm_rope(q[r], lw["nq"], eps=eps, rope=self.rope, tok0=plan.tok0)             # K5 (q)
+                    self._sp_attention(q[r], handles, bufs, H, scale, att=t.att[r])                       # K6
+                a = t._operand(t.att, t.att8, t.att8s, lw["wo"], rows=rows_all)
+                xr = t.x if rows_all is None else t.x[rows_all]
+                t._mm(a, lw["wo"], lw["bo"], xr, EPI_RESID_F32, resid=xr, gate=g1)                        # K7
+                return
             if rows_all is None:
                 t._mm(h, lw["wqkv"], lw["bqkv"], t.qkv, EPI_BF16, nsplit=d)                             # K4, 2n rows
             else:   # n rows into the first half of each plane: three plain GEMMs keep the [3, 2n, d] plane layout

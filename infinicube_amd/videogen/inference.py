@@ -89,6 +89,8 @@ class WanVideoGenerator:
             self.pipe.enable_vram_management()
 
         if self._pool is not None:
+            # layout / K|V transport that passed the pool's start-up probe (sent to the workers with every request)
+            self.pipe.parallelism, self.pipe.kv_exchange = self._pool.plan
             self._pool.wait_ready()
         print("✓ WanVideoGenerator initialization complete")
 

@@ -375,17 +375,17 @@ class WanVideoPipeline:
         engine = self._get_engine()
         ops = engine.ops
         world, rank = 1, 0
+        from . import multigpu
         try:
             import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized():
-                world, rank = dist.get_world_size(), dist.get_rank()
+            if dist.is_available() and dist.is_initialized() and not multigpu.degraded():   # degraded: a failed multi-GPU start
+                world, rank = dist.get_world_size(), dist.get_rank()                        # left a dead group behind
         except Exception:  # pragma: no cover
             pass
         lkey = (world, rank, self.parallelism, cfg_scale != 1.0)
         # process groups are created once per (world, mode).  Behind a worker pool the cache belongs to the POOL, not to this
         # pipeline object: a second generator on the same pool gives rank 0 a new pipeline while the workers keep theirs, and
         # creating groups is a collective they would never join
-        from . import multigpu
         layouts = multigpu.layout_cache()
         if layouts is None:
             layouts = self._layouts

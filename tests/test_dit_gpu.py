@@ -194,7 +194,10 @@ def test_fp8_gemm_mode_forward_and_loop(hip_ops):
 def test_sequence_parallel_path_on_one_gpu(hip_ops, chunks, model, gemm_dtype):
     """The world>1 code path (token shards, RoPE offsets, chunked K/V gather feeding the carried-state
     attention kernel, per-shard Euler update) driven on ONE GPU: two shard engines run with a stand-in
-    for the RCCL all-gather that serves the other shard's K/V rows from the unsharded run."""
+    for the RCCL all-gather that serves the other shard's K/V rows from the unsharded run.
+    Compared with the UNSHARDED HIP OUTPUT (a self-comparison: it proves the sharded schedule computes what the unsharded one
+    does, not parity with the oracle - that is test_forward_parity / test_denoise_loop_psnr for the unsharded path, and
+    tests/test_fullsize_gpu.py::test_layer_14b_sequence_parallel_shards_full_S for the shard shapes directly against the oracle)."""
     from infinicube_amd.videogen.seqpar import ShardPlan
     grid = TokenGrid(9, 64, 96)
     attn_dtype = "fp8" if gemm_dtype.endswith("+attn") else "bf16"      # 4th case: e4m3 self-attention, per-chunk K/V scales
@@ -516,12 +519,16 @@ def test_native_forward_matches_python_driver(hip_ops, name, mode):
     assert hip_ops.lib.icv_dit_create(ctypes.byref(bad), ctypes.byref(hh)) != 0
 
 
-@pytest.mark.parametrize("name,mode", [("tiny", "bf16"), ("small", "bf16"), ("tiny-i2v", "bf16"), ("tiny", "fp8"), ("tiny-i2v", "fp8")])
+@pytest.mark.parametrize("name,mode", [("tiny", "bf16"), ("small", "bf16"), ("tiny-i2v", "bf16"), ("tiny", "fp8"), ("tiny-i2v", "fp8"),
+                                       ("small", "bf16+sp"), ("tiny", "fp8+sp")])
 def test_cfg_batched_forward_pair_is_bit_identical(hip_ops, name, mode):
     """The two CFG forwards of a step as ONE batch of 2n rows (WanDiT.forward_pair, the single-rank default) against two
     sequential forwards on the HIP kernels: every token-local kernel computes a row independently of the row count and the
     branch-specific launches (RoPE, self-attention, cross-attention) see the same operands, so a whole CFG loop is
-    bit-identical — with and without the shared stem."""
+    bit-identical — with and without the shared stem.  "+sp": the same under the sequence-parallel schedule on one rank
+    (force_sp: what every rank of the `sp` layout runs - projections over 2n rows, exchange + chunked attention per branch)."""
+    sp = mode.endswith("+sp")
+    mode = mode.split("+")[0]
     cfg, grid = preset(name), (TokenGrid(17, 128, 160) if name == "small" else TokenGrid(9, 64, 96))
     sd, bsd = syn.make_dit_state_dict(cfg), syn.make_buffer_embedder_state_dict(cfg)
     noise, c1, c2, bl = syn.make_latent_noise(grid), syn.make_text_context(cfg, 1), syn.make_text_context(cfg, 2), syn.make_buffer_latents(cfg, grid)
@@ -531,7 +538,7 @@ def test_cfg_batched_forward_pair_is_bit_identical(hip_ops, name, mode):
     res = {}
     for batch in (False, True):
         for share in (False, True):
-            m = WanDiT(cfg, sd, hip_ops, bsd, **kw).prepare(grid, graphs=False)
+            m = WanDiT(cfg, sd, hip_ops, bsd, **kw).prepare(grid, graphs=False, force_sp=sp, sp_chunks=3)
             m.cfg_batch, m.share_stem = batch, share
             add = m.embed_buffers(bl)
             if y is not None:
@@ -539,7 +546,7 @@ def test_cfg_batched_forward_pair_is_bit_identical(hip_ops, name, mode):
             lat = noise.clone().to("cuda:0")
             m.denoise(lat, m.encode_context(c1, clip), m.encode_context(c2, clip), add, FlowMatchScheduler(3), 5.0)
             torch.cuda.synchronize()
-            assert (m._pair is not None) == batch
+            assert (m._pair is not None) == batch and m.sp_on == sp
             res[(batch, share)] = lat.cpu()
     assert torch.isfinite(res[(True, False)]).all()
     for k, v in res.items():

@@ -4,6 +4,7 @@ UMT5 / VAE components.  Checks the drop-in's observable behaviour: frame count/s
 determinism, that prompt / seed / buffers each change the result, checkpoint overlay semantics."""
 import contextlib
 import io
+import json
 import os
 import re
 
@@ -282,3 +283,25 @@ def test_checkpoint_download_behaviour(tmp_path, capsys, monkeypatch):
     (part / "diffusion_pytorch_model.safetensors.index.json").write_text(json.dumps({"weight_map": {
         "a": "diffusion_pytorch_model-00001-of-00002.safetensors", "b": "diffusion_pytorch_model-00003-of-00003.safetensors"}}))
     assert not mc2.present()
+
+
+def test_first_contact_tool_reads_the_checkpoint_header(tmp_path, capsys):
+    """tools/first_contact.py (the script that settles ORACLE_RISKS R1-R7 once real weights exist): its header-only steps on
+    synthetic checkpoints of both embedder hypotheses and of an unknown layout, and the structural checks on a DiT key list."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("first_contact", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "first_contact.py"))
+    fc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fc)
+    cfg = preset("tiny")
+    for variant, want in (("concat", "H1"), ("dual", "H2")):
+        bsd = syn.make_buffer_embedder_state_dict(cfg, variant=variant)
+        path = str(tmp_path / f"{variant}.safetensors")
+        save_file({**{"buffer_embedder." + k: v.contiguous() for k, v in bsd.items()}, "dit.blocks.0.modulation": torch.zeros(1, 6, cfg.dim), "stray": torch.zeros(1)}, path)
+        assert fc.main(["--checkpoint", path, "--describe-only"]) == 0
+        rec = json.loads(capsys.readouterr().out)
+        assert rec["R4_buffer_embedder"]["hypothesis"] == want and rec["dit_overlay_keys"] == 1 and rec["unprefixed_keys_dropped_by_the_loader"] == ["stray"]
+    path = str(tmp_path / "odd.safetensors")
+    save_file({"buffer_embedder.stem.0.weight": torch.zeros(8, 3, 3, 3)}, path)
+    assert fc.main(["--checkpoint", path, "--describe-only"]) == 2 and "unknown" in capsys.readouterr().out
+    ok, f = fc.structural_checks({k: tuple(v.shape) for k, v in syn.make_dit_state_dict(cfg).items()})
+    assert ok and f["R8_rmsnorm_over_full_d"] and f["R9_norm3_affine"] and f["R9_modulation_shape"]

@@ -348,10 +348,14 @@ def test_gloo_cfg_branch_parallel_equals_single(world, mode, kv_exchange):
                        branch_exchange=lambda a, b: None)
 
 
-@pytest.mark.parametrize("name,kw", [("tiny", {}), ("tiny-i2v", {}), ("tiny", dict(gemm_dtype="fp8", attn_dtype="fp8", fp8_weights=WanDiT.FP8_WEIGHTS))])
-def test_cfg_batched_forward_pair_equals_sequential_forwards(name, kw):
+@pytest.mark.parametrize("name,kw,force_sp", [("tiny", {}, False), ("tiny-i2v", {}, False),
+                                              ("tiny", dict(gemm_dtype="fp8", attn_dtype="fp8", fp8_weights=WanDiT.FP8_WEIGHTS), False),
+                                              ("tiny", {}, True), ("tiny", dict(gemm_dtype="fp8", attn_dtype="fp8", fp8_weights=WanDiT.FP8_WEIGHTS), True)])
+def test_cfg_batched_forward_pair_equals_sequential_forwards(name, kw, force_sp):
     """WanDiT.forward_pair (the two CFG forwards of a step as one batch of 2n rows through every token-local op) against two
-    sequential forwards, with and without the shared stem: same per-row arithmetic, so the latents of a loop are identical."""
+    sequential forwards, with and without the shared stem: same per-row arithmetic, so the latents of a loop are identical.
+    ``force_sp``: the same under the sequence-parallel schedule (the `sp` layout runs both forwards on every rank: the
+    projections over 2n rows, exchange + chunked attention per branch)."""
     cfg = preset(name)
     sd, bsd = syn.make_dit_state_dict(cfg), syn.make_buffer_embedder_state_dict(cfg)
     noise, c1, c2, bl = syn.make_latent_noise(GRID), syn.make_text_context(cfg, 1), syn.make_text_context(cfg, 2), syn.make_buffer_latents(cfg, GRID)
@@ -360,7 +364,8 @@ def test_cfg_batched_forward_pair_equals_sequential_forwards(name, kw):
     res = {}
     for batch in (False, True):
         for share in (False, True):
-            m = WanDiT(cfg, sd, OracleOps(), bsd, **kw).prepare(GRID)
+            m = WanDiT(cfg, sd, OracleOps(), bsd, **kw).prepare(GRID, force_sp=force_sp, sp_chunks=3)
+            assert m.sp_on == force_sp
             m.cfg_batch, m.share_stem = batch, share
             add = m.embed_buffers(bl)
             if y is not None:

@@ -134,3 +134,46 @@ def test_worker_that_dies_while_loading_is_reported(tmp_path, monkeypatch):
             multigpu._ACTIVE_POOL.close()
     import torch.distributed as dist
     assert not dist.is_initialized()
+
+
+@pytest.mark.parametrize("inject,want_plan,n_failed", [
+    ("0:1:raise", ("sp", "allgather"), 1),               # world 3 + p2p requested: plan 0 = (sp, p2p) fails on a worker -> (sp, allgather)
+    ("0:0:hang,1:2:raise", None, 2),                     # rank 0 itself hangs in plan 0, a worker raises in plan 1 -> ONE GPU
+])
+def test_pool_start_falls_back_plan_by_plan(tmp_path, monkeypatch, capfd, inject, want_plan, n_failed):
+    """The staged start of the worker pool (the mirror of bench.py's launch guard): every plan is probed on all ranks before any
+    weights load; a rank that raises or hangs in the probe abandons that process group (workers killed, group destroyed) and the
+    next plan starts from fresh processes; when nothing is left the caller's generator simply runs on one GPU.  Frames must equal
+    the single-process run either way, and stderr names what failed."""
+    import torch.distributed as dist
+    path = _checkpoint(tmp_path)
+    _, ref1, _, _, _ = _run(path, tmp_path, "single.mp4")
+    monkeypatch.setenv("ICV_WORLD", "3")
+    monkeypatch.setenv("ICV_DIST_BACKEND", "gloo")
+    monkeypatch.setenv("ICV_WORKER_FACTORY", "mgpu_factory:factory")
+    monkeypatch.setenv("ICV_PARALLELISM", "auto")
+    monkeypatch.setenv("ICV_KV_EXCHANGE", "p2p")
+    monkeypatch.setenv("ICV_WORLD_TIMEOUT_S", "300")
+    monkeypatch.setenv("ICV_WORLD_PROBE_TIMEOUT_S", "8")
+    monkeypatch.setenv("ICV_TEST_POOL_INJECT", inject)
+    monkeypatch.setenv("PYTHONPATH", os.pathsep.join([os.path.dirname(HERE), HERE, os.environ.get("PYTHONPATH", "")]))
+    g = None
+    try:
+        g, got1, _, _, _ = _run(path, tmp_path, "multi.mp4")
+        err = capfd.readouterr().err
+        assert err.count("multi-GPU start with plan") == n_failed
+        if want_plan is None:
+            assert g._pool is None and "continuing on ONE GPU" in err
+            assert np.array_equal(got1, ref1)
+        else:
+            assert g._pool is not None and g._pool.plan == want_plan and len(g._pool.failed_plans) == n_failed
+            assert dist.is_initialized() and dist.get_world_size() == 3
+            assert (g.pipe.parallelism, g.pipe.kv_exchange) == want_plan
+            d = np.abs(ref1.astype(np.int16) - got1.astype(np.int16))
+            assert d.max() <= 2
+    finally:
+        if g is not None and g._pool is not None:
+            g._pool.close()
+        from infinicube_amd.videogen import multigpu
+        multigpu._DEGRADED = None
+    assert not dist.is_initialized()

@@ -39,61 +39,92 @@ cfg, grid = dataclasses.replace(cfg_full, num_layers=LAYERS), GRID_480P
 sd = syn.make_dit_state_dict(cfg, seed=0, device=DEV, dtype=torch.bfloat16)
 bsd = syn.make_buffer_embedder_state_dict(cfg, device=DEV, dtype=torch.bfloat16)
 noise, ctx, bl = syn.make_latent_noise(grid).to(DEV), syn.make_text_context(cfg, 1), syn.make_buffer_latents(cfg, grid)
+ctx2 = syn.make_text_context(cfg, 2)
 peers = torch.randn((grid.S, 2 * cfg.dim), device=DEV).to(torch.bfloat16) * 0.3      # stand-in for the arrived K|V rows
 
 
 class ServedGather:
-    """seqpar.KVGather's interface; the peers' rows are a device copy (what is left of an exchange once it has landed)."""
+    """seqpar.KVGather's interface with the transfer taken out: the peers' rows are ALREADY in the gathered buffer (constant random
+    rows: what is left of an exchange once it has landed) and this rank's own rows are placed by a copy on a SIDE stream, as
+    RCCL's own stream would (an all-gather writes the local shard too) - nothing of the exchange runs on the compute stream.
+    (Round 3's version copied the peers' rows on the compute stream at every start(): ~0.35 ms per layer that no real rank pays.)"""
     timing, n_collectives = None, 0
 
     def __init__(self, world):
         self.world = world
+        self.side = torch.cuda.Stream()
+        self.filled = set()
 
     def start(self, rows, out):
         m = rows.shape[0]
-        out.copy_(peers[: self.world * m])
-        out[:m].copy_(rows)
-        return ()
+        if out.data_ptr() not in self.filled:            # first use of this slice of the gathered buffer: the peers' rows
+            out.copy_(peers[: out.shape[0]])
+            self.filled.add(out.data_ptr())
+        ready = torch.cuda.Event()
+        ready.record()
+        self.side.wait_event(ready)
+        with torch.cuda.stream(self.side):
+            out[:m].copy_(rows)
+            done = torch.cuda.Event()
+            done.record()
+        return (done,)
 
     def wait(self, handle):
-        pass
+        for ev in handle:
+            torch.cuda.current_stream().wait_event(ev)
 
 
-def time_forward(world, chunks, iters=3):
+def time_forward(world, chunks, iters=3, pair=False):
+    """ms per layer of ONE forward on the shard (pair=False), or of BOTH CFG forwards issued as WanDiT.forward_pair (pair=True:
+    what a rank of the `sp` layout runs per step - projections over 2n rows, exchange + attention per branch)."""
     plan = ShardPlan.make(grid.S, world, 0)
     m = WanDiT(cfg, sd, ops, bsd).prepare(grid, plan, kv_gather=ServedGather(world) if world > 1 else None, sp_chunks=chunks, graphs=False)
     ck, bt = m.encode_context(ctx), m.embed_buffers(bl)
-    m.forward_tokens(noise, ck, 500.0, bt, m.head_out[0])
+    cu = m.encode_context(ctx2) if pair else None
+
+    def run():
+        if pair:
+            m.forward_pair(noise, ck, cu, 500.0, bt, m.head_out)
+        else:
+            m.forward_tokens(noise, ck, 500.0, bt, m.head_out[0])
+
+    run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        m.forward_tokens(noise, ck, 500.0, bt, m.head_out[0])
+        run()
     e1.record()
     torch.cuda.synchronize()
     del m
     torch.cuda.empty_cache()
-    return e0.elapsed_time(e1) / iters / LAYERS          # ms per layer-forward (patch embed + head amortised: < 0.1 %)
+    return e0.elapsed_time(e1) / iters / LAYERS          # ms per layer (patch embed + head amortised: < 0.1 %)
 
 
 rows = []
-ONLY = os.environ.get("ONLY")          # "world:chunks" -> time just that shard shape (for a rocprofv3 kernel trace of it)
+ONLY = os.environ.get("ONLY")          # "world:chunks[:pair]" -> time just that shard shape (for a rocprofv3 kernel trace of it)
 if ONLY:
-    w, c = (int(v) for v in ONLY.split(":"))
-    t = time_forward(w, c, iters=int(os.environ.get("ITERS", "3")))
-    print(f"shard 1/{w} chunks {c}: {t:.3f} ms per layer-forward")
+    w, c, *rest = ONLY.split(":")
+    t = time_forward(int(w), int(c), iters=int(os.environ.get("ITERS", "3")), pair=bool(rest))
+    print(f"shard 1/{w} chunks {c}{' pair' if rest else ''}: {t:.3f} ms per layer")
     sys.exit(0)
-base = time_forward(1, 1)
 L = cfg_full.num_layers
-one_gpu_step = 2 * L * base
-print(f"1 GPU: {base:.2f} ms per layer-forward -> {one_gpu_step:.0f} ms per step (2 forwards x {L} layers)")
-for n_gpus, layout, world, fwd in ((2, "cfg+sp", 1, 1), (4, "cfg+sp", 2, 1), (8, "cfg+sp (auto)", 4, 1), (8, "sp", 8, 2), (4, "sp", 4, 2), (2, "sp", 2, 2)):
+# one GPU: the product's default step = the CFG-batched pair (bench.py's `cfg_forwards_batched`)
+base1 = time_forward(1, 1)
+base = time_forward(1, 1, pair=True)
+one_gpu_step = L * base
+print(f"1 GPU: {base:.2f} ms per layer for both forwards of a step (pair-batched; two separate forwards: {2 * base1:.2f}) -> {one_gpu_step:.0f} ms per step x {L} layers")
+for n_gpus, layout, world, pair in ((2, "cfg+sp", 1, False), (4, "cfg+sp", 2, False), (8, "cfg+sp (auto)", 4, False), (8, "sp", 8, True), (8, "sp unpaired", 8, False),
+                                    (4, "sp", 4, True), (2, "sp", 2, True)):
     for chunks in ((1,) if world == 1 else (4, 2)):
-        t = base if world == 1 else time_forward(world, chunks)
-        step = fwd * L * t
-        rows.append(dict(n_gpus=n_gpus, layout=layout, sp_world=world, sp_chunks=chunks, ms_per_layer_forward=t, compute_only_ms_per_step=step,
+        if pair:
+            t = time_forward(world, chunks, pair=True)          # both forwards of the step
+        else:
+            t = (base1 if world == 1 else time_forward(world, chunks)) * (2 if layout.startswith("sp") else 1)
+        step = L * t
+        rows.append(dict(n_gpus=n_gpus, layout=layout, sp_world=world, sp_chunks=chunks, ms_per_layer_per_step=t, compute_only_ms_per_step=step,
                          compute_only_steps_per_s=1e3 / step, compute_only_scaling=one_gpu_step / step))
-        print(f"N = {n_gpus} {layout:14s} shard 1/{world} chunks {chunks}: {t:6.2f} ms per layer-forward -> {step:7.1f} ms per step, "
+        print(f"N = {n_gpus} {layout:14s} shard 1/{world} chunks {chunks}: {t:6.2f} ms per layer per step -> {step:7.1f} ms per step, "
               f"{1e3 / step:.3f} steps/s, x{one_gpu_step / step:.2f} of one GPU (compute only, exchange fully hidden)")
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(dict(model="wan2.1-t2v-14b", S=grid.S, layers_timed=LAYERS, one_gpu_ms_per_step=one_gpu_step, rows=rows), open("gpurun_out/sp_compute_only_projection.json", "w"), indent=1)
