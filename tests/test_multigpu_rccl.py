@@ -144,8 +144,8 @@ def test_shared_gpu_gloo_ranks_equal_single_gpu(tmp_path, gpu_single, world, par
 @pytest.mark.gpu
 @needs_gpus(2)
 @pytest.mark.parametrize("world,parallelism,kv_exchange", [
-    (2, "sp", "allgather"), (2, "sp", "p2p"), (2, "sp", "native"), (2, "cfg+sp", "allgather"),
-    (4, "cfg+sp", "allgather"), (4, "cfg+sp", "p2p"), (4, "sp", "native"), (8, "auto", "allgather"), (8, "sp", "p2p")])
+    (2, "sp", "allgather"), (2, "sp", "native"), (2, "cfg+sp", "allgather"),
+    (4, "cfg+sp", "p2p"), (4, "sp", "native"), (8, "auto", "allgather"), (8, "sp", "p2p")])
 def test_rccl_loop_ranks_equal_single_gpu(tmp_path, gpu_single, world, parallelism, kv_exchange):
     """A full CFG loop on N GPUs over RCCL — `sp` and `cfg+sp`, the three K|V transports — against the 1-GPU latent."""
     if _n_gpus() < world:
@@ -155,17 +155,25 @@ def test_rccl_loop_ranks_equal_single_gpu(tmp_path, gpu_single, world, paralleli
     _close(got, gpu_single["loop"], f"RCCL x{world} {parallelism}/{kv_exchange}", rel_bound=1e-2, psnr_bound=50.0)
 
 
+BIG_LAYER = ["--backend", "nccl", "--ops", "hip", "--model", "14b", "--frames", 93, "--height", 480, "--width", 832, "--scenario", "layer",
+             "--sp-chunks", 4]
+
+
+@pytest.fixture(scope="module")
+def big_layer_single(tmp_path_factory):
+    """The 1-GPU run of the 14B block, once for the three transports (the driver's suite has a time limit)."""
+    return run_ranks(1, str(tmp_path_factory.mktemp("ranks_big") / "single.pt"), BIG_LAYER, timeout=600)
+
+
 @pytest.mark.gpu
 @needs_gpus(2)
 @pytest.mark.parametrize("kv_exchange", ["allgather", "p2p", "native"])
-def test_rccl_14b_layer_full_S_ranks_equal_single_gpu(tmp_path, kv_exchange):
+def test_rccl_14b_layer_full_S_ranks_equal_single_gpu(tmp_path, big_layer_single, kv_exchange):
     """Config #4's layer: ONE Wan2.1-14B block at S = 37 440 sharded over every GPU of the box, K|V rows over RCCL,
     against the same block on one GPU."""
     n = max(w for w in (2, 4, 8) if w <= _n_gpus())
-    big = ["--backend", "nccl", "--ops", "hip", "--model", "14b", "--frames", 93, "--height", 480, "--width", 832, "--scenario", "layer",
-           "--sp-chunks", 4]
-    ref = run_ranks(1, str(tmp_path / "single.pt"), big, timeout=900)
-    got = run_ranks(n, str(tmp_path / "multi.pt"), big + ["--kv-exchange", kv_exchange], timeout=900)
+    big, ref = BIG_LAYER, big_layer_single
+    got = run_ranks(n, str(tmp_path / "multi.pt"), big + ["--kv-exchange", kv_exchange], timeout=600)
     assert got["info"]["sp_world"] == n and got["info"]["kv_collectives"] == 4
     _close(got, ref, f"RCCL x{n} 14B block S=37440 {kv_exchange}")
 
@@ -225,7 +233,7 @@ def test_bench_falls_back_and_says_so(inject, plan_prefix, n_failed):
     cmd = [sys.executable, "bench.py", "--gpus", "4", "--model", "small", "--frames", "17", "--height", "256", "--width", "448", "--steps", "2",
            "--warmup", "1", "--no-cpu-baseline"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    env.update(ICV_BENCH_SHARE_GPU="1", ICV_DIST_BACKEND="gloo", ICV_GUARD_INJECT=inject, ICV_GUARD_BUDGETS="autotune=25", ICV_BENCH_DIST_TIMEOUT_S="40")
+    env.update(ICV_BENCH_SHARE_GPU="1", ICV_DIST_BACKEND="gloo", ICV_GUARD_INJECT=inject, ICV_GUARD_BUDGETS="autotune=12", ICV_BENCH_DIST_TIMEOUT_S="40")
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]

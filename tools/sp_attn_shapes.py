@@ -56,6 +56,15 @@ for world in (4, 8):
             for c in range(C):
                 chunk_call(q, k[b[c]:b[c + 1]], v[b[c]:b[c + 1]], o, acc, ml, H, c == 0, c == C - 1, main.cuda_stream)
         rows.append((f"{C} ramped chunks", timeit(seq)))
+        if C == 4:     # the layout the DiT really reads: K and V as the two column halves of ONE gathered [S, 2d] row matrix
+            kv = torch.cat([k, v], dim=1).contiguous()
+            kh, vh = kv[:, :d], kv[:, d:]
+
+            def seq_kv():
+                for c in range(C):
+                    chunk_call(q, kh[b[c]:b[c + 1]], vh[b[c]:b[c + 1]], o, acc, ml, H, c == 0, c == C - 1, main.cuda_stream)
+            rows.append((f"{C} ramped chunks, K|V halves of one [S, 2d] matrix", timeit(seq_kv)))
+            del kv, kh, vh
         lib.icv_set_option(b"attn7_short", 1 << 30)
         rows.append((f"{C} ramped chunks, 4-wave blocks two per CU", timeit(seq)))
         lib.icv_set_option(b"attn7_short", -1)
