@@ -49,35 +49,25 @@ LATENT_STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743,
 class CausalConv3d(nn.Conv3d):
     """Conv3d with symmetric spatial padding and all temporal padding on the left (zeros).
 
-    ``split2d`` (set by WanVAE on the GPU, ICV_VAE_CONV=split2d|native): a 3x3x3 stride-1 convolution over a clip is the sum
-    over its three temporal taps of a 3x3 2-D convolution over the frames - sum_dt conv2d(x[t + dt], w[:, :, dt]).  In NDHWC
-    memory the frames of a [1, C, T, H, W] clip ARE an NHWC batch [T, C, H, W] (a view, no copy), so each tap is one stock
-    conv2d call; MIOpen's 2-D bf16 NHWC kernels are far better tuned than its 3-D ones (measured in
-    profiles/r04/vae_conv_split2d.md).  The three bf16 tap outputs are summed in fp32 and rounded once."""
+    ``fold_pad`` (set by WanVAE on the GPU, ICV_VAE_PAD=conv|copy): instead of materialising the padded clip with F.pad (a full
+    copy of every activation: 8 % of a decode, profiles/r04/vae_decode_kernel_stats.md) the convolution pads symmetrically
+    itself - 2p frames on BOTH sides in time - and the 2p trailing output frames, the only ones that saw the right-hand zeros,
+    are dropped: output frame t of the symmetric convolution reads input frames t-2p..t, so the first T frames ARE the causal
+    result, bit for bit the same sums.  The slice is a prefix of the (time-major) NDHWC buffer: a view."""
 
-    split2d = False
+    fold_pad = False
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self._pad = (self.padding[2], self.padding[2], self.padding[1], self.padding[1], 2 * self.padding[0], 0)
+        self._sym = (2 * self.padding[0], self.padding[1], self.padding[2])
         self.padding = (0, 0, 0)
-        self._w2d = None
 
     def forward(self, x):
-        x = F.pad(x, self._pad)
-        if (self.split2d and x.is_cuda and self.kernel_size == (3, 3, 3) and self.stride == (1, 1, 1) and x.shape[0] == 1
-                and x.is_contiguous(memory_format=torch.channels_last_3d)):
-            if self._w2d is None or self._w2d[0].device != x.device or self._w2d[0].dtype != x.dtype:
-                self._w2d = [self.weight.detach()[:, :, dt].contiguous(memory_format=torch.channels_last) for dt in range(3)]
-            _, c, t, h, w = x.shape
-            frames = x[0].permute(1, 0, 2, 3)                    # [T+2, C, H, W]: a view of the NDHWC clip as an NHWC batch
-            T = t - 2
-            acc = None
-            for dt in range(3):
-                y = F.conv2d(frames[dt: dt + T], self._w2d[dt], self.bias if dt == 0 else None)
-                acc = y.float() if acc is None else acc.add_(y)
-            return acc.to(x.dtype).permute(1, 0, 2, 3)[None]     # [1, OC, T, H', W'] (NDHWC in memory)
-        return super().forward(x)
+        if self.fold_pad and self.stride == (1, 1, 1) and any(self._sym):
+            y = F.conv3d(x, self.weight, self.bias, self.stride, self._sym, self.dilation, self.groups)
+            return y[:, :, : x.shape[2]] if self._sym[0] else y
+        return super().forward(F.pad(x, self._pad))
 
 
 class RMS_norm(nn.Module):
@@ -265,12 +255,13 @@ class WanVAE:
         # around every convolution (measured: encode 1.28 -> 1.11 s, decode 2.09 -> 1.92 s, search 48 -> 27 s, -3.4 GiB);
         # ICV_VAE_CHANNELS_LAST=0 switches it off
         self.channels_last = os.environ.get("ICV_VAE_CHANNELS_LAST", "1") == "1" and torch.device(device).type == "cuda"
-        # ICV_VAE_CONV=split2d: every 3x3x3 convolution as three 2-D convolutions over the frames (CausalConv3d.split2d)
-        self.conv_mode = os.environ.get("ICV_VAE_CONV", "native")
+        # the causal pad folded into the convolution (CausalConv3d.fold_pad; profiles/r04/vae_layer_tuning.md: decode 1.91 -> 1.79 s,
+        # encode 1.11 -> 1.07 s; ICV_VAE_PAD=copy restores the F.pad form)
+        self.fold_pad = os.environ.get("ICV_VAE_PAD", "conv") == "conv"
         if self.channels_last:
             for m in self.net.modules():
                 if isinstance(m, CausalConv3d):
-                    m.split2d = self.conv_mode == "split2d"
+                    m.fold_pad = self.fold_pad
             for m in self.net.modules():
                 if isinstance(m, nn.Conv3d):
                     m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last_3d)
