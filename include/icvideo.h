@@ -226,6 +226,16 @@ int icv_instance_overlay_u8(const unsigned char* semantics_rgb, const int* insta
  * one rounded f32 multiply, truncation toward zero, wrap modulo 2^16.  depth f32 [n] (16-byte aligned), out u16 [n]. */
 int icv_depth_to_u16(const float* depth, int64_t n, float scale, unsigned short* out, void* stream);
 
+/* ---- the Wan-VAE's channel RMS norm (+ SiLU) as ONE pass over NDHWC rows ----------------------
+ * Replaces, inside the tiled VAE encode / decode the reference asks for with `tiled=True`
+ * [R infinicube/videogen/inference.py:69,171,225], the fork's `RMS_norm` (F.normalize over channels * sqrt(C) * gamma)
+ * and the `nn.SiLU` that follows it in every residual block and head ([EXT] public Wan2.1 VAE): as stock ops five
+ * elementwise / reduction passes over the activation.  x, out bf16 [rows, C] (C contiguous: the pixels of an NDHWC / NHWC
+ * buffer; out may alias x), gamma f32 [C]:   y = x / max(|x|_2, eps) * scale * gamma;  act = 1: y = y * sigmoid(y).
+ * fp32 inside, one rounding to bf16.  C % 8 == 0, C <= 2048. */
+int icv_rmsnorm_act_rows(const void* x, void* out, const float* gamma, int64_t rows, int64_t C, float scale,
+                         float eps, int act, void* stream);
+
 /* ---- voxel ray-cast of the guidance-buffer renderer ------------------------------------------
  * Replaces the three fVDB-bound calls of `generate_infinicube_buffer_from_fvdb_grid`
  * [R infinicube/utils/fvdb_utils.py:572-605]: `get_zdepth_map_from_voxel` (`segments_along_rays(o, d, 1, eps=1e-1)`

@@ -78,7 +78,22 @@ class RMS_norm(nn.Module):
         self.scale = dim ** 0.5
         self.gamma = nn.Parameter(torch.ones((dim, *bdims) if channel_first else (dim,)))
 
+    # set by WanVAE on the GPU (ICV_VAE_NORM=hip|stock): ("lib", act) -> the norm (and the SiLU that follows it in the network, which
+    # is then an Identity) run as ONE libicvideo kernel over the NDHWC rows (csrc/vae_ops.hip, icv_rmsnorm_act_rows)
+    fused = None
+
     def forward(self, x):
+        if (self.fused is not None and self.channel_first and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() in (4, 5)
+                and x.is_contiguous(memory_format=torch.channels_last_3d if x.dim() == 5 else torch.channels_last)):
+            from .. import native
+            lib, act = self.fused
+            if getattr(self, "_g32", None) is None or self._g32.device != x.device:
+                self._g32 = self.gamma.detach().reshape(-1).to(device=x.device, dtype=torch.float32).contiguous()
+            out = torch.empty_like(x)          # same NDHWC strides
+            c = x.shape[1]
+            native.check(lib.icv_rmsnorm_act_rows(x.data_ptr(), out.data_ptr(), self._g32.data_ptr(), x.numel() // c, c, self.scale, 1e-12,
+                                                  int(act), torch.cuda.current_stream(x.device).cuda_stream), "icv_rmsnorm_act_rows")
+            return out
         return F.normalize(x, dim=(1 if self.channel_first else -1)) * self.scale * self.gamma
 
 
@@ -258,10 +273,26 @@ class WanVAE:
         # the causal pad folded into the convolution (CausalConv3d.fold_pad; profiles/r04/vae_layer_tuning.md: decode 1.91 -> 1.79 s,
         # encode 1.11 -> 1.07 s; ICV_VAE_PAD=copy restores the F.pad form)
         self.fold_pad = os.environ.get("ICV_VAE_PAD", "conv") == "conv"
+        # the channel RMS norm + the SiLU behind it as one HIP pass over the NDHWC rows (RMS_norm.fused; profiles/r04/vae_layer_tuning.md);
+        # ICV_VAE_NORM=stock keeps the composite torch ops
+        self.hip_norm = os.environ.get("ICV_VAE_NORM", "hip") == "hip" and dtype == torch.bfloat16
         if self.channels_last:
             for m in self.net.modules():
                 if isinstance(m, CausalConv3d):
                     m.fold_pad = self.fold_pad
+            if self.hip_norm:
+                from .. import native
+                lib = native.lib()
+                for seq in self.net.modules():
+                    if isinstance(seq, nn.Sequential):
+                        kids = list(seq.named_children())
+                        for (n0, a), (n1, b) in zip(kids[:-1], kids[1:]):
+                            if isinstance(a, RMS_norm) and isinstance(b, nn.SiLU):
+                                a.fused = (lib, 1)
+                                setattr(seq, n1, nn.Identity())      # no parameters: the state-dict layout is unchanged
+                for m in self.net.modules():
+                    if isinstance(m, RMS_norm) and m.fused is None and m.channel_first:
+                        m.fused = (lib, 0)                            # the attention block's norm (no activation behind it)
             for m in self.net.modules():
                 if isinstance(m, nn.Conv3d):
                     m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last_3d)
