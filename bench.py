@@ -467,10 +467,20 @@ def run_rank(args, world, rank, phase, stdout_fd):
             cands = [(m, c) for m in ("allgather", "p2p", "native") for c in sorted({args.sp_chunks, 2}, reverse=True)]
             if share:      # several ranks on ONE GPU (development boxes): RCCL refuses duplicate devices in a communicator
                 cands = [mc for mc in cands if mc[0] != "native"]
+            def exchange_only():          # one layer's K|V exchange with nothing to hide under: the raw transfer
+                handles, _ = model._sp_start_gather()
+                for h in handles:
+                    model.kv_gather.wait(h)
+
             (args.kv_exchange, args.sp_chunks), table = autotune_kv_exchange(
-                model, two_layers, sync, cands, reps=2, reduce_max=reduce_max,
+                model, two_layers, sync, cands, reps=2, reduce_max=reduce_max, exchange_only=exchange_only,
                 log=(lambda m: print(f"[bench] {m}", file=sys.stderr, flush=True)) if rank == 0 else None)
+            recv = 2 * 2 * plan.n_tok * cfg.dim * (layout.sp_world - 1)         # bytes each rank RECEIVES per layer exchange (k | v rows, bf16)
+            for row in table:
+                if row.get("exchange_ms"):
+                    row["recv_gb_per_s_per_rank"] = recv / (row["exchange_ms"] * 1e-3) / 1e9
             autotune = {"seconds": time.perf_counter() - t_tune, "layers_timed": min(2, cfg.num_layers), "table": table,
+                        "bytes_received_per_rank_per_layer_exchange": recv,
                         "chosen": {"kv_exchange": args.kv_exchange, "sp_chunks": args.sp_chunks}}
         else:
             args.kv_exchange = "allgather"          # cfg+sp at N = 2: no K|V exchange at all

@@ -296,7 +296,7 @@ def gather_latent(latent: torch.Tensor, plan: ShardPlan, grid, group=None) -> to
     return full.reshape(T, Hp, Wp, C, 2, 2).permute(3, 0, 1, 4, 2, 5).reshape(C, T, H8, W8).contiguous()
 
 
-def autotune_kv_exchange(model, run_layers, sync, candidates=None, reps: int = 2, reduce_max=None, log=None):
+def autotune_kv_exchange(model, run_layers, sync, candidates=None, reps: int = 2, reduce_max=None, log=None, exchange_only=None):
     """Start-up choice of the K|V exchange (transport x chunk count) by MEASUREMENT on the ranks that will run it.
 
     xGMI is point-to-point and what RCCL schedules over it is not known before the first contact: ``allgather`` may ring
@@ -306,12 +306,14 @@ def autotune_kv_exchange(model, run_layers, sync, candidates=None, reps: int = 2
     / connection set-up happens there) and ``reps`` times under a timer; the time a layer takes IS the compute plus whatever
     part of the transfer stayed exposed.  Every rank must end with the same choice: times are max-reduced over the ranks
     (``reduce_max(list) -> list``) and ties break by candidate order.  A candidate that raises is dropped on every rank
-    (its failure is max-reduced too).  Returns (best (mode, chunks), table of dict rows)."""
+    (its failure is max-reduced too).  ``exchange_only()`` (optional): one layer's exchange with nothing to hide under; its time is
+    recorded next to the layer time (``exchange_ms``: the raw transfer, for the bandwidth it implies), never used for the choice.
+    Returns (best (mode, chunks), table of dict rows)."""
     import time
     cands = list(candidates or [(m, c) for m in ("allgather", "p2p", "native") for c in (4, 2)])
     table = []
     for mode, chunks in cands:
-        ms, err = float("inf"), ""
+        ms, err, xms = float("inf"), "", 0.0
         try:
             model.set_kv_exchange(mode, chunks)
             run_layers()
@@ -321,15 +323,24 @@ def autotune_kv_exchange(model, run_layers, sync, candidates=None, reps: int = 2
                 run_layers()
             sync()
             ms = 1e3 * (time.perf_counter() - t0) / reps
+            if exchange_only is not None:
+                exchange_only()
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    exchange_only()
+                sync()
+                xms = 1e3 * (time.perf_counter() - t0) / 3
         except Exception as e:      # noqa: BLE001 - a transport that cannot run here is simply not a candidate
             err = f"{type(e).__name__}: {e}"[:200]
         bad = 1.0 if err else 0.0
         if reduce_max is not None:
-            ms_r, bad = reduce_max([ms if not err else 0.0, bad])
+            ms_r, bad, xms = reduce_max([ms if not err else 0.0, bad, xms])
             ms = float("inf") if bad else ms_r
         elif err:
             ms = float("inf")
-        table.append(dict(kv_exchange=mode, sp_chunks=chunks, ms=None if ms == float("inf") else ms, error=err or None))
+        table.append(dict(kv_exchange=mode, sp_chunks=chunks, ms=None if ms == float("inf") else ms, error=err or None,
+                          exchange_ms=(xms or None) if ms != float("inf") else None))
         if log:
             log(f"autotune {mode:9s} chunks {chunks}: " + (f"{ms:.2f} ms" if ms != float("inf") else f"unusable ({err or 'failed on another rank'})"))
     usable = [(r["ms"], i) for i, r in enumerate(table) if r["ms"] is not None]

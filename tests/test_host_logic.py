@@ -379,3 +379,67 @@ def test_cfg_batched_forward_pair_equals_sequential_forwards(name, kw, force_sp)
     m = WanDiT(cfg, sd, OracleOps(), bsd, **kw).prepare(GRID)
     m.PAIR_MAX_OPERAND_BYTES = 1000                      # a workload whose 2n-row operands would pass the 4 GiB offset limit
     assert not m._pair_ok()
+
+
+def _autotune_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from infinicube_amd.videogen.seqpar import autotune_kv_exchange
+        sd, bsd, noise, c1, c2, bl = _inputs()
+        plan = ShardPlan.make(GRID.S, world, rank)
+        m = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID, plan, kv_exchange="allgather")
+        ck, bt = m.encode_context(c1), m.embed_buffers(bl)
+
+        def two_layers():
+            m.forward_tokens(noise, ck, 500.0, bt, m.head_own, num_layers=2)
+
+        def exchange_only():
+            handles, _ = m._sp_start_gather()
+            for h in handles:
+                m.kv_gather.wait(h)
+
+        def reduce_max(vals):
+            t = torch.tensor(vals, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return t.tolist()
+
+        best, table = autotune_kv_exchange(m, two_layers, dist.barrier, [("allgather", 3), ("p2p", 3), ("native", 3), ("p2p", 1)], reps=1,
+                                           reduce_max=reduce_max, exchange_only=exchange_only)
+        # the engine now runs the chosen exchange: a loop on it still equals the single-process loop
+        lat = noise.clone()
+        m.denoise(lat, ck, m.encode_context(c2), bt, FlowMatchScheduler(2), 5.0)
+        lat = gather_latent(lat, plan, GRID)
+        q.put((rank, best, table, m.kv_gather.mode, len(m.sp_bounds) - 1, lat))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_kv_exchange_autotune_agrees_across_ranks_and_drops_what_cannot_run():
+    """seqpar.autotune_kv_exchange over two real gloo ranks: every candidate is timed on a couple of real layers, the times are
+    max-reduced so both ranks choose the SAME (transport, chunks); `native` cannot run here (no GPU, no RCCL) and is dropped on
+    every rank instead of failing the run; the engine is left on the chosen exchange and a loop on it matches the single process."""
+    sd, bsd, noise, c1, c2, bl = _inputs()
+    single = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID)
+    ref = noise.clone()
+    single.denoise(ref, single.encode_context(c1), single.encode_context(c2), single.embed_buffers(bl), FlowMatchScheduler(2), 5.0)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() * 3 + 77) % 2000
+    procs = [ctx.Process(target=_autotune_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, best0, table0, mode0, chunks0, lat0), (_, best1, table1, mode1, chunks1, lat1) = got
+    assert best0 == best1 and (mode0, chunks0) == (mode1, chunks1) == tuple(best0)
+    assert [r["kv_exchange"] for r in table0] == ["allgather", "p2p", "native", "p2p"]
+    native_row = table0[2]
+    assert native_row["ms"] is None and native_row["error"] and table1[2]["ms"] is None
+    assert all(r["ms"] > 0 and r["exchange_ms"] > 0 for i, r in enumerate(table0) if i != 2)
+    assert [r["ms"] for r in table0] == [r["ms"] for r in table1], "the reduced times are identical on every rank"
+    assert torch.equal(lat0, lat1) and float((lat0 - ref).norm() / ref.norm()) < 2e-3
