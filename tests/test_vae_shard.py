@@ -109,3 +109,51 @@ def test_worker_pool_frames_with_the_tiled_vae_sharded_over_the_ranks(tmp_path, 
         if g is not None and g._pool is not None:
             g._pool.close()
     assert not dist.is_initialized()
+
+
+def _fixed_latent():
+    return torch.randn((16, 3, 8, 12), generator=torch.Generator().manual_seed(3))
+
+
+def _gpu_shard_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, HERE)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from infinicube_amd.videogen.vae import TileShard, WanVAE, WanVAENet
+        torch.manual_seed(11)
+        vae = WanVAE(WanVAENet(dim=32), "cuda:0", torch.bfloat16)
+        lats = vae.encode_many(_clips(), shard=TileShard.current(), **TILE)
+        vid = vae.decode(_fixed_latent(), shard=TileShard.current(), **TILE)
+        torch.cuda.synchronize()
+        q.put((rank, [x.float().cpu() for x in lats], vid.float().cpu()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_vae_tiles_on_the_gpu_two_ranks_sharing_it():
+    """The same dealing of tiles with the PRODUCT configuration of the VAE (bf16, NDHWC, folded pad, HIP norm kernel) in two
+    processes that share the one GPU of the box (gloo carries the device tensors): both ranks end with IDENTICAL latents and
+    frames (they blend the same broadcast tiles in the same order) and those agree with the unsharded call to bf16 rounding
+    (MIOpen may pick different kernels in different processes, so not bit for bit)."""
+    from infinicube_amd.videogen.vae import WanVAE, WanVAENet
+    torch.manual_seed(11)
+    vae = WanVAE(WanVAENet(dim=32), "cuda:0", torch.bfloat16)
+    ref_l = [x.float().cpu() for x in vae.encode_many(_clips(), **TILE)]
+    ref_v = vae.decode(_fixed_latent(), **TILE).float().cpu()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() * 11 + 5) % 2000
+    procs = [ctx.Process(target=_gpu_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=600) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, l0, v0), (_, l1, v1) = got
+    assert all(torch.equal(a, b) for a, b in zip(l0, l1)) and torch.equal(v0, v1), "the ranks blended different tiles"
+    for a, b, what in ((l0[0], ref_l[0], "latent"), (l0[1], ref_l[1], "latent 2"), (v0, ref_v, "video")):
+        rel = float((a - b).norm() / b.norm().clamp_min(1e-6))
+        assert rel < 3e-2, f"{what}: sharded vs unsharded rel-L2 {rel}"
