@@ -599,7 +599,8 @@ def run_rank(args, world, rank, phase, stdout_fd):
                 "cfg_stem_shared": bool(args.share_stem),
                 # the two forwards of a step issued as ONE batch of 2n rows through the token-local kernels (WanDiT.forward_pair;
                 # bit-identical to two sequential forwards, ICV_CFG_BATCH=0 switches it off): same work, better tile quantisation
-                "cfg_forwards_batched": bool(world == 1 and model._pair_ok()),
+                # (single rank, and every rank of the `sp` layout)
+                "cfg_forwards_batched": bool(layout.mode == "sp" and model._pair_ok()),     # cfg+sp: one forward per rank, nothing to batch
                 "c_abi_calls_per_forward": abi_calls / (args.steps * (1 if layout.mode == "cfg+sp" else 2)),
                 "host_enqueue_ms_per_step": 1e3 * t_issue_one,       # one extra step issued on a drained queue (untimed for the metric)
                 "host_ms_in_timed_loop_per_step": 1e3 * t_in_loop / args.steps,   # includes blocking inside launches once the HIP queue is full: NOT issue cost

@@ -44,7 +44,8 @@ def _dev():
 def semantic_to_color(semantics):
     """semantics: int array/tensor of class indices (any shape) -> float32 colours [..., 3] in [0,1] (numpy)."""
     lib, dev = native.lib(), _dev()
-    sem = torch.as_tensor(np.asarray(semantics.cpu() if isinstance(semantics, torch.Tensor) else semantics))
+    # a CUDA tensor (e.g. the voxel renderer's class map) stays on the device: no host round trip before the kernel
+    sem = semantics if isinstance(semantics, torch.Tensor) else torch.as_tensor(np.asarray(semantics))
     shape = tuple(sem.shape)
     sem_d = sem.to(dev, torch.int32).contiguous().reshape(-1)
     lut = torch.from_numpy(WAYMO_PALETTE[WAYMO_MAPPING]).to(dev).contiguous()
@@ -70,8 +71,10 @@ def generate_rgb_semantic_buffer(semantics_rgb: np.ndarray, instance_buffer) -> 
     """semantics_rgb uint8 [N,H,W,3], instance_buffer uint16 [N,H,W] -> uint8 [N,H,W,3]: instance colour where
     instance > 0, semantic colour elsewhere."""
     lib, dev = native.lib(), _dev()
-    inst_np = instance_buffer.cpu().numpy() if isinstance(instance_buffer, torch.Tensor) else np.asarray(instance_buffer)
-    inst = torch.from_numpy(inst_np.astype(np.int32)).to(dev).contiguous()
+    if isinstance(instance_buffer, torch.Tensor):          # device-resident ids stay there (only the few unique ids cross PCIe)
+        inst = instance_buffer.to(dev, torch.int32).contiguous()
+    else:
+        inst = torch.from_numpy(np.asarray(instance_buffer).astype(np.int32)).to(dev).contiguous()
     ids = torch.unique(inst).cpu().numpy()
     table = create_instance_mapping(ids[ids != 0])
     lut = np.zeros((65536, 3), dtype=np.uint8)
