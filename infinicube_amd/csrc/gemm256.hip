@@ -87,6 +87,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
   static_assert(!EARLY_B1 || TWO_PHASE, "EARLY_B1 is a variant of the two-phase schedule");
   // round 3 A/B (profiles/r03/gemm_cache_policy_ab.txt): non-temporal DMA loads of the activation (bit 16) / weight (bit 32) stream
   constexpr int AUX_A = (SCH & 16) ? 2 : 0, AUX_B = (SCH & 32) ? 2 : 0;
+  // round 4 A/B (SCH bit 6, "k-split"): the four 16 KiB units of a stage are cut by K-HALF instead of by row half - AK0 / AK1 =
+  // all 256 A rows x k [0,32) / [32,64), BK0 / BK1 likewise - and a phase is ONE k-step of all 32 accumulators: both phases read
+  // 12 fragments per wave (8 a + 4 b) instead of 16 + 8, so the two L-segments of a K-tile load the LDS port equally
+  // (profiles/r04/gemm_ksplit_ab.txt).  Same DMA distances, same WAR / RAW argument as the two-phase schedule below.
+  constexpr bool KSPLIT = (SCH & 64) != 0;
+  static_assert(!KSPLIT || (MF == 16 && TWO_PHASE && !EARLY_B1), "k-split is a variant of the two-phase 16x16x32 schedule");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -128,6 +134,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
       offB[h][q] = (unsigned)((rb * p.ldw + c * 8) * 2);
     }
   }
+  // k-split units: unit row u = block row (A: m0 + u, W: n0 + u), 64-byte rows (32 k), 4 chunks of 16 B, physical chunk =
+  // logical ^ ((u >> 2) & 3): 16 consecutive rows at one logical chunk then cover all 16 chunk slots of the 256-byte bank space
+  unsigned offKA[2], offKB[2];
+  if (KSPLIT) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int u = q * 128 + (tid >> 2);
+      const int c = (tid & 3) ^ ((u >> 2) & 3);
+      int64_t ra = m0 + u;
+      ra = ra < p.M ? ra : p.M - 1;
+      offKA[q] = (unsigned)((ra * p.lda + c * 8) * 2);
+      int64_t rb = n0 + u;
+      rb = rb < p.N ? rb : p.N - 1;
+      offKB[q] = (unsigned)((rb * p.ldw + c * 8) * 2);
+    }
+  }
   const char* Ab = reinterpret_cast<const char*>(p.A);
   const char* Wb = reinterpret_cast<const char*>(p.W);
   const int nt = (int)(p.K / BK);
@@ -165,6 +187,68 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
   }
   constexpr int NAF = (MF == 16) ? 4 : 2, NBF = (MF == 16) ? 2 : 1, FROWS = MF * 128;  // frags per half, bytes per frag row block
 
+  if (KSPLIT) {
+    constexpr int U_AK0 = 0, U_AK1 = 1, U_BK0 = 2, U_BK1 = 3;
+    // fragment addressing: a-fragment i8 (0..7) = block rows wr*128 + (i8>>2)*64 + (i8&3)*16 + fr, b-fragment j4 (0..3) = block cols
+    // wc*64 + (j4>>1)*32 + (j4&1)*16 + fr (the epilogue's mapping); lane (fr, kq) reads the 16-byte chunk kq of its row
+    const int kar = wr * 128 + fr, kbr = wc * 64 + fr;
+    const int ka_off = kar * 64 + ((kq ^ ((kar >> 2) & 3)) << 4);
+    const int kb_off = kbr * 64 + ((kq ^ ((kbr >> 2) & 3)) << 4);
+    bf16x8 kaf[8], kbf[4];
+    dma_unit<AUX_A>(Ab, offKA, kbyte(0), smem + U_AK0 * UNIT_BYTES, wave);
+    dma_unit<AUX_B>(Wb, offKB, kbyte(0), smem + U_BK0 * UNIT_BYTES, wave);
+    dma_unit<AUX_A>(Ab, offKA, kbyte(0) + 64, smem + U_AK1 * UNIT_BYTES, wave);
+    dma_unit<AUX_B>(Wb, offKB, kbyte(0) + 64, smem + U_BK1 * UNIT_BYTES, wave);
+    dma_unit<AUX_A>(Ab, offKA, kbyte(1), smem + STAGE_BYTES + U_AK0 * UNIT_BYTES, wave);
+    dma_unit<AUX_B>(Wb, offKB, kbyte(1), smem + STAGE_BYTES + U_BK0 * UNIT_BYTES, wave);
+    G256_VMCNT8();            // AK0(0), BK0(0) landed (4 younger units in flight)
+    G256_BARRIER();
+    if (wr == 1) G256_BARRIER();  // stagger: group 1 runs one barrier behind group 0
+#define G256K_READ(UA, UB)                                                                                         \
+    {                                                                                                              \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                \
+        kbf[j] = *reinterpret_cast<const bf16x8*>(cur + (UB) * UNIT_BYTES + kb_off + ((j >> 1) * 32 + (j & 1) * 16) * 64); \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                \
+        kaf[i] = *reinterpret_cast<const bf16x8*>(cur + (UA) * UNIT_BYTES + ka_off + ((i >> 2) * 64 + (i & 3) * 16) * 64); \
+    }
+#define G256K_MFMA()                                                                                               \
+    {                                                                                                              \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
+      __builtin_amdgcn_s_setprio(1);                                                                               \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                \
+      _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                           \
+        const int j = (i & 1) ? 3 - jj : jj;          /* boustrophedon: consecutive MFMAs share an operand */      \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kbf[j], kaf[i], acc[i][j], 0, 0, 0);                   \
+      }                                                                                                            \
+      __builtin_amdgcn_s_setprio(0);                                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
+    }
+    // Per K-tile t (stage s = t&1), each phase = L-segment ; barrier ; 32 MFMA ; barrier :
+    //   P1: read AK0, BK0 | DMA AK1(t+1), BK1(t+1) -> s^1 | vmcnt(8) : AK1, BK1(t) landed (issued in P1(t-1); younger: P2(t-1)'s and these)
+    //   P2: read AK1, BK1 | DMA AK0(t+2), BK0(t+2) -> s   | vmcnt(8) : AK0, BK0(t+1) landed (issued in P2(t-1))
+    // WAR: a unit is re-staged in the phase after its last read, by which time every wave's reads of it were retired
+    // (lgkmcnt(0)) before a barrier the re-staging group has passed - the argument of the two-phase schedule, for all four units.
+    for (int t = 0; t < nt; ++t) {
+      char* cur = smem + (t & 1) * STAGE_BYTES;
+      char* oth = smem + ((t + 1) & 1) * STAGE_BYTES;
+      G256K_READ(U_AK0, U_BK0);
+      if (!(p.ablate & 1)) dma_unit<AUX_A>(Ab, offKA, kbyte(t + 1) + 64, oth + U_AK1 * UNIT_BYTES, wave);
+      if (!(p.ablate & 1)) dma_unit<AUX_B>(Wb, offKB, kbyte(t + 1) + 64, oth + U_BK1 * UNIT_BYTES, wave);
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      G256_BARRIER();
+      G256K_MFMA();
+      G256_BARRIER();
+      G256K_READ(U_AK1, U_BK1);
+      if (!(p.ablate & 1)) dma_unit<AUX_A>(Ab, offKA, kbyte(t + 2), cur + U_AK0 * UNIT_BYTES, wave);
+      if (!(p.ablate & 1)) dma_unit<AUX_B>(Wb, offKB, kbyte(t + 2), cur + U_BK0 * UNIT_BYTES, wave);
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      G256_BARRIER();
+      G256K_MFMA();
+      G256_BARRIER();
+    }
+#undef G256K_READ
+#undef G256K_MFMA
+  } else {
   // ---- prologue: tile 0 complete + A0,B0 of tile 1 ----
   dma_unit<AUX_A>(Ab, offA[0], kbyte(0), smem + U_A0 * UNIT_BYTES, wave);
   dma_unit<AUX_B>(Wb, offB[0], kbyte(0), smem + U_B0 * UNIT_BYTES, wave);
@@ -301,6 +385,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
     G256_BARRIER();
   }
 #undef G256_MFMA
+  }   // !KSPLIT
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain tail DMA before the LDS is released
   if (wr == 0) G256_BARRIER();                       // re-balance the stagger
 
@@ -421,7 +506,7 @@ int icv_gemm256_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw,
   const bool m32 = icv_get_option_int("gemm256_mfma", 16) == 32;
   // schedule variant (A/B switch "gemm256_sched"): bit 0 = two 32-MFMA phases per K-tile, bit 1 = batched residual loads,
   // bit 2 (with both: 7) = B1 of the next tile requested a full tile ahead
-  const int sch = icv_get_option_int("gemm256_sched", G256_SCHED_DEFAULT) & 63;
+  const int sch = icv_get_option_int("gemm256_sched", G256_SCHED_DEFAULT) & 127;
 #define G256_CASE(E_)                                                                              \
   case E_:                                                                                         \
     if (m32) return (sch & 1) ? g256::launch<E_, 32, 1>(p, st) : g256::launch<E_, 32, 0>(p, st);   \
@@ -434,6 +519,7 @@ int icv_gemm256_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw,
       case 19: return g256::launch<E_, 16, 19>(p, st);                                             \
       case 35: return g256::launch<E_, 16, 35>(p, st);                                             \
       case 51: return g256::launch<E_, 16, 51>(p, st);                                             \
+      case 67: return g256::launch<E_, 16, 67>(p, st);                                             \
       default: return g256::launch<E_, 16, 3>(p, st);                                              \
     }
   switch (epilogue) {

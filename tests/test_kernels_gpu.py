@@ -168,6 +168,41 @@ def test_gemm256_mfma32_variant(hip_ops, epi):
         hip_ops.lib.icv_set_option(b"gemm256_mfma", 16)
 
 
+@pytest.mark.parametrize("epi", [EPI_BF16, EPI_GELU_BF16, EPI_RESID_F32, EPI_F32])
+def test_gemm256_ksplit_schedule_is_bit_identical(hip_ops, epi):
+    """gemm256_sched 67 (round 4's A/B: the four LDS units of a stage cut by k-half, one k-step of all 32 accumulators per phase)
+    adds the same products in the same k order per accumulator as the default schedule: bit-identical outputs - incl. an M
+    tail, a strided A, a split-plane output, K of 1 / 2 / many tiles - and deterministic under repetition (race screen)."""
+    lib = hip_ops.lib
+    lib.icv_set_option(b"gemm256", 1)
+    try:
+        for M, N, K, pad in ((777, 512, 256, 0), (1500, 1024, 2048, 64), (256, 256, 64, 0), (300, 768, 128, 0), (2049, 256, 5120, 0)):
+            a_full = rnd((M, K + pad), 321).to(torch.bfloat16).to(DEV)
+            a = a_full[:, :K]
+            w = rnd((N, K), 322, 1.0 / math.sqrt(K)).to(torch.bfloat16).to(DEV)
+            bias = rnd((N,), 323, 0.1).to(DEV)
+            resid, gate = rnd((M, N), 324).to(DEV), rnd((N,), 325).to(DEV)
+            outs = {}
+            for sched in (3, 67, 67):
+                lib.icv_set_option(b"gemm256_sched", sched)
+                if epi == EPI_RESID_F32:
+                    out = resid.clone()
+                    hip_ops.gemm(a, w, bias, out, epi, resid=out, gate=gate)
+                elif epi == EPI_BF16 and N % 3 == 0:
+                    out = torch.zeros((3, M, N // 3), dtype=torch.bfloat16, device=DEV)
+                    hip_ops.gemm(a, w, bias, out, epi, nsplit=N // 3)
+                else:
+                    out = torch.zeros((M, N), dtype=torch.float32 if epi == EPI_F32 else torch.bfloat16, device=DEV)
+                    hip_ops.gemm(a, w, bias, out, epi)
+                torch.cuda.synchronize()
+                outs.setdefault(sched, []).append(out)
+            assert torch.equal(outs[67][0], outs[3][0]), f"k-split schedule differs from the default at M={M} N={N} K={K} epi={epi}"
+            assert torch.equal(outs[67][0], outs[67][1]), "k-split schedule is not deterministic (race?)"
+    finally:
+        lib.icv_set_option(b"gemm256", 2)
+        lib.icv_set_option(b"gemm256_sched", 3)
+
+
 @pytest.mark.parametrize("variant", [0, 1])
 def test_gemm_variants_agree_and_race_screen(hip_ops, variant):
     """128-tile kernel vs 256-tile 4-phase kernel on the same problem (compare both to the oracle),

@@ -59,7 +59,7 @@ def fuzz_gemm():
     epi = rng.choice([EPI_BF16, EPI_GELU_BF16, EPI_RESID_F32, EPI_F32])
     tile = rng.choice([0, 1, 2])         # 128-tile kernel, 256-tile kernel, heuristic
     mfma = rng.choice([16, 16, 32])
-    sched = rng.choice([0, 1, 2, 3, 3, 7, 11, 19, 35, 51])   # 19 / 35 / 51: non-temporal DMA of the A / W / both streams (A/B only)
+    sched = rng.choice([0, 1, 2, 3, 3, 7, 11, 19, 35, 51, 67, 67])   # 19 / 35 / 51: non-temporal DMA of the A / W / both streams (A/B only); 67: k-split units (round 4)
     pad = rng.choice([0, 0, 64])         # strided A
     ops.lib.icv_set_option(b"gemm256", tile); ops.lib.icv_set_option(b"gemm256_mfma", mfma); ops.lib.icv_set_option(b"gemm256_sched", sched)
     g = torch.Generator(device=DEV).manual_seed(rng.randint(0, 2 ** 31))
