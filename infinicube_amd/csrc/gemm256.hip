@@ -135,13 +135,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
     }
   }
   // k-split units: unit row u = block row (A: m0 + u, W: n0 + u), 64-byte rows (32 k), 4 chunks of 16 B, physical chunk =
-  // logical ^ ((u >> 2) & 3): 16 consecutive rows at one logical chunk then cover all 16 chunk slots of the 256-byte bank space
+  // logical ^ ((u >> 1) & 3) (conflict-free by PMC; selectable below)
   unsigned offKA[2], offKB[2];
+  // chunk swizzle of a 64-byte-row unit: selectable for the bank-conflict A/B ("gemm256_ablate" bits 2-3; results stay correct)
+  const int ksw = (p.ablate >> 2) & 3;
+  auto kswz = [ksw](int r) -> int {
+    // measured (SQ_LDS_BANK_CONFLICT, profiles/r04/gemm_ksplit_ab.txt): (r>>1)&3 and the bit-1 | bit-3 form are conflict-free,
+    // (r>>2)&3 and r&3 conflict two-way on every ds_read_b128
+    return ksw == 0 ? ((r >> 1) & 3) : ksw == 1 ? ((r >> 2) & 3) : ksw == 2 ? (((r >> 1) & 1) | (((r >> 3) & 1) << 1)) : (r & 3);
+  };
   if (KSPLIT) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int u = q * 128 + (tid >> 2);
-      const int c = (tid & 3) ^ ((u >> 2) & 3);
+      const int c = (tid & 3) ^ kswz(u);
       int64_t ra = m0 + u;
       ra = ra < p.M ? ra : p.M - 1;
       offKA[q] = (unsigned)((ra * p.lda + c * 8) * 2);
@@ -192,8 +199,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Params p) {
     // fragment addressing: a-fragment i8 (0..7) = block rows wr*128 + (i8>>2)*64 + (i8&3)*16 + fr, b-fragment j4 (0..3) = block cols
     // wc*64 + (j4>>1)*32 + (j4&1)*16 + fr (the epilogue's mapping); lane (fr, kq) reads the 16-byte chunk kq of its row
     const int kar = wr * 128 + fr, kbr = wc * 64 + fr;
-    const int ka_off = kar * 64 + ((kq ^ ((kar >> 2) & 3)) << 4);
-    const int kb_off = kbr * 64 + ((kq ^ ((kbr >> 2) & 3)) << 4);
+    // (fragment rows add multiples of 16 to kar / kbr: none of the swizzle candidates below looks at bits >= 4)
+    const int ka_off = kar * 64 + ((kq ^ kswz(kar & 15)) << 4);
+    const int kb_off = kbr * 64 + ((kq ^ kswz(kbr & 15)) << 4);
     bf16x8 kaf[8], kbf[4];
     dma_unit<AUX_A>(Ab, offKA, kbyte(0), smem + U_AK0 * UNIT_BYTES, wave);
     dma_unit<AUX_B>(Wb, offKB, kbyte(0), smem + U_BK0 * UNIT_BYTES, wave);
