@@ -53,3 +53,17 @@ def real_vae_factory(torch_dtype, device, model_configs):
                             ops=OracleOps())
     pipe.num_inference_steps = 2
     return pipe
+
+
+def gpu_real_vae_factory(torch_dtype, device, model_configs):
+    """`gpu_factory` with the PRODUCT configuration of the tiled Wan-VAE (bf16, NDHWC, folded pad, HIP norm kernel; 32 base channels,
+    seeded weights) instead of the pooling stand-in: in a multi-rank run its tiles are dealt to the ranks on the GPU."""
+    import os
+    from infinicube_amd.videogen.ops import HipOps
+    from infinicube_amd.videogen.vae import WanVAE, WanVAENet
+    dev = "cuda:0" if os.environ.get("ICV_TEST_SHARE_GPU") == "1" else WanVideoPipeline.resolve_device(device)
+    torch.manual_seed(11)
+    vae = WanVAE(WanVAENet(dim=32), dev, torch.bfloat16)
+    pipe = WanVideoPipeline(dev, torch_dtype, DiTHolder(syn.make_dit_state_dict(CFG), CFG), HashTextEncoder(CFG), vae, ops=HipOps(dev))
+    pipe.num_inference_steps = 2
+    return pipe

@@ -270,7 +270,7 @@ def test_bench_line_for_n_gpus(launcher):
     assert d["scaling"] == "strong" and d["value"] > 0
 
 
-def _pool_frames(tmp_path, monkeypatch, n, backend, share):
+def _pool_frames(tmp_path, monkeypatch, n, backend, share, factory="gpu_factory", max_diff=2, max_frac=0.02):
     """Frames of the single-GPU generator and of the same generator behind an n-rank worker pool (ICV_WORLD=n)."""
     import contextlib
     import io
@@ -290,14 +290,14 @@ def _pool_frames(tmp_path, monkeypatch, n, backend, share):
 
     def run():
         with contextlib.redirect_stdout(io.StringIO()):
-            g = WanVideoGenerator(path, device="cuda:0", use_wan_1pt3b=True, pipeline_factory=F.gpu_factory)
+            g = WanVideoGenerator(path, device="cuda:0", use_wan_1pt3b=True, pipeline_factory=getattr(F, factory))
             frames = g.generate(sem, co, seed=3)
         return g, np.stack([np.asarray(f) for f in frames])
 
     _, ref = run()
     monkeypatch.setenv("ICV_WORLD", str(n))
     monkeypatch.setenv("ICV_DIST_BACKEND", backend)
-    monkeypatch.setenv("ICV_WORKER_FACTORY", "mgpu_factory:gpu_factory")
+    monkeypatch.setenv("ICV_WORKER_FACTORY", f"mgpu_factory:{factory}")
     monkeypatch.setenv("ICV_WORLD_TIMEOUT_S", "240")
     monkeypatch.setenv("PYTHONPATH", os.pathsep.join([ROOT, HERE, os.environ.get("PYTHONPATH", "")]))
     g = None
@@ -305,7 +305,7 @@ def _pool_frames(tmp_path, monkeypatch, n, backend, share):
         g, got = run()
         assert dist.is_initialized() and dist.get_world_size() == n and dist.get_backend() == backend and g._pool is not None
         d = np.abs(ref.astype(np.int16) - got.astype(np.int16))
-        assert d.max() <= 2 and (d > 0).mean() < 0.02, f"{n}-rank frames differ from the single-GPU frames: max {d.max()}, {100 * (d > 0).mean():.2f} % pixels"
+        assert d.max() <= max_diff and (d > 0).mean() < max_frac, f"{n}-rank frames differ from the single-GPU frames: max {d.max()}, {100 * (d > 0).mean():.2f} % pixels"
     finally:
         if g is not None and g._pool is not None:
             g._pool.close()
@@ -318,6 +318,15 @@ def test_worker_pool_two_processes_sharing_the_gpu(tmp_path, monkeypatch):
     box: the caller's process and one worker share cuda:0 and talk over gloo (request broadcast, velocity swap, latent
     gather) — the worker-pool path end to end on HIP kernels, minus the RCCL transport."""
     _pool_frames(tmp_path, monkeypatch, 2, "gloo", share=True)
+
+
+@pytest.mark.gpu
+def test_worker_pool_sharing_the_gpu_with_the_tiled_vae_dealt_to_the_ranks(tmp_path, monkeypatch):
+    """The same with the PRODUCT's tiled Wan-VAE (bf16, NDHWC, HIP norm kernel): both buffer encodes and the decode are shared out
+    over the two processes on the GPU (the worker joins the decode's broadcasts and returns nothing); frames against the
+    single-process generator.  A random-weight VAE amplifies the rounding-level latent differences of a sharded loop, and MIOpen
+    may pick different kernels in the two processes, so the bar is on the bulk of the pixels, not on every one."""
+    _pool_frames(tmp_path, monkeypatch, 2, "gloo", share=True, factory="gpu_real_vae_factory", max_diff=64, max_frac=0.5)
 
 
 @pytest.mark.gpu
