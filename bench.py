@@ -246,8 +246,8 @@ def supervise(args, world, rank):
 
     guard.install_sigterm(last_words)
     # per-step bound for the timed / warm-up budgets: generous (a 14B step on ONE GPU is 3.4 s)
-    per_step = float(os.environ.get("ICV_BENCH_STEP_BUDGET_S", "30"))
-    budgets = {"warmup": 240.0 + per_step * args.warmup, "timed": 120.0 + per_step * (args.steps + 1)}
+    per_step = float(os.environ.get("ICV_BENCH_STEP_BUDGET_S", "8"))        # N >= 2: a 14B step is <= 1.7 s
+    budgets = {"warmup": 90.0 + per_step * args.warmup, "timed": 60.0 + per_step * (args.steps + 1)}
     try:
         sup = guard.Supervisor(rank, world, plan_attempts(args, world), [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], budgets=budgets)
         res = sup.run()

@@ -33,17 +33,20 @@ from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
 # phase budgets in seconds (a worker may declare its own budget for a phase it can size: PhaseReporter(name, budget_s=))
+# Sized so that THREE attempts that each hang in their longest phase still end (with the error record) inside the half hour a
+# benchmark driver typically allows: a rank's real phases take 5-60 s each at 14B / N = 8, the budgets are ~4x that.
 DEFAULT_PHASE_BUDGET_S = {
-    "start": 300.0,      # interpreter + first `import torch` of a fresh box (1-2 min while the image pages in)
-    "init": 180.0,       # init_process_group + first barrier
-    "groups": 180.0,     # sub-groups + a first small collective on each (lazy communicator creation happens HERE)
-    "setup": 300.0,      # weights into HBM, workspace, caches
-    "autotune": 120.0,
-    "warmup": 300.0,
-    "timed": 600.0,
-    "report": 180.0,
+    "start": 240.0,      # interpreter + first `import torch` of a fresh box (1-2 min while the image pages in)
+    "init": 120.0,       # init_process_group + first all-reduce
+    "groups": 120.0,     # sub-groups + a first small collective on each (lazy communicator creation happens HERE)
+    "setup": 180.0,      # weights into HBM, workspace, caches
+    "autotune": 90.0,
+    "warmup": 120.0,
+    "timed": 240.0,
+    "report": 90.0,
 }
-FALLBACK_BUDGET_S = 300.0
+FALLBACK_BUDGET_S = 180.0
+TOTAL_BUDGET_S = 1500.0      # no new attempt is started after this much supervisor time (ICV_GUARD_TOTAL_BUDGET_S)
 
 
 @dataclass
@@ -258,8 +261,18 @@ class Supervisor:
         """{"ok", "attempt", "plan", "failed": [records], "result": rank 0's worker result or None}"""
         history = []
         out = dict(ok=False, attempt=None, plan=None, failed=history, result=None)
+        t_start, total = time.time(), float(os.environ.get("ICV_GUARD_TOTAL_BUDGET_S", TOTAL_BUDGET_S))
         try:
             for k, att in enumerate(self.attempts):
+                # every supervisor started within seconds of the others and saw the same failures: the same decision everywhere
+                # (rank 0's clock decides for all through the store, so that a slow rank cannot disagree)
+                if k > 0:
+                    if self.rank == 0:
+                        self.store.set(f"go{k}", "1" if time.time() - t_start < total else "0")
+                    if self.store.get(f"go{k}").decode() != "1":
+                        history.append(dict(attempt=k, plan=att.label, rank=0, phase="supervisor",
+                                            reason=f"not started: {total:.0f} s of supervisor time were already spent on the failed plans"))
+                        break
                 rec = self._run_attempt(k, att)
                 if rec is None:
                     out.update(ok=True, attempt=k, plan=att.label)

@@ -136,3 +136,11 @@ def test_bench_supervised_ranks_walk_every_plan_and_report(tmp_path):
     assert [f["plan"] for f in d["failed_attempts"]] == ["cfg+sp / kv-exchange auto / 4 chunks", "cfg+sp / kv-exchange allgather / 4 chunks",
                                                         "sp / kv-exchange allgather / 4 chunks"]
     assert "no GPU visible" in d["error"]
+
+
+def test_total_budget_stops_the_ladder():
+    """A driver gives a bench run a fixed time: once ICV_GUARD_TOTAL_BUDGET_S of supervisor time is spent on failed plans no further
+    plan is started (rank 0's clock decides for every rank through the store) and the record says so."""
+    res, outs = _launch(2, {"ICV_GUARD_INJECT": "0:1:groups:raise", "ICV_GUARD_TOTAL_BUDGET_S": "0"})
+    assert not res["ok"] and [f["phase"] for f in res["failed"]] == ["groups", "supervisor"]
+    assert "not started" in res["failed"][1]["reason"] and all(rc == 1 for rc, _, _ in outs)
