@@ -144,3 +144,22 @@ def test_total_budget_stops_the_ladder():
     res, outs = _launch(2, {"ICV_GUARD_INJECT": "0:1:groups:raise", "ICV_GUARD_TOTAL_BUDGET_S": "0"})
     assert not res["ok"] and [f["phase"] for f in res["failed"]] == ["groups", "supervisor"]
     assert "not started" in res["failed"][1]["reason"] and all(rc == 1 for rc, _, _ in outs)
+
+
+def test_bench_plan_ladder():
+    """bench.py's ladder for a given command line: most capable plan first, duplicates removed, `--no-fallback` = one plan."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    labels = lambda argv, world: [a.label for a in bench.plan_attempts(bench.parse_args(argv), world)]   # noqa: E731
+    assert labels([], 8) == ["cfg+sp / kv-exchange auto / 4 chunks", "cfg+sp / kv-exchange allgather / 4 chunks", "sp / kv-exchange allgather / 4 chunks"]
+    assert labels([], 3) == ["sp / kv-exchange auto / 4 chunks", "sp / kv-exchange allgather / 4 chunks"]            # odd world: auto = sp
+    assert labels(["--parallelism", "sp", "--kv-exchange", "allgather"], 8) == ["sp / kv-exchange allgather / 4 chunks"]
+    assert labels(["--kv-exchange", "p2p", "--sp-chunks", "2"], 4) == ["cfg+sp / kv-exchange p2p / 2 chunks", "cfg+sp / kv-exchange allgather / 2 chunks",
+                                                                        "sp / kv-exchange allgather / 4 chunks"]
+    assert labels(["--no-fallback"], 8) == ["cfg+sp / kv-exchange auto / 4 chunks"]
+    plan = json.loads(bench.plan_attempts(bench.parse_args([]), 8)[2].env["ICV_BENCH_PLAN"])
+    assert plan == dict(parallelism="sp", kv_exchange="allgather", sp_chunks=4)
+    rec = bench.error_record(bench.parse_args(["--gpus", "8"]), 8, "boom", failed=[dict(plan="x")], phase="groups")
+    assert rec["value"] is None and rec["error"] == "boom" and rec["failed_phase"] == "groups" and rec["n_gpus"] == 8 and rec["unit"] == "denoise steps/s"
