@@ -505,6 +505,12 @@ def test_native_forward_matches_python_driver(hip_ops, name, mode):
             assert hip_ops.lib.icv_dit_bind(h, b"no_such_tensor", -1, lat.data_ptr()) != 0
             assert b"unknown tensor" in hip_ops.lib.icv_last_error()
             assert hip_ops.lib.icv_dit_bind(h, b"wqkv", cfg.num_layers, lat.data_ptr()) != 0
+        if native_on and mode == "sp":               # under the sequence-parallel schedule every KEY-CHUNK launch is timed
+            m.native_profile(True)
+            m.forward_tokens(lat, ck, 500.0, add, m.head_out[0])
+            ms, n = m.native_profile_read()
+            assert n == cfg.num_layers * 3 and 0.0 < ms < 1e3, (ms, n)
+            m.native_profile(False)
     assert torch.isfinite(outs[True][1]).all()
     assert torch.equal(outs[True][0], outs[False][0]), "icv_dit_forward differs from the per-op driver (one forward)"
     assert torch.equal(outs[True][1], outs[False][1]), "icv_dit_forward differs from the per-op driver (CFG loop, shared stem)"
