@@ -621,6 +621,12 @@ def run_rank(args, world, rank, phase, stdout_fd):
         if comm is not None:
             comm["autotune"] = autotune
             comm["parallelism"] = layout.mode
+            try:      # what the first contact ran on: library version, device, the RCCL / HSA switches in the environment
+                comm["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception:
+                comm["rccl_version"] = None
+            comm["device_name"] = torch.cuda.get_device_name(device)
+            comm["env"] = {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_", "ICV_")) and "INJECT" not in k}
             out["multi_gpu"] = comm
         if world == 1 and args.e2e:
             phase("e2e")
