@@ -1,3 +1,4 @@
+# (historical: this job A/B-ed ICV_VAE_CONV=split2d, a variant that measured slower and was removed again - profiles/r04/vae_layer_tuning.md)
 mkdir -p gpurun_out/r04e; export TMPDIR=/tmp
 for mode in native split2d; do
   ICV_VAE_CONV=$mode python tools/aux_bench.py 2>&1 | grep "^VAE" | tee -a gpurun_out/r04e/vae_conv_modes.txt

@@ -1,3 +1,4 @@
+# (historical: ICV_VAE_NORM=fused here was the stock F.rms_norm variant, measured slower and removed; today ICV_VAE_NORM=hip|stock selects the HIP row kernel)
 mkdir -p gpurun_out/r04f; export TMPDIR=/tmp
 for pad in copy conv; do for norm in composite fused; do
   ICV_VAE_PAD=$pad ICV_VAE_NORM=$norm python tools/aux_bench.py 2>&1 | grep "^VAE" | tee -a gpurun_out/r04f/vae_layer_tuning.txt
