@@ -213,7 +213,8 @@ class Supervisor:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(self.rank), WORLD_SIZE=str(self.world))
         if self.rank == 0:
             env["ICV_GUARD_RESULT_FILE"] = result_file
-        open(phase_file, "w").write(f"start\t{time.time():.3f}\t\n")
+        with open(phase_file, "w") as f:
+            f.write(f"start\t{time.time():.3f}\t\n")
         logf = open(log_file, "wb")
         self.log(f"attempt {k} ({att.label}): starting the worker (log {log_file})")
         self.proc = subprocess.Popen(self.cmd, env=env, stdout=logf, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL,

@@ -430,7 +430,7 @@ class WanVideoPipeline:
         buf_tokens = None
         # multi-rank run: the VAE's tiles are dealt to ALL ranks of the job (vae.TileShard; bit-identical result on every rank)
         from .vae import TileShard
-        vshard = dict(shard=TileShard.current()) if (world > 1 and getattr(self.vae, "accepts_uint8", False)) else {}
+        vshard = dict(shard=TileShard.current()) if (world > 1 and getattr(self.vae, "supports_tile_shard", False)) else {}
         if self.buffer_embedder is not None and semantic_buffer_video is not None and coordinate_buffer_video is not None:
             vids = (semantic_buffer_video, coordinate_buffer_video)
             for vid in vids:

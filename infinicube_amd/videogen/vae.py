@@ -87,8 +87,10 @@ class RMS_norm(nn.Module):
                 and x.is_contiguous(memory_format=torch.channels_last_3d if x.dim() == 5 else torch.channels_last)):
             from .. import native
             lib, act = self.fused
-            if getattr(self, "_g32", None) is None or self._g32.device != x.device:
+            if getattr(self, "_g32", None) is None or self._g32.device != x.device or self._g32_version != self.gamma._version:
+                # fp32 copy of gamma for the kernel; re-made when the parameter is written again (a later load_state_dict)
                 self._g32 = self.gamma.detach().reshape(-1).to(device=x.device, dtype=torch.float32).contiguous()
+                self._g32_version = self.gamma._version
             out = torch.empty_like(x)          # same NDHWC strides
             c = x.shape[1]
             native.check(lib.icv_rmsnorm_act_rows(x.data_ptr(), out.data_ptr(), self._g32.data_ptr(), x.numel() // c, c, self.scale, 1e-12,
@@ -268,6 +270,7 @@ class WanVAE:
     ``decode(latent) -> video[3,F,H,W]``, optionally spatially tiled like diffsynth's WanVideoVAE."""
 
     accepts_uint8 = True      # encode() / encode_many() take [F, H, W, 3] uint8 clips and normalise them on the device
+    supports_tile_shard = True   # encode_many() / decode() take shard=TileShard(...): tiles dealt to the ranks of a multi-rank run
 
     def __init__(self, net: WanVAENet, device, dtype=torch.bfloat16):
         self.net, self.device, self.dtype = net.to(device=device, dtype=dtype).eval(), device, dtype
