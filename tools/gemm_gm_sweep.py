@@ -7,7 +7,7 @@ from infinicube_amd.videogen.ops import HipOps, EPI_BF16, EPI_GELU_BF16, EPI_RES
 ops = HipOps("cuda:0")
 GMS = [int(x) for x in os.environ.get("GMS", "1,2,3,4,6,8,16").split(",")]
 ROUNDS = int(os.environ.get("ROUNDS", "3"))
-S = 37440
+S = 37440 * int(os.environ.get("M_MULT", "1"))      # M_MULT=2: the CFG-batched pair's 2S rows (the single-rank default)
 for name, M, N, K, epi in (("14b qkv", S, 15360, 5120, EPI_BF16), ("14b o", S, 5120, 5120, EPI_RESID_F32), ("14b xq", S, 5120, 5120, EPI_BF16),
                            ("14b ffn1", S, 13824, 5120, EPI_GELU_BF16), ("14b ffn2", S, 5120, 13824, EPI_RESID_F32),
                            ("sp4 ffn1", 9360, 13824, 5120, EPI_GELU_BF16), ("sp4 o", 9360, 5120, 5120, EPI_RESID_F32),
