@@ -203,8 +203,10 @@ def test_bench_stdout_is_one_json_line_on_one_gpu(n, launcher):
         str(_free_port())] + tail
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     if n > 1:
-        env.update(ICV_BENCH_SHARE_GPU="1", ICV_DIST_BACKEND="gloo")
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        # gloo moving device tensors between processes that share one GPU is slow and erratic (seconds per all-gather): give the
+        # watched phases room, this test is about the line, not about speed
+        env.update(ICV_BENCH_SHARE_GPU="1", ICV_DIST_BACKEND="gloo", ICV_GUARD_BUDGETS="autotune=400,warmup=400,timed=400")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1 and lines[0].startswith("{"), f"stdout must be ONE JSON line and nothing else, got {len(lines)} lines: {r.stdout[:400]!r}"
@@ -220,7 +222,7 @@ def test_bench_stdout_is_one_json_line_on_one_gpu(n, launcher):
         if n >= 4:
             at = d["multi_gpu"]["autotune"]
             assert {(r["kv_exchange"], r["sp_chunks"]) for r in at["table"]} >= {("allgather", 4), ("p2p", 4), ("allgather", 2)}
-            assert d["multi_gpu"]["kv_exchange"] == at["chosen"]["kv_exchange"] and any(r["ms"] for r in at["table"]) and at["seconds"] < 30
+            assert d["multi_gpu"]["kv_exchange"] == at["chosen"]["kv_exchange"] and any(r["ms"] for r in at["table"])
 
 
 @pytest.mark.gpu
@@ -233,7 +235,8 @@ def test_bench_falls_back_and_says_so(inject, plan_prefix, n_failed):
     cmd = [sys.executable, "bench.py", "--gpus", "4", "--model", "small", "--frames", "17", "--height", "256", "--width", "448", "--steps", "2",
            "--warmup", "1", "--no-cpu-baseline"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    env.update(ICV_BENCH_SHARE_GPU="1", ICV_DIST_BACKEND="gloo", ICV_GUARD_INJECT=inject, ICV_GUARD_BUDGETS="autotune=12", ICV_BENCH_DIST_TIMEOUT_S="40")
+    env.update(ICV_BENCH_SHARE_GPU="1", ICV_DIST_BACKEND="gloo", ICV_GUARD_INJECT=inject, ICV_BENCH_DIST_TIMEOUT_S="40",
+               ICV_GUARD_BUDGETS="autotune=12,warmup=400,timed=400" if "hang" in inject else "autotune=400,warmup=400,timed=400")
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
