@@ -161,7 +161,8 @@ class Supervisor:
             k, v = item.split("=")
             self.budgets[k] = float(v)
         self.scale = budget_scale * float(os.environ.get("ICV_GUARD_BUDGET_SCALE", "1"))
-        self.log = log or (lambda m: print(f"[guard {rank}] {m}", file=sys.stderr, flush=True))
+        t0 = time.time()
+        self.log = log or (lambda m: print(f"[guard {rank} +{time.time() - t0:6.1f}s] {m}", file=sys.stderr, flush=True))
         self.dir = tempfile.mkdtemp(prefix=f"icv_guard_r{rank}_")
         self.proc: Optional[subprocess.Popen] = None
         self.store = store if store is not None else self._connect_store()
@@ -248,7 +249,9 @@ class Supervisor:
                 return None
             if state == "timeout":
                 self._fail(k, "report", "not every rank reported completion")
+        self.log(f"attempt {k}: stopping the worker (last phase '{(_last_phase(phase_file) or ('?',))[0]}')")
         _kill_group(self.proc)
+        self.log(f"attempt {k}: worker gone")
         logf.close()
         sys.stderr.write(f"---- [guard {self.rank}] attempt {k} worker log tail ----\n{_tail(log_file, 3000)}\n")
         sys.stderr.flush()

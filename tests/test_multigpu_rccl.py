@@ -196,7 +196,7 @@ def test_bench_stdout_is_one_json_line_on_one_gpu(n, launcher):
     """The bench contract on a 1-GPU box: stdout is ONE JSON line and nothing else (native libraries print there too: gloo's
     "[Gloo] Rank ..." lines, RCCL's banner), for the plain N = 1 form and — N ranks sharing the one GPU over gloo, a code-path
     check, never a measurement — for the self-launching and the torch.distributed.run forms, with the layout `auto` builds."""
-    tail = ["bench.py", "--gpus", str(n), "--model", "small", "--frames", "17", "--height", "256", "--width", "448", "--steps", "2", "--warmup", "1",
+    tail = ["bench.py", "--gpus", str(n), "--model", "small", "--frames", "9", "--height", "128", "--width", "160", "--steps", "2", "--warmup", "1",
             "--no-cpu-baseline"]
     cmd = [sys.executable] + tail if launcher != "torchrun" else [
         sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port",
@@ -232,8 +232,8 @@ def test_bench_falls_back_and_says_so(inject, plan_prefix, n_failed):
     """First-contact robustness on the real bench.py (4 ranks sharing the one GPU over gloo): a rank that RAISES while the groups
     are built, and a rank that HANGS in the autotune followed by one that raises in the warm-up of the next plan - every rank moves
     to the next plan together, the run still ends with a measured line, and `multi_gpu` names the plan that ran and what failed."""
-    cmd = [sys.executable, "bench.py", "--gpus", "4", "--model", "small", "--frames", "17", "--height", "256", "--width", "448", "--steps", "2",
-           "--warmup", "1", "--no-cpu-baseline"]
+    cmd = [sys.executable, "bench.py", "--gpus", "4", "--model", "tiny", "--frames", "9", "--height", "128", "--width", "160", "--steps", "1",
+           "--warmup", "1", "--no-cpu-baseline"]      # tiny: the last plan is plain `sp` over gloo with device tensors - seconds per all-gather
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env.update(ICV_BENCH_SHARE_GPU="1", ICV_DIST_BACKEND="gloo", ICV_GUARD_INJECT=inject, ICV_BENCH_DIST_TIMEOUT_S="40",
                ICV_GUARD_BUDGETS="autotune=12,warmup=400,timed=400" if "hang" in inject else "autotune=400,warmup=400,timed=400")
