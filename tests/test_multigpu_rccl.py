@@ -273,7 +273,7 @@ def test_bench_line_for_n_gpus(launcher):
     assert d["scaling"] == "strong" and d["value"] > 0
 
 
-def _pool_frames(tmp_path, monkeypatch, n, backend, share, factory="gpu_factory", max_diff=2, max_frac=0.02):
+def _pool_frames(tmp_path, monkeypatch, n, backend, share, factory="gpu_factory", max_diff=2, max_frac=0.02, max_mean=None):
     """Frames of the single-GPU generator and of the same generator behind an n-rank worker pool (ICV_WORLD=n)."""
     import contextlib
     import io
@@ -309,6 +309,7 @@ def _pool_frames(tmp_path, monkeypatch, n, backend, share, factory="gpu_factory"
         assert dist.is_initialized() and dist.get_world_size() == n and dist.get_backend() == backend and g._pool is not None
         d = np.abs(ref.astype(np.int16) - got.astype(np.int16))
         assert d.max() <= max_diff and (d > 0).mean() < max_frac, f"{n}-rank frames differ from the single-GPU frames: max {d.max()}, {100 * (d > 0).mean():.2f} % pixels"
+        assert max_mean is None or d.mean() <= max_mean, f"mean |diff| {d.mean():.3f} levels"
     finally:
         if g is not None and g._pool is not None:
             g._pool.close()
@@ -327,9 +328,13 @@ def test_worker_pool_two_processes_sharing_the_gpu(tmp_path, monkeypatch):
 def test_worker_pool_sharing_the_gpu_with_the_tiled_vae_dealt_to_the_ranks(tmp_path, monkeypatch):
     """The same with the PRODUCT's tiled Wan-VAE (bf16, NDHWC, HIP norm kernel): both buffer encodes and the decode are shared out
     over the two processes on the GPU (the worker joins the decode's broadcasts and returns nothing); frames against the
-    single-process generator.  A random-weight VAE amplifies the rounding-level latent differences of a sharded loop, and MIOpen
-    may pick different kernels in the two processes, so the bar is on the bulk of the pixels, not on every one."""
-    _pool_frames(tmp_path, monkeypatch, 2, "gloo", share=True, factory="gpu_real_vae_factory", max_diff=64, max_frac=0.5)
+    single-process generator.  The latents are identical (no K|V sharding at two ranks: one CFG branch per rank); the tiles the
+    OTHER process computed are not bit-identical to the ones this process would have computed (MIOpen's convolution kernels are
+    not reproducible across processes, search or no search - measured: up to 6 levels on 58 % of the bytes of a random-weight
+    VAE's frames), so the bar is a small mean difference and a bounded maximum, not equality (equality of the dealing itself
+    is proven on the CPU, tests/test_vae_shard.py)."""
+    monkeypatch.setenv("ICV_VAE_FIND", "0")
+    _pool_frames(tmp_path, monkeypatch, 2, "gloo", share=True, factory="gpu_real_vae_factory", max_diff=24, max_frac=1.01, max_mean=2.0)
 
 
 @pytest.mark.gpu

@@ -122,7 +122,7 @@ def _fixed_latent():
 
 
 def _gpu_shard_worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ICV_VAE_FIND="0")
     sys.path.insert(0, HERE)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -144,6 +144,7 @@ def test_sharded_vae_tiles_on_the_gpu_two_ranks_sharing_it():
     frames (they blend the same broadcast tiles in the same order) and those agree with the unsharded call to bf16 rounding
     (MIOpen may pick different kernels in different processes, so not bit for bit)."""
     from infinicube_amd.videogen.vae import WanVAE, WanVAENet
+    os.environ["ICV_VAE_FIND"] = "0"        # MIOpen's immediate-mode pick: the same kernels in every process (see vae._searched_kernels)
     torch.manual_seed(11)
     vae = WanVAE(WanVAENet(dim=32), "cuda:0", torch.bfloat16)
     ref_l = [x.float().cpu() for x in vae.encode_many(_clips(), **TILE)]
@@ -160,6 +161,7 @@ def test_sharded_vae_tiles_on_the_gpu_two_ranks_sharing_it():
         assert p.exitcode == 0
     (_, l0, v0), (_, l1, v1) = [(r, [torch.from_numpy(x) for x in a], torch.from_numpy(b)) for r, a, b in got]
     assert all(torch.equal(a, b) for a, b in zip(l0, l1)) and torch.equal(v0, v1), "the ranks blended different tiles"
+    os.environ.pop("ICV_VAE_FIND", None)
     for a, b, what in ((l0[0], ref_l[0], "latent"), (l0[1], ref_l[1], "latent 2"), (v0, ref_v, "video")):
         rel = float((a - b).norm() / b.norm().clamp_min(1e-6))
         assert rel < 3e-2, f"{what}: sharded vs unsharded rel-L2 {rel}"
