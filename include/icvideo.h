@@ -28,7 +28,8 @@ extern "C" {
 
 /* 2: icv_unpatchify_cfg_euler gained `round_bf16` (a signature change a host built against 1 cannot detect otherwise);
  *    icv_dit_set_fp8 / icv_dit_set_seqpar and the e4m3 / sequence-parallel bind names were added. */
-#define ICV_ABI_VERSION 2
+/* 3: icv_ipc_* (the copy-engine K|V transport) were added; no existing signature changed. */
+#define ICV_ABI_VERSION 3
 
 /* ---- library / device ------------------------------------------------------------------ */
 int icv_abi_version(void);
@@ -325,6 +326,41 @@ int icv_comm_unique_id(char* id);
 int icv_comm_create(const char* id, int rank, int world, icv_comm** out);
 void icv_comm_destroy(icv_comm* comm);
 int icv_allgather_kv(icv_comm* comm, const void* rows, void* out, int64_t m, int64_t row_bytes, void* stream);
+
+/* ---- K13 without compute units: copy-engine pulls of the peers' K|V rows (csrc/ipc.hip) -------------
+ * Replaces: the same per-layer K|V exchange as icv_allgather_kv (north_star "all-gather of K/V over xGMI"), for the case
+ * where the RCCL channel kernels cost the overlapped attention more than the transfer is worth (one attention work-group
+ * per CU: a CU taken by a channel stretches a whole round — profiles/r05/kv_contention.md).  Every rank owns a SYMMETRIC
+ * HEAP (same size everywhere) that holds its K|V rows; peers open it through hipIpc and PULL row chunks with
+ * hipMemcpyAsync on one stream per peer (SDMA over the pair's xGMI link); readiness and reuse are flag words in a POSIX
+ * shared-memory segment `shm_name` (mapped and hipHostRegister'ed by every rank) written with hipStreamWriteValue32 and
+ * waited for with hipStreamWaitValue32 — no wave and no host round trip anywhere in the per-layer path.
+ *   every rank:  icv_ipc_create(name, rank, world, heap, heap_bytes, &ipc) — `heap` = a BORROWED device buffer of heap_bytes
+ *                (it must stay alive until icv_ipc_destroy; the allocation containing it is what gets exported), or NULL
+ *                to let the library hipMalloc one (icv_ipc_heap returns it); icv_ipc_export(ipc, handle) -> host ships the
+ *                ICV_IPC_HANDLE_BYTES of every rank to every rank (any side channel); icv_ipc_open_peer(ipc, p, handle_p);
+ *                after everyone has mapped the segment one rank may icv_ipc_shm_unlink(name) (nothing is left in /dev/shm).
+ *   per layer:   icv_ipc_acquire(ipc, stream)  BEFORE the kernels that overwrite heap rows (waits until every peer has
+ *                pulled everything published so far);  per row chunk  icv_ipc_gather_start(ipc, src_offset, bytes, out,
+ *                stream, &ticket): the `bytes` at `src_offset` of EVERY rank's heap -> out [world * bytes], rank-major;
+ *                the rows must have been produced on `stream`.  icv_ipc_gather_wait(ipc, ticket, stream): `stream` waits
+ *                until that chunk has landed.  Every rank must issue the same sequence of gather_start calls; at most
+ *                ICV_IPC_SLOTS exchanges may be un-waited at a time.
+ * Needs hipDeviceAttributeCanUseStreamWaitValue and working hipIpc between the ranks' devices: icv_ipc_create /
+ * icv_ipc_open_peer fail (non-zero, text in icv_last_error) where either is refused and the host drops the transport. */
+#define ICV_IPC_HANDLE_BYTES 72 /* hipIpcMemHandle_t of the allocation + the heap's byte offset inside it */
+#define ICV_IPC_SLOTS 32
+typedef struct icv_ipc icv_ipc;
+int icv_ipc_create(const char* shm_name, int rank, int world, void* heap, int64_t heap_bytes, icv_ipc** out);
+void icv_ipc_destroy(icv_ipc* ipc);
+int icv_ipc_shm_unlink(const char* shm_name);
+int icv_ipc_heap(icv_ipc* ipc, void** base, int64_t* bytes);
+int icv_ipc_export(icv_ipc* ipc, char* handle);
+int icv_ipc_open_peer(icv_ipc* ipc, int peer, const char* handle);
+int icv_ipc_gather_start(icv_ipc* ipc, int64_t src_offset, int64_t bytes, void* out, void* stream, int64_t* ticket);
+int icv_ipc_gather_wait(icv_ipc* ipc, int64_t ticket, void* stream);
+int icv_ipc_acquire(icv_ipc* ipc, void* stream);
+int64_t icv_ipc_tickets(const icv_ipc* ipc);
 
 /* ---- dtype plumbing: f32 -> bf16 (round-to-nearest-even), n elements ---------------------- */
 int icv_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);

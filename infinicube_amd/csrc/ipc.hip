@@ -1,0 +1,257 @@
+// K13 without compute units (SURVEY.md §8e "hide it"): the per-layer exchange of the post-RoPE K|V rows as PULLS by the copy
+// engines.  An RCCL all-gather is a kernel: every channel is a work-group pinned on a CU for the whole transfer, and the
+// attention it is supposed to hide under runs exactly one 8-wave work-group per CU — a taken CU stretches a whole round of
+// that launch (measured: profiles/r05/kv_contention.md).  Here nothing of the exchange runs on a CU:
+//
+//   * every rank keeps its K|V rows in a SYMMETRIC HEAP — one device buffer of the same size on every rank (the caller's own,
+//     e.g. a torch tensor: the allocation that contains it is found with hipMemGetAddressRange and exported whole, the offset
+//     travels with the handle — what torch's own CUDA-IPC does; or a hipMalloc made here), exported once with
+//     hipIpcGetMemHandle and opened by every peer (hipIpcOpenMemHandle, peer access enabled lazily), so "rows at byte offset
+//     o of rank p" is an address this rank can hand to hipMemcpyAsync; between two devices that copy is executed by an SDMA
+//     engine over the xGMI link of that pair, and the (world - 1) pulls of a chunk run on (world - 1) streams — one per peer =
+//     one per link (xGMI is point-to-point: 7 links, 7 engines, no ring);
+//   * readiness is a FLAG WORD per (rank, slot) in a small POSIX shared-memory segment that every rank maps and registers
+//     with hipHostRegister: the producer's launch stream writes a sequence number behind the kernels that produced the rows
+//     (hipStreamWriteValue32), the consumer's pull stream waits for ">= that number" in front of its copy
+//     (hipStreamWaitValue32: a wait packet executed by the command processor — no wave, no host round trip).  Sequence
+//     numbers only grow, so a late waiter can never miss a publish and no host handshake is needed;
+//   * the reverse hazard (the producer's next layer overwriting rows a slow peer is still pulling) is closed the same way:
+//     each pull stream writes "pulled up to ticket k" into done[consumer][producer] behind its copy, and
+//     icv_ipc_acquire makes the producer's launch stream wait for every peer's counter before the K|V GEMM of the next layer.
+//
+// Every rank issues the same sequence of icv_ipc_gather_start calls (same program), so ticket k names the same exchange
+// everywhere and its flag slot / sequence number need no negotiation.  Deadlock freedom with streams multiplexed onto a few
+// hardware queues: every wait a rank enqueues is for a flag whose write the peer enqueued EARLIER in its own program order
+// than its own waits of the same ticket, so processing each rank's packets in submission order always terminates.
+//
+// The host side (infinicube_amd/videogen/seqpar.py, KVGather mode "ipc") ships the 64-byte handles and the segment name
+// through the torch.distributed group once, runs a pattern self-test, and joins the start-up autotune as one more candidate.
+#include <errno.h>
+#include <fcntl.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <vector>
+
+#include "icv_common.h"
+
+namespace {
+
+constexpr int kSlots = ICV_IPC_SLOTS;
+
+#define ICV_HIP_OK(call, what)                                                          \
+  do {                                                                                  \
+    const hipError_t e_ = (call);                                                       \
+    if (e_ != hipSuccess) {                                                             \
+      icv_set_error("%s: %s (%s)", what, hipGetErrorName(e_), hipGetErrorString(e_));   \
+      return 2;                                                                         \
+    }                                                                                   \
+  } while (0)
+
+size_t flags_bytes(int world) { return sizeof(uint32_t) * ((size_t)world * kSlots + (size_t)world * world); }
+
+}  // namespace
+
+struct icv_ipc {
+  int rank = 0, world = 1, device = 0;
+  char* heap = nullptr;
+  int64_t heap_bytes = 0;
+  bool own_heap = false;               // hipMalloc'ed here (heap == NULL at create) or borrowed from the caller
+  std::vector<char*> peer;             // address of every rank's heap as THIS process sees it ([rank] = own heap)
+  std::vector<void*> peer_base;        // what hipIpcOpenMemHandle returned (the allocation the peer's heap lives in)
+  std::vector<hipStream_t> pull;       // one pull stream per peer
+  std::vector<hipEvent_t> landed;      // [peer * kSlots + slot]: that peer's chunk of the ticket in this slot has landed
+  hipEvent_t started[kSlots] = {};     // launch-stream position at gather_start (the pulls' destination is free from there)
+  uint32_t* flags_host = nullptr;      // mmap of the shared segment
+  uint32_t* flags_dev = nullptr;       // the same words as the GPU addresses them
+  size_t flags_len = 0;
+  bool registered = false;
+  int64_t next_ticket = 0;
+  bool waited[kSlots];
+  uint32_t* ready(int r, int slot) const { return flags_dev + (size_t)r * kSlots + slot; }
+  uint32_t* done(int consumer, int producer) const { return flags_dev + (size_t)world * kSlots + (size_t)consumer * world + producer; }
+};
+
+extern "C" int icv_ipc_create(const char* shm_name, int rank, int world, void* heap_ptr, int64_t heap_bytes, icv_ipc** out) {
+  ICV_REQUIRE(shm_name && out, "icv_ipc_create: null argument");
+  ICV_REQUIRE(world >= 1 && rank >= 0 && rank < world, "icv_ipc_create: bad (rank, world) = (%d, %d)", rank, world);
+  ICV_REQUIRE(heap_bytes > 0, "icv_ipc_create: empty heap");
+  int dev = 0, can_wait = 0;
+  ICV_HIP_OK(hipGetDevice(&dev), "hipGetDevice");
+  ICV_HIP_OK(hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, dev), "hipDeviceGetAttribute");
+  ICV_REQUIRE(can_wait, "icv_ipc_create: device %d cannot execute hipStreamWaitValue32 (no copy-engine K|V transport here)", dev);
+  icv_ipc* c = new icv_ipc();
+  c->rank = rank; c->world = world; c->device = dev; c->heap_bytes = heap_bytes;
+  c->peer.assign(world, nullptr);
+  for (int s = 0; s < kSlots; ++s) c->waited[s] = true;
+  auto fail = [&](int rc) { icv_ipc_destroy(c); return rc; };
+  // flag segment: created by whoever comes first (new POSIX shared memory reads as zeros), sized identically by everyone
+  const int fd = shm_open(shm_name, O_CREAT | O_RDWR, 0600);
+  if (fd < 0) { icv_set_error("icv_ipc_create: shm_open(%s): %s", shm_name, strerror(errno)); return fail(2); }
+  c->flags_len = flags_bytes(world);
+  if (ftruncate(fd, (off_t)c->flags_len) != 0) { icv_set_error("icv_ipc_create: ftruncate: %s", strerror(errno)); close(fd); return fail(2); }
+  void* m = mmap(nullptr, c->flags_len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED) { icv_set_error("icv_ipc_create: mmap: %s", strerror(errno)); return fail(2); }
+  c->flags_host = (uint32_t*)m;
+#define ICV_IPC_TRY(call, what)                                                              \
+  do {                                                                                       \
+    const hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess) {                                                                  \
+      icv_set_error("icv_ipc_create: %s: %s (%s)", what, hipGetErrorName(e_), hipGetErrorString(e_)); \
+      return fail(2);                                                                        \
+    }                                                                                        \
+  } while (0)
+  ICV_IPC_TRY(hipHostRegister(m, c->flags_len, hipHostRegisterMapped | hipHostRegisterPortable), "hipHostRegister(flag segment)");
+  c->registered = true;
+  void* d = nullptr;
+  ICV_IPC_TRY(hipHostGetDevicePointer(&d, m, 0), "hipHostGetDevicePointer");
+  c->flags_dev = (uint32_t*)d;
+  void* heap = heap_ptr;
+  if (!heap) {
+    ICV_IPC_TRY(hipMalloc(&heap, (size_t)heap_bytes), "hipMalloc(symmetric heap)");
+    c->own_heap = true;
+  }
+  c->heap = (char*)heap;
+  c->peer[rank] = c->heap;
+  c->pull.assign(world, nullptr);
+  c->landed.assign((size_t)world * kSlots, nullptr);
+  for (int p = 0; p < world; ++p) {
+    if (p == rank) continue;
+    ICV_IPC_TRY(hipStreamCreateWithFlags(&c->pull[p], hipStreamNonBlocking), "hipStreamCreateWithFlags");
+    for (int s = 0; s < kSlots; ++s) ICV_IPC_TRY(hipEventCreateWithFlags(&c->landed[(size_t)p * kSlots + s], hipEventDisableTiming), "hipEventCreateWithFlags");
+  }
+  for (int s = 0; s < kSlots; ++s) ICV_IPC_TRY(hipEventCreateWithFlags(&c->started[s], hipEventDisableTiming), "hipEventCreateWithFlags");
+#undef ICV_IPC_TRY
+  *out = c;
+  return 0;
+}
+
+extern "C" int icv_ipc_shm_unlink(const char* shm_name) {
+  ICV_REQUIRE(shm_name, "icv_ipc_shm_unlink: null argument");
+  if (shm_unlink(shm_name) != 0 && errno != ENOENT) {
+    icv_set_error("icv_ipc_shm_unlink(%s): %s", shm_name, strerror(errno));
+    return 2;
+  }
+  return 0;
+}
+
+extern "C" int icv_ipc_heap(icv_ipc* c, void** base, int64_t* bytes) {
+  ICV_REQUIRE(c && base && bytes, "icv_ipc_heap: null argument");
+  *base = c->heap;
+  *bytes = c->heap_bytes;
+  return 0;
+}
+
+extern "C" int icv_ipc_export(icv_ipc* c, char* handle) {
+  ICV_REQUIRE(c && handle, "icv_ipc_export: null argument");
+  static_assert(sizeof(hipIpcMemHandle_t) + sizeof(int64_t) == ICV_IPC_HANDLE_BYTES, "ICV_IPC_HANDLE_BYTES = hipIpcMemHandle_t + offset");
+  // the handle names a whole ALLOCATION: find the one that contains the heap and ship the heap's offset inside it
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  ICV_HIP_OK(hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)c->heap), "hipMemGetAddressRange(symmetric heap)");
+  const int64_t off = c->heap - (char*)base;
+  ICV_REQUIRE(off >= 0 && (size_t)(off + c->heap_bytes) <= size, "icv_ipc_export: the heap [%p, +%lld) is not inside one device allocation (base %p, %zu bytes)",
+              (void*)c->heap, (long long)c->heap_bytes, (void*)base, size);
+  hipIpcMemHandle_t h;
+  ICV_HIP_OK(hipIpcGetMemHandle(&h, (void*)base), "hipIpcGetMemHandle");
+  memcpy(handle, &h, sizeof(h));
+  memcpy(handle + sizeof(h), &off, sizeof(off));
+  return 0;
+}
+
+extern "C" int icv_ipc_open_peer(icv_ipc* c, int peer, const char* handle) {
+  ICV_REQUIRE(c && handle, "icv_ipc_open_peer: null argument");
+  ICV_REQUIRE(peer >= 0 && peer < c->world && peer != c->rank, "icv_ipc_open_peer: bad peer %d (rank %d of %d)", peer, c->rank, c->world);
+  ICV_REQUIRE(!c->peer[peer], "icv_ipc_open_peer: peer %d is already open", peer);
+  hipIpcMemHandle_t h;
+  int64_t off = 0;
+  memcpy(&h, handle, sizeof(h));
+  memcpy(&off, handle + sizeof(h), sizeof(off));
+  void* p = nullptr;
+  ICV_HIP_OK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle");
+  c->peer_base.resize(c->world, nullptr);
+  c->peer_base[peer] = p;
+  c->peer[peer] = (char*)p + off;
+  return 0;
+}
+
+extern "C" int icv_ipc_gather_start(icv_ipc* c, int64_t src_offset, int64_t bytes, void* out, void* stream, int64_t* ticket) {
+  ICV_REQUIRE(c && out && ticket, "icv_ipc_gather_start: null argument");
+  ICV_REQUIRE(bytes > 0 && src_offset >= 0 && src_offset + bytes <= c->heap_bytes,
+              "icv_ipc_gather_start: rows [%lld, +%lld) are outside the %lld-byte symmetric heap", (long long)src_offset, (long long)bytes,
+              (long long)c->heap_bytes);
+  for (int p = 0; p < c->world; ++p) ICV_REQUIRE(c->peer[p], "icv_ipc_gather_start: peer %d's heap was never opened", p);
+  const int64_t k = c->next_ticket;
+  const int slot = (int)(k % kSlots);
+  ICV_REQUIRE(c->waited[slot], "icv_ipc_gather_start: %d exchanges in flight without a wait (ticket %lld was never waited for)", kSlots,
+              (long long)(k - kSlots));
+  const uint32_t seq = (uint32_t)(k / kSlots + 1);
+  hipStream_t s = (hipStream_t)stream;
+  char* dst = (char*)out;
+  // the rows were produced on `s`: publish them behind their producers
+  ICV_HIP_OK(hipStreamWriteValue32(s, c->ready(c->rank, slot), seq, 0), "hipStreamWriteValue32(ready)");
+  // everything this rank still does with `out` (the previous layer's attention reads it) was enqueued on `s` before this point
+  ICV_HIP_OK(hipEventRecord(c->started[slot], s), "hipEventRecord(started)");
+  for (int i = 1; i < c->world; ++i) {
+    const int p = (c->rank + i) % c->world;          // start with the right-hand neighbour: at any moment every link is asked once
+    hipStream_t ps = c->pull[p];
+    ICV_HIP_OK(hipStreamWaitEvent(ps, c->started[slot], 0), "hipStreamWaitEvent(started)");
+    ICV_HIP_OK(hipStreamWaitValue32(ps, c->ready(p, slot), seq, hipStreamWaitValueGte, 0xffffffffu), "hipStreamWaitValue32(ready)");
+    ICV_HIP_OK(hipMemcpyAsync(dst + (int64_t)p * bytes, c->peer[p] + src_offset, (size_t)bytes, hipMemcpyDeviceToDevice, ps), "hipMemcpyAsync(pull)");
+    ICV_HIP_OK(hipStreamWriteValue32(ps, c->done(c->rank, p), (uint32_t)(k + 1), 0), "hipStreamWriteValue32(done)");
+    ICV_HIP_OK(hipEventRecord(c->landed[(size_t)p * kSlots + slot], ps), "hipEventRecord(landed)");
+  }
+  // own rows: a local copy in launch-stream order
+  ICV_HIP_OK(hipMemcpyAsync(dst + (int64_t)c->rank * bytes, c->heap + src_offset, (size_t)bytes, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync(own rows)");
+  c->waited[slot] = false;
+  c->next_ticket = k + 1;
+  *ticket = k;
+  return 0;
+}
+
+extern "C" int icv_ipc_gather_wait(icv_ipc* c, int64_t ticket, void* stream) {
+  ICV_REQUIRE(c, "icv_ipc_gather_wait: null argument");
+  ICV_REQUIRE(ticket >= 0 && ticket < c->next_ticket && ticket >= c->next_ticket - kSlots, "icv_ipc_gather_wait: ticket %lld is not in flight (next %lld)",
+              (long long)ticket, (long long)c->next_ticket);
+  const int slot = (int)(ticket % kSlots);
+  for (int p = 0; p < c->world; ++p) {
+    if (p == c->rank) continue;
+    ICV_HIP_OK(hipStreamWaitEvent((hipStream_t)stream, c->landed[(size_t)p * kSlots + slot], 0), "hipStreamWaitEvent(landed)");
+  }
+  c->waited[slot] = true;
+  return 0;
+}
+
+extern "C" int icv_ipc_acquire(icv_ipc* c, void* stream) {
+  ICV_REQUIRE(c, "icv_ipc_acquire: null argument");
+  if (c->next_ticket == 0) return 0;
+  for (int p = 0; p < c->world; ++p) {
+    if (p == c->rank) continue;
+    ICV_HIP_OK(hipStreamWaitValue32((hipStream_t)stream, c->done(p, c->rank), (uint32_t)c->next_ticket, hipStreamWaitValueGte, 0xffffffffu),
+               "hipStreamWaitValue32(done)");
+  }
+  return 0;
+}
+
+extern "C" int64_t icv_ipc_tickets(const icv_ipc* c) { return c ? c->next_ticket : -1; }
+
+extern "C" void icv_ipc_destroy(icv_ipc* c) {
+  if (!c) return;
+  for (hipStream_t s : c->pull)
+    if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+  for (hipEvent_t e : c->landed)
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->started)
+    if (e) (void)hipEventDestroy(e);
+  for (void* b : c->peer_base)
+    if (b) (void)hipIpcCloseMemHandle(b);
+  if (c->heap && c->own_heap) (void)hipFree(c->heap);
+  if (c->flags_host) {
+    if (c->registered) (void)hipHostUnregister(c->flags_host);
+    munmap(c->flags_host, c->flags_len);
+  }
+  delete c;
+}

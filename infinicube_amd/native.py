@@ -76,12 +76,24 @@ SIGNATURES.update({
     "icv_comm_create": (c_int, [c_char_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "icv_comm_destroy": (None, [c_void_p]),
     "icv_allgather_kv": (c_int, [c_void_p, _P, _P, _I, _I, _P]),
+    "icv_ipc_create": (c_int, [c_char_p, c_int, c_int, _P, _I, ctypes.POINTER(c_void_p)]),
+    "icv_ipc_destroy": (None, [c_void_p]),
+    "icv_ipc_shm_unlink": (c_int, [c_char_p]),
+    "icv_ipc_heap": (c_int, [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64)]),
+    "icv_ipc_export": (c_int, [c_void_p, c_char_p]),
+    "icv_ipc_open_peer": (c_int, [c_void_p, c_int, c_char_p]),
+    "icv_ipc_gather_start": (c_int, [c_void_p, _I, _I, _P, _P, ctypes.POINTER(c_int64)]),
+    "icv_ipc_gather_wait": (c_int, [c_void_p, _I, _P]),
+    "icv_ipc_acquire": (c_int, [c_void_p, _P]),
+    "icv_ipc_tickets": (c_int64, [c_void_p]),
     "icv_dit_profile": (c_int, [c_void_p, c_int]),
     "icv_dit_profile_read": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
 })
 
 COMM_ID_BYTES = 128   # ICV_COMM_ID_BYTES
-ABI_VERSION = 2       # ICV_ABI_VERSION of include/icvideo.h
+IPC_HANDLE_BYTES = 72  # ICV_IPC_HANDLE_BYTES
+IPC_SLOTS = 32         # ICV_IPC_SLOTS
+ABI_VERSION = 3       # ICV_ABI_VERSION of include/icvideo.h
 
 _lib: Optional[ctypes.CDLL] = None
 

@@ -304,15 +304,37 @@ class WanDiT:
         self.cfg_batch = os.environ.get("ICV_CFG_BATCH", "1") == "1"
         self._pair = None
         if self.sp_on:
-            self.kv_loc = a((n, 2 * d), BF16)                      # local k | v rows (one exchange moves both)
+            old = getattr(self, "kv_gather", None)
+            if old is not None and old is not kv_gather and hasattr(old, "close"):
+                old.close()                                        # a copy-engine transport owns a heap and streams
+            self.kv_gather = kv_gather or KVGather(self.plan, group, kv_exchange)
+            self._sp_local_rows()                                  # kv_loc: local k | v rows (one exchange moves both)
             self.kv_full = a((self.plan.world * n, 2 * d), BF16)   # gathered rows (chunk-major, rank-major inside)
             self.sp_acc = a((n, d), F32)                           # carried O accumulator between key chunks
             self.sp_ml = a((n, cfg.num_heads, 2), F32)             # carried (running max, row sum)
             self.sp_bounds = chunk_bounds(n, sp_chunks)
-            self.kv_gather = kv_gather or KVGather(self.plan, group, kv_exchange)
         else:
             self.kv_loc, self.kv_full, self.kv_gather = None, None, None
         return self
+
+    def _sp_local_rows(self):
+        """(Re)place the matrices this rank writes its K|V rows into where the current transport wants them: plain workspace
+        for the collective modes, the symmetric heap the peers pull from for KVGather mode "ipc" (seqpar._IpcHeap) - sized
+        for this engine's [n, 2d] rows plus the [2n, 2d] rows of its CFG-batched pair twin (forward_pair)."""
+        n, d, kg = self.plan.n_tok, self.cfg.dim, self.kv_gather
+        if hasattr(kg, "reserve"):
+            kg.reserve(3 * n * 2 * d * 2 + 1024, self.ops.device)
+        rows = (lambda r: kg.local_rows(r, 2 * d, BF16, self.ops.alloc)) if hasattr(kg, "local_rows") else (lambda r: self.ops.alloc((r, 2 * d), BF16))
+        self.kv_loc = rows(n)
+        self._kv_rows = rows
+        if getattr(self, "_pair", None) is not None:
+            self._pair.kv_loc = rows(2 * n)
+
+    def _sp_acquire(self):
+        """Before the K|V GEMM overwrites the local rows: wait for the peers' pulls of the previous layer (mode "ipc" only)."""
+        kg = self.kv_gather
+        if hasattr(kg, "acquire"):
+            kg.acquire()
 
     def set_kv_exchange(self, mode: Optional[str], sp_chunks: int):
         """Switch the transport / chunking of the per-layer K|V exchange on a prepared engine (start-up autotune,
@@ -322,7 +344,10 @@ class WanDiT:
         n = self.plan.n_tok
         self.sp_bounds = chunk_bounds(n, sp_chunks)
         old = self.kv_gather
+        if hasattr(old, "close"):
+            old.close()
         self.kv_gather = KVGather(self.plan, getattr(old, "group", None), mode)
+        self._sp_local_rows()
         if self.attn_fp8:      # the e4m3 K/V side of the workspace is sized for the largest gathered chunk
             kv_rows = self.plan.world * max(b1 - b0 for b0, b1 in zip(self.sp_bounds[:-1], self.sp_bounds[1:]))
             self.attn8_ws = self.ops.attention_fp8_buffers(n, kv_rows, self.cfg.dim, self.cfg.num_heads)
@@ -624,6 +649,7 @@ class WanDiT:
                 pass                                                                        # taken from the cond forward
             elif self.sp_on:
                 h = self._norm(lw["wqkv"], shift=sh1, scale=sc1, eps=eps)                   # K3
+                self._sp_acquire()
                 # K and V first, so their all-gather (K13) is already moving while Q is projected
                 self._mm(h, lw["wqkv"], lw["bqkv"], self.kv_loc, EPI_BF16, rows=slice(d, 3 * d))            # K4 (k | v rows)
                 ops.rmsnorm_rope(self.kv_loc[:, :d], lw["nk"], eps=eps, rope=self.rope, tok0=plan.tok0)      # K5 (k)
@@ -690,7 +716,7 @@ class WanDiT:
                 t.att8, t.att8s = a((n2, d), FP8), a((n2,), F32)
                 t.ff8, t.ff8s = a((n2, cfg.ffn_dim), FP8), a((n2,), F32)
             if self.sp_on:      # both branches' K|V rows: local [2n, 2d] (cond rows, then uncond rows), gathered [2, world*n, 2d]
-                t.kv_loc = a((n2, 2 * d), BF16)
+                t.kv_loc = self._kv_rows(n2)
                 t.kv_full = a((2, self.plan.world * self.plan.n_tok, 2 * d), BF16)
             self._pair = t
         return self._pair
@@ -727,6 +753,7 @@ class WanDiT:
                 # rounds of 256 CUs to 740 tiles = 2.89 rounds - while exchange and attention stay per branch: the uncond rows
                 # travel under the cond branch's attention
                 rs = slice(0, 2 * n) if rows_all is None else rows_all
+                self._sp_acquire()
                 t._mm(h, lw["wqkv"], lw["bqkv"], t.kv_loc[rs], EPI_BF16, rows=slice(d, 3 * d))            # K4 (k | v rows)
                 pend = []
                 for bi, r in enumerate(halves):

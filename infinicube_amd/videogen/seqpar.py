@@ -9,6 +9,7 @@ GPU [R infinicube/inference/guidance_buffer_generation.py:759-766].
 
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -120,12 +121,17 @@ class KVGather:
         one peer's shard, once (SURVEY.md §8e: 0.63 ms instead of 4.4 ms per 14B layer at world 8 if RCCL rings);
       * ``"native"``: ``icv_allgather_kv`` of libicvideo on this group's own RCCL communicator (``icv_comm_create``; the id
         travels through the torch.distributed group once) and a dedicated HIP stream fenced with events — the same
-        transfer without torch.distributed in the per-layer path (SURVEY §8b's C export; GPU ranks only)."""
+        transfer without torch.distributed in the per-layer path (SURVEY §8b's C export; GPU ranks only);
+      * ``"ipc"``: NO compute unit and no RCCL in the per-layer path (csrc/ipc.hip, ``icv_ipc_*``): the local rows live in a
+        symmetric heap every peer has opened through hipIpc, each rank PULLS its peers' chunks with copy-engine
+        ``hipMemcpyAsync`` on one stream per peer, readiness / reuse are flag words waited for by the command processor
+        (``hipStreamWaitValue32``).  The RCCL modes run channel kernels on CUs that the one-work-group-per-CU attention also
+        wants (profiles/r05/kv_contention.md); this one leaves the CUs alone.  GPU ranks only; the torch.distributed group
+        carries the 72-byte handles once.  The rows handed to ``start`` must come from ``local_rows`` (the heap)."""
 
-    MODES = ("allgather", "p2p", "native")
+    MODES = ("allgather", "p2p", "native", "ipc")
 
     def __init__(self, plan: ShardPlan, group=None, mode: Optional[str] = None):
-        import os
         self.plan = plan
         self.group = group
         self.mode = mode or os.environ.get("ICV_KV_EXCHANGE", "allgather")
@@ -146,12 +152,47 @@ class KVGather:
                 raise ValueError(f"K/V exchange group has {len(self.peers)} ranks, the shard plan {plan.world}")
         if self.mode == "native":
             self._native = _NativeComm.for_group(self.dist, group, self.peers, plan.rank, plan.world)
+        self._heap = None           # mode "ipc": the symmetric heap (made by reserve())
+
+    # ---- where the local K|V rows live ---------------------------------------------------------------------------------
+    def reserve(self, nbytes: int, device) -> None:
+        """Mode "ipc": create the symmetric heap of ``nbytes`` on every rank of the group, exchange the handles, open the
+        peers, self-test (a COLLECTIVE of the group: every rank calls it at the same point with the same size; raises the SAME
+        error on every rank when any rank fails).  Other modes: nothing to do."""
+        if self.mode != "ipc":
+            return
+        if self._heap is not None:
+            self._heap.close()
+        self._heap = _IpcHeap(self.dist, self.group, self.peers, self.plan.rank, self.plan.world, int(nbytes), device)
+
+    def local_rows(self, rows: int, cols: int, dtype, alloc):
+        """The [rows, cols] matrix this rank writes its K|V rows into: carved out of the symmetric heap in mode "ipc" (so the
+        peers can pull it), a plain ``alloc((rows, cols), dtype)`` otherwise."""
+        if self.mode != "ipc":
+            return alloc((rows, cols), dtype)
+        if self._heap is None:
+            raise RuntimeError("KVGather mode 'ipc': reserve() the symmetric heap before asking for local rows")
+        return self._heap.carve(rows, cols, dtype)
+
+    def acquire(self) -> None:
+        """Call BEFORE the kernels that overwrite the local rows (the K|V GEMM of the next layer): the launch stream waits until
+        every peer has pulled everything published so far.  A no-op for the collective modes (their sends complete in stream
+        order before the next writer starts)."""
+        if self._heap is not None:
+            self._heap.acquire()
+
+    def close(self) -> None:
+        if self._heap is not None:
+            self._heap.close()
+            self._heap = None
 
     def start(self, rows: torch.Tensor, out: torch.Tensor):
         assert rows.is_contiguous() and out.is_contiguous() and out.shape[0] == self.plan.world * rows.shape[0]
         self.n_collectives += 1
         if self.mode == "native":
             return (self._native.allgather(rows, out),)
+        if self.mode == "ipc":
+            return (self._heap.gather(rows, out),)
         if self.plan.world == 1:          # the one-rank rehearsal of the schedule (WanDiT.prepare(force_sp=True)): a local copy
             out.copy_(rows)
             return ()
@@ -203,11 +244,12 @@ class _NativeComm:
     def close_all(cls) -> int:
         """Destroy every cached communicator (side streams drained first).  Call BEFORE destroy_process_group / before the
         peers of a worker pool exit.  Returns how many were closed."""
+        n_heaps = _IpcHeap.close_all()           # the copy-engine transports die with the same world
         comms = list(cls._cache.values())
         for c in comms:
             c.close()
         cls._cache.clear()
-        return len(comms)
+        return len(comms) + n_heaps
 
     def __init__(self, dist, group, peers, rank: int, world: int):
         import ctypes
@@ -256,6 +298,145 @@ class _NativeComm:
         self.close()
 
 
+class _IpcHeap:
+    """Symmetric heap + flag segment + pull streams of ONE KVGather in mode "ipc" (csrc/ipc.hip).
+
+    Creation is a collective of the sequence-parallel group (the torch.distributed group carries the segment name and the
+    72-byte heap handles, as Python objects: works on nccl and gloo groups alike) and ends with a pattern self-test: every rank
+    fills the head of its heap with its own pattern, the chunk is exchanged exactly as in the loop, and a wrong byte anywhere
+    fails the transport on EVERY rank (hipIpc between two devices / processes is refused on some hosts, and a transport that
+    moves stale bytes must never win an autotune by being fast).  Any failure on any rank raises the same RuntimeError on
+    every rank, so the start-up ladder drops the candidate symmetrically."""
+
+    _live = []            # every open heap of this process (close_all at world teardown)
+    _serial = [0]
+    SELF_TEST_BYTES = 1 << 20
+
+    def __init__(self, dist, group, peers, rank: int, world: int, nbytes: int, device):
+        import ctypes
+        import secrets
+        from .. import native
+        self.lib, self.native, self.dist, self.group = native.lib(), native, dist, group
+        self.rank, self.world, self.handle, self.cursor = rank, world, None, 0
+        self.device = torch.device(device)
+        nbytes = (max(int(nbytes), self.SELF_TEST_BYTES) + 255) // 256 * 256
+        self._serial[0] += 1
+        name = f"/icv_kv_{os.getpid()}_{self._serial[0]}_{secrets.token_hex(4)}"
+        if world > 1:
+            box = [name]
+            dist.broadcast_object_list(box, src=peers[0], group=group)
+            name = box[0]
+        err, blob = "", b""
+        try:
+            # torch owns the memory (borrowed by the library); a dedicated allocation, so the exported range is this heap
+            self.mem = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
+            h = ctypes.c_void_p()
+            native.check(self.lib.icv_ipc_create(name.encode(), rank, world, self.mem.data_ptr(), nbytes, ctypes.byref(h)), "icv_ipc_create")
+            self.handle = h
+            buf = ctypes.create_string_buffer(native.IPC_HANDLE_BYTES)
+            native.check(self.lib.icv_ipc_export(h, buf), "icv_ipc_export")
+            blob = buf.raw
+        except Exception as e:      # noqa: BLE001 - reported to every rank below
+            err = f"rank {rank}: {type(e).__name__}: {e}"[:300]
+        got = self._agree((err, blob))
+        self._raise_if_any(got, "set-up")
+        err = ""
+        try:
+            for p in range(world):
+                if p != rank:
+                    native.check(self.lib.icv_ipc_open_peer(self.handle, p, got[p][1]), f"icv_ipc_open_peer({p})")
+        except Exception as e:      # noqa: BLE001
+            err = f"rank {rank}: {type(e).__name__}: {e}"[:300]
+        self._raise_if_any(self._agree((err, b"")), "opening the peers' heaps")
+        if rank == 0:
+            self.lib.icv_ipc_shm_unlink(name.encode())      # everyone has it mapped: leave nothing behind in /dev/shm
+        self._live.append(self)
+        self._raise_if_any(self._agree((self._self_test(), b"")), "self-test")
+
+    def _agree(self, item):
+        if self.world == 1:
+            return [item]
+        got = [None] * self.world
+        self.dist.all_gather_object(got, item, group=self.group)
+        return got
+
+    def _raise_if_any(self, got, what):
+        errs = [g[0] for g in got if g[0]]
+        if errs:
+            self.close()
+            raise RuntimeError(f"copy-engine K|V transport unusable ({what}): " + "; ".join(errs))
+
+    def _self_test(self) -> str:
+        try:
+            n = self.SELF_TEST_BYTES
+            for rep in range(2):        # twice: the second round reuses the rows (acquire) and the flag words
+                self.acquire()
+                self.mem[:n] = (torch.arange(n, device=self.device, dtype=torch.int32) * (2 * self.rank + 3) + 17 * rep).to(torch.uint8)
+                out = torch.zeros((self.world * n,), dtype=torch.uint8, device=self.device)
+                self.gather(self.mem[:n], out).wait()
+                torch.cuda.synchronize(self.device)
+                for p in range(self.world):
+                    want = (torch.arange(n, device=self.device, dtype=torch.int32) * (2 * p + 3) + 17 * rep).to(torch.uint8)
+                    if not torch.equal(out[p * n:(p + 1) * n], want):
+                        return f"rank {self.rank}: the rows pulled from rank {p} are wrong (round {rep})"
+            return ""
+        except Exception as e:      # noqa: BLE001
+            return f"rank {self.rank}: {type(e).__name__}: {e}"[:300]
+
+    def carve(self, rows: int, cols: int, dtype) -> torch.Tensor:
+        nbytes = rows * cols * torch.empty((), dtype=dtype).element_size()
+        start = (self.cursor + 255) // 256 * 256
+        if start + nbytes > self.mem.numel():
+            raise RuntimeError(f"symmetric K|V heap exhausted: {start + nbytes} > {self.mem.numel()} bytes (reserve() more)")
+        self.cursor = start + nbytes
+        return self.mem[start: start + nbytes].view(dtype).view(rows, cols)
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def gather(self, rows: torch.Tensor, out: torch.Tensor):
+        import ctypes
+        off = rows.data_ptr() - self.mem.data_ptr()
+        nbytes = rows.numel() * rows.element_size()
+        if off < 0 or off + nbytes > self.mem.numel():
+            raise ValueError("KVGather mode 'ipc': the rows to exchange are not inside the symmetric heap (use local_rows())")
+        t = ctypes.c_int64()
+        self.native.check(self.lib.icv_ipc_gather_start(self.handle, off, nbytes, out.data_ptr(), self._stream(), ctypes.byref(t)), "icv_ipc_gather_start")
+        return _IpcWork(self, t.value)
+
+    def acquire(self):
+        self.native.check(self.lib.icv_ipc_acquire(self.handle, self._stream()), "icv_ipc_acquire")
+
+    def close(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h is not None:
+            try:
+                torch.cuda.synchronize(self.device)
+                self.lib.icv_ipc_destroy(h)
+            except Exception:  # pragma: no cover - interpreter shutdown
+                pass
+        if self in self._live:
+            self._live.remove(self)
+
+    @classmethod
+    def close_all(cls) -> int:
+        heaps = list(cls._live)
+        for h in heaps:
+            h.close()
+        return len(heaps)
+
+    def __del__(self):
+        self.close()
+
+
+class _IpcWork:
+    def __init__(self, heap, ticket):
+        self.heap, self.ticket = heap, ticket
+
+    def wait(self):
+        self.heap.native.check(self.heap.lib.icv_ipc_gather_wait(self.heap.handle, self.ticket, self.heap._stream()), "icv_ipc_gather_wait")
+
+
 class _EventWork:
     """wait() = the current stream waits for the transfer (like an async nccl work handle)."""
 
@@ -300,49 +481,59 @@ def autotune_kv_exchange(model, run_layers, sync, candidates=None, reps: int = 2
     """Start-up choice of the K|V exchange (transport x chunk count) by MEASUREMENT on the ranks that will run it.
 
     xGMI is point-to-point and what RCCL schedules over it is not known before the first contact: ``allgather`` may ring
-    (world-1 hops), ``p2p`` uses every link once, ``native`` is the same collective on libicvideo's own communicator; more
-    chunks hide more of the transfer but launch shorter attention kernels.  Each candidate runs ``run_layers()`` (a couple of
-    real DiT layers on this rank's shard: exchange + chunked attention exactly as in the loop) once to warm up (communicator
-    / connection set-up happens there) and ``reps`` times under a timer; the time a layer takes IS the compute plus whatever
-    part of the transfer stayed exposed.  Every rank must end with the same choice: times are max-reduced over the ranks
-    (``reduce_max(list) -> list``) and ties break by candidate order.  A candidate that raises is dropped on every rank
-    (its failure is max-reduced too).  ``exchange_only()`` (optional): one layer's exchange with nothing to hide under; its time is
-    recorded next to the layer time (``exchange_ms``: the raw transfer, for the bandwidth it implies), never used for the choice.
+    (world-1 hops), ``p2p`` uses every link once, ``native`` is the same collective on libicvideo's own communicator, ``ipc``
+    moves the rows with the copy engines and leaves every CU to the attention it overlaps with; more chunks hide more of the
+    transfer but launch shorter attention kernels.  Each candidate runs ``run_layers()`` (a couple of real DiT layers on this
+    rank's shard: exchange + chunked attention exactly as in the loop) once to warm up and ``reps`` times under a timer; the time
+    a layer takes IS the compute plus whatever part of the transfer stayed exposed.  Every rank must end with the same choice:
+    times are max-reduced over the ranks (``reduce_max(list) -> list``) and ties break by candidate order.
+
+    Failure handling, in two phases.  SET-UP (``model.set_kv_exchange``: communicator / heap creation, handle exchange,
+    self-test) may fail on any rank: its outcome is max-reduced BEFORE anybody runs the candidate's layers, so a transport
+    that cannot be set up on one rank is dropped on every rank and nobody is left inside one of its collectives.  RUNNING a
+    candidate that every rank set up is different: a rank that raises in the middle of ``run_layers()`` leaves its peers
+    blocked in that candidate's exchange, and no reduce can be reached from there - such an error is FATAL for this attempt and
+    propagates (the launch ladder above, multigpu / launch_guard, abandons the process group and falls back to its next plan).
+    ``exchange_only()`` (optional): one layer's exchange with nothing to hide under; its time is recorded next to the layer time
+    (``exchange_ms``: the raw transfer, for the bandwidth it implies), never used for the choice.
     Returns (best (mode, chunks), table of dict rows)."""
     import time
-    cands = list(candidates or [(m, c) for m in ("allgather", "p2p", "native") for c in (4, 2)])
+    cands = list(candidates or [(m, c) for m in ("allgather", "p2p", "native", "ipc") for c in (4, 2)])
     table = []
     for mode, chunks in cands:
-        ms, err, xms = float("inf"), "", 0.0
+        err = ""
         try:
             model.set_kv_exchange(mode, chunks)
-            run_layers()
-            sync()
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                run_layers()
-            sync()
-            ms = 1e3 * (time.perf_counter() - t0) / reps
-            if exchange_only is not None:
-                exchange_only()
-                sync()
-                t0 = time.perf_counter()
-                for _ in range(3):
-                    exchange_only()
-                sync()
-                xms = 1e3 * (time.perf_counter() - t0) / 3
-        except Exception as e:      # noqa: BLE001 - a transport that cannot run here is simply not a candidate
-            err = f"{type(e).__name__}: {e}"[:200]
+        except Exception as e:      # noqa: BLE001 - a transport that cannot be set up here is simply not a candidate
+            err = f"{type(e).__name__}: {e}"[:300]
         bad = 1.0 if err else 0.0
         if reduce_max is not None:
-            ms_r, bad, xms = reduce_max([ms if not err else 0.0, bad, xms])
-            ms = float("inf") if bad else ms_r
-        elif err:
-            ms = float("inf")
-        table.append(dict(kv_exchange=mode, sp_chunks=chunks, ms=None if ms == float("inf") else ms, error=err or None,
-                          exchange_ms=(xms or None) if ms != float("inf") else None))
+            bad = reduce_max([bad])[0]
+        if bad:
+            table.append(dict(kv_exchange=mode, sp_chunks=chunks, ms=None, error=err or "set-up failed on another rank", exchange_ms=None))
+            if log:
+                log(f"autotune {mode:9s} chunks {chunks}: unusable ({err or 'set-up failed on another rank'})")
+            continue
+        run_layers()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            run_layers()
+        sync()
+        ms, xms = 1e3 * (time.perf_counter() - t0) / reps, 0.0
+        if exchange_only is not None:
+            exchange_only()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                exchange_only()
+            sync()
+            xms = 1e3 * (time.perf_counter() - t0) / 3
+        if reduce_max is not None:
+            ms, xms = reduce_max([ms, xms])
+        table.append(dict(kv_exchange=mode, sp_chunks=chunks, ms=ms, error=None, exchange_ms=xms or None))
         if log:
-            log(f"autotune {mode:9s} chunks {chunks}: " + (f"{ms:.2f} ms" if ms != float("inf") else f"unusable ({err or 'failed on another rank'})"))
+            log(f"autotune {mode:9s} chunks {chunks}: {ms:.2f} ms" + (f" (exchange alone {xms:.2f} ms)" if xms else ""))
     usable = [(r["ms"], i) for i, r in enumerate(table) if r["ms"] is not None]
     if not usable:
         raise RuntimeError(f"K|V exchange autotune: no transport worked: {table}")

@@ -277,6 +277,39 @@ def test_sequence_parallel_path_on_one_gpu(hip_ops, chunks, model, gemm_dtype):
     assert rel < (6e-2 if attn_dtype == "fp8" else 5e-3), f"sharded vs unsharded forward rel-L2 {rel}"
 
 
+def test_copy_engine_transport_one_rank_rehearsal(hip_ops):
+    """KVGather mode "ipc" (csrc/ipc.hip) on the one rank a one-GPU process has: the symmetric heap is carved for the engine's
+    and its CFG-pair twin's K|V rows, exported (hipMemGetAddressRange + hipIpcGetMemHandle of torch's allocation), the flag
+    segment is created, registered and unlinked, the start-up self-test runs, and an 8-step CFG loop on the sequence-parallel
+    schedule (publish -> own-rows copy -> wait, acquire before every K|V GEMM; 3 chunks x 2 branches x layers tickets through
+    the 32-slot ring) is BIT-IDENTICAL to the same schedule on the collective transport.  The peers' half of the protocol is
+    tests/test_multigpu_rccl.py::test_shared_gpu_copy_engine_transport_is_bit_identical_to_allgather."""
+    import glob
+    from infinicube_amd.videogen.seqpar import _IpcHeap
+    grid = TokenGrid(9, 64, 96)
+    cfg, sd, bsd, _, _ = _setup("tiny", grid)
+    noise, c1, c2, bl = syn.make_latent_noise(grid), syn.make_text_context(cfg, 1), syn.make_text_context(cfg, 2), syn.make_buffer_latents(cfg, grid)
+    lats = {}
+    for mode in ("allgather", "ipc"):
+        m = WanDiT(cfg, sd, hip_ops, bsd).prepare(grid, force_sp=True, kv_exchange=mode, sp_chunks=3)
+        assert m.sp_on and m.kv_gather.mode == mode
+        lat = noise.clone().to("cuda:0")
+        m.denoise(lat, m.encode_context(c1), m.encode_context(c2), m.embed_buffers(bl), FlowMatchScheduler(8), 5.0)
+        torch.cuda.synchronize()
+        lats[mode] = lat.clone()
+        if mode == "ipc":
+            heap = m.kv_gather._heap
+            assert heap is not None and heap in _IpcHeap._live
+            assert m.kv_loc.data_ptr() >= heap.mem.data_ptr() and m._pair is not None and m._pair.kv_loc.data_ptr() > m.kv_loc.data_ptr()
+            n_tickets = hip_ops.lib.icv_ipc_tickets(heap.handle)
+            assert n_tickets == 2 + m.kv_gather.n_collectives, "two self-test exchanges + one ticket per chunk exchange"
+            assert n_tickets > 2 * 32, "the loop must wrap the flag-slot ring at least twice"
+            assert not glob.glob("/dev/shm/icv_kv_*"), "the flag segment's name must not outlive the set-up"
+            m.kv_gather.close()
+            assert heap not in _IpcHeap._live
+    assert torch.isfinite(lats["ipc"]).all() and torch.equal(lats["ipc"], lats["allgather"])
+
+
 @pytest.mark.parametrize("transport", ["torch", "native"])
 def test_sequence_parallel_gather_on_rccl_stream(hip_ops, transport):
     """transport = "torch": torch.distributed's collective; "native": libicvideo's own RCCL communicator and side stream

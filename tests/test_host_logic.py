@@ -406,7 +406,7 @@ def _autotune_worker(rank, world, port, q):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return t.tolist()
 
-        best, table = autotune_kv_exchange(m, two_layers, dist.barrier, [("allgather", 3), ("p2p", 3), ("native", 3), ("p2p", 1)], reps=1,
+        best, table = autotune_kv_exchange(m, two_layers, dist.barrier, [("allgather", 3), ("p2p", 3), ("native", 3), ("p2p", 1), ("ipc", 3)], reps=1,
                                            reduce_max=reduce_max, exchange_only=exchange_only)
         # the engine now runs the chosen exchange: a loop on it still equals the single-process loop
         lat = noise.clone()
@@ -419,8 +419,9 @@ def _autotune_worker(rank, world, port, q):
 
 def test_kv_exchange_autotune_agrees_across_ranks_and_drops_what_cannot_run():
     """seqpar.autotune_kv_exchange over two real gloo ranks: every candidate is timed on a couple of real layers, the times are
-    max-reduced so both ranks choose the SAME (transport, chunks); `native` cannot run here (no GPU, no RCCL) and is dropped on
-    every rank instead of failing the run; the engine is left on the chosen exchange and a loop on it matches the single process."""
+    max-reduced so both ranks choose the SAME (transport, chunks); `native` (no GPU, no RCCL) and `ipc` (no GPU: its set-up is
+    a collective that fails on every rank with the same error) cannot run here and are dropped on every rank in the SET-UP
+    phase, before anybody enters one of their exchanges, instead of failing the run; the engine is left on the chosen exchange and a loop on it matches the single process."""
     sd, bsd, noise, c1, c2, bl = _inputs()
     single = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID)
     ref = noise.clone()
@@ -437,9 +438,10 @@ def test_kv_exchange_autotune_agrees_across_ranks_and_drops_what_cannot_run():
         assert p.exitcode == 0
     (_, best0, table0, mode0, chunks0, lat0), (_, best1, table1, mode1, chunks1, lat1) = got
     assert best0 == best1 and (mode0, chunks0) == (mode1, chunks1) == tuple(best0)
-    assert [r["kv_exchange"] for r in table0] == ["allgather", "p2p", "native", "p2p"]
-    native_row = table0[2]
-    assert native_row["ms"] is None and native_row["error"] and table1[2]["ms"] is None
-    assert all(r["ms"] > 0 and r["exchange_ms"] > 0 for i, r in enumerate(table0) if i != 2)
+    assert [r["kv_exchange"] for r in table0] == ["allgather", "p2p", "native", "p2p", "ipc"]
+    for dropped in (2, 4):
+        assert table0[dropped]["ms"] is None and table0[dropped]["error"] and table1[dropped]["ms"] is None
+    assert "copy-engine K|V transport unusable" in table0[4]["error"] and "rank 0" in table0[4]["error"] and "rank 1" in table0[4]["error"]
+    assert all(r["ms"] > 0 and r["exchange_ms"] > 0 for i, r in enumerate(table0) if i not in (2, 4))
     assert [r["ms"] for r in table0] == [r["ms"] for r in table1], "the reduced times are identical on every rank"
     assert torch.equal(lat0, lat1) and float((lat0 - ref).norm() / ref.norm()) < 2e-3

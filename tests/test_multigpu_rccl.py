@@ -142,6 +142,21 @@ def test_shared_gpu_gloo_ranks_equal_single_gpu(tmp_path, gpu_single, world, par
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,parallelism", [(2, "sp"), (4, "sp")])
+def test_shared_gpu_copy_engine_transport_is_bit_identical_to_allgather(tmp_path, world, parallelism):
+    """KVGather mode "ipc" (csrc/ipc.hip, the CU-free K|V transport) between REAL processes: N ranks sharing the one GPU open
+    each other's symmetric heap through hipIpc, pull each other's K|V row chunks with hipMemcpyAsync on one stream per peer,
+    gated by the flag words in the shared segment (hipStreamWriteValue32 / hipStreamWaitValue32) - the whole protocol of
+    the N-GPU run except that the copy is a same-device blit instead of SDMA over xGMI.  The exchange only moves bytes, so the
+    final latent must be BIT-IDENTICAL to the same N-rank run on the collective (`allgather`, gloo here) transport."""
+    args = ["--backend", "gloo", "--share-gpu"] + GPU_TINY[2:] + ["--scenario", "loop", "--parallelism", parallelism]
+    ref = run_ranks(world, str(tmp_path / "allgather.pt"), args + ["--kv-exchange", "allgather"])
+    got = run_ranks(world, str(tmp_path / "ipc.pt"), args + ["--kv-exchange", "ipc"])
+    assert got["info"]["world"] == world and got["info"]["kv_exchange"] == "ipc" and got["info"]["kv_collectives"] == ref["info"]["kv_collectives"] > 0
+    assert torch.equal(got["result"], ref["result"]), "the copy-engine transport moved different bytes than the collective one"
+
+
+@pytest.mark.gpu
 @needs_gpus(2)
 @pytest.mark.parametrize("world,parallelism,kv_exchange", [
     (2, "sp", "allgather"), (2, "sp", "native"), (2, "cfg+sp", "allgather"),
