@@ -177,9 +177,11 @@ def parse_args(argv=None):
                          "peer (the direct, fully-connected schedule), or by libicvideo's own RCCL communicator (icv_allgather_kv; "
                          "seqpar.KVGather); 'auto' (default) = a start-up autotune times two real layers with each transport x "
                          "{4, 2} chunks on the ranks of the run and keeps the fastest (the table goes into multi_gpu.autotune)")
-    ap.add_argument("--rccl-max-channels", type=int, default=0,
-                    help="N>1: cap RCCL's channel count (NCCL_MAX_NCHANNELS; one channel = one workgroup = one CU taken from the attention "
-                         "kernel while a transfer runs) - an A/B knob for the first runs on real xGMI, 0 = RCCL's own choice")
+    ap.add_argument("--rccl-max-channels", type=int, default=-1,
+                    help="N>1: cap RCCL's channel count (NCCL_MAX_NCHANNELS; one channel = one resident workgroup beside the attention "
+                         "kernel while a transfer runs): -1 (default) = 8 unless NCCL_MAX_NCHANNELS is already set - derived from the "
+                         "measured slow-down of the shard-shape attention under k co-running copy work-groups, "
+                         "profiles/r05/kv_contention.md; 0 = RCCL's own choice")
     ap.add_argument("--no-fallback", action="store_true",
                     help="N>1: run only the requested plan; a failure is reported instead of trying the simpler layouts")
     ap.add_argument("--native-forward", action="store_true",
@@ -341,8 +343,8 @@ def run_rank(args, world, rank, phase, stdout_fd):
         import datetime
         import torch.distributed as dist
         phase("init")
-        if args.rccl_max_channels > 0:
-            os.environ["NCCL_MAX_NCHANNELS"] = str(args.rccl_max_channels)     # read when the communicators are created
+        from infinicube_amd.videogen.seqpar import apply_rccl_channel_cap
+        apply_rccl_channel_cap(args.rccl_max_channels)                          # read when the communicators are created
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("ICV_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm
         # an explicit collective timeout: a wedged exchange must end THIS attempt (the supervisor then moves every rank to

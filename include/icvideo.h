@@ -28,7 +28,8 @@ extern "C" {
 
 /* 2: icv_unpatchify_cfg_euler gained `round_bf16` (a signature change a host built against 1 cannot detect otherwise);
  *    icv_dit_set_fp8 / icv_dit_set_seqpar and the e4m3 / sequence-parallel bind names were added. */
-/* 3: icv_ipc_* (the copy-engine K|V transport) were added; no existing signature changed. */
+/* 3: icv_ipc_* (the copy-engine K|V transport), icv_conv3d_ndhwc and the padded-volume VAE helpers were added; no existing
+ *    signature changed. */
 #define ICV_ABI_VERSION 3
 
 /* ---- library / device ------------------------------------------------------------------ */
@@ -314,6 +315,22 @@ int icv_dit_forward(icv_dit* ctx, const float* latent, int64_t C, int64_t H8, in
  * `launches` then counts chunk launches: chunks x layers per forward.  Leave it off under graph capture. */
 int icv_dit_profile(icv_dit* ctx, int enable);
 int icv_dit_profile_read(icv_dit* ctx, double* total_ms, int64_t* launches);
+
+/* ---- the Wan-VAE's convolutions as shifted-row GEMMs on the matrix cores (csrc/conv.hip) ---------
+ * Replaces, inside the tiled VAE encode / decode [R infinicube/videogen/inference.py:69,171,225], every nn.Conv3d / nn.Conv2d
+ * of the fork's Wan-VAE ([EXT] public Wan2.1 VAE: causal 3x3x3, (3,1,1), per-frame 3x3, 1x1x1) — stock PyTorch hands these
+ * to MIOpen, whose first call per shape searches kernels for tens of seconds and whose choice differs between processes.
+ * The activation is a PADDED NDHWC volume flattened to rows: x bf16 [rows, ldx] where the causal / spatial zero padding
+ * are real rows; a tap (dt, dh, dw) is ONE row offset (dt*Hp + dh)*Wp + dw for the whole volume:
+ *     out[m, 0:cout] = bias + sum_i  x[m + tap_row_offsets[i], 0:cin] . w[:, i*cin : (i+1)*cin]^T  (+ resid[m, 0:cout])
+ * for every m in [m0, m1) — halo rows included (their results are garbage by construction; the consumer masks them).
+ * w bf16 [cout, K], K = ntaps*cin rounded up to a multiple of 64 with zeros, K-contiguous, tap-major / channel-minor;
+ * cin % 32 == 0, cout % 4 == 0 (pad with zero channels / filters); out / resid bf16 with row strides ldo / ldr.
+ * x points at row 0; x_rows_before / x_rows_after = how many addressable rows the buffer has before row 0 and after row
+ * m1 - 1 (every m + offset must fall inside; checked).  fp32 accumulate, one rounding to bf16. */
+int icv_conv3d_ndhwc(const void* x, int64_t ldx, int64_t x_rows_before, int64_t x_rows_after, const void* w, const float* bias,
+                     const int64_t* tap_row_offsets, int64_t ntaps, int64_t cin, int64_t m0, int64_t m1, int64_t cout, void* out,
+                     int64_t ldo, const void* resid, int64_t ldr, void* stream);
 
 /* ---- K13: the sequence-parallel K|V exchange as a C entry point ---------------------------------
  * Replaces: the fork's sequence-parallel attention gather (north_star "per-layer K/V all-gather"; upstream xDiT/USP

@@ -16,6 +16,24 @@ from typing import Optional
 import torch
 
 
+# Default cap on RCCL's channel count for the K|V transports that run RCCL kernels (every channel = one resident work-group beside
+# an attention launch that runs one work-group per CU).  Measured on one MI355X (profiles/r05/kv_contention.md): the first
+# resident copy work-group already costs the shard-shape attention 10-21 %, the next seven add ~5 points, but 16+ jump to +22 % at
+# the sp8 shape; 8 channels move 150-190 GB/s, above what either layout needs to hide its exchange (sp8: 126 GB/s).
+RCCL_MAX_CHANNELS_DEFAULT = 8
+
+
+def apply_rccl_channel_cap(max_channels: int = -1, env=None) -> str:
+    """Set NCCL_MAX_NCHANNELS before the communicators are created: -1 = RCCL_MAX_CHANNELS_DEFAULT unless the variable is already
+    set (a user's own value wins), 0 = leave RCCL's own choice, k > 0 = k.  Returns the value in force ('' = RCCL's own)."""
+    env = os.environ if env is None else env
+    if max_channels > 0:
+        env["NCCL_MAX_NCHANNELS"] = str(max_channels)
+    elif max_channels < 0:
+        env.setdefault("NCCL_MAX_NCHANNELS", str(RCCL_MAX_CHANNELS_DEFAULT))
+    return env.get("NCCL_MAX_NCHANNELS", "")
+
+
 @dataclass(frozen=True)
 class ShardPlan:
     world: int

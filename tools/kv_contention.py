@@ -1,0 +1,163 @@
+"""What does a co-running K|V transfer cost the attention it is supposed to hide under?  (one GPU.)
+
+Self-attention at the per-rank shard shapes of the 8-GPU run (14B: n = 9 360 = cfg2 x sp4, n = 4 680 = sp8; 37 440 keys in 4 ramped
+chunks, K|V as the column halves of one [S, 2d] matrix: exactly the launches of the loop) is timed alone and then beside a
+transfer that runs for its whole duration on a second stream:
+  * `k` resident copy work-groups (tools/kv_occupy.hip), k = 1..32, in two footprints: "light" (no LDS: can share a CU with
+    other waves) and "64K LDS" (cannot share a CU with an attention work-group: takes the CU for itself) — what an RCCL
+    all-gather with k channels is to the attention launch;
+  * a loop of hipMemcpyAsync device-to-device copies (same device: the runtime's blit KERNEL — not what the copy-engine
+    transport does between two devices, where the copy is SDMA; here it shows what a chip-wide copy kernel costs);
+  * a 1-rank RCCL all-gather loop on libicvideo's own communicator (`icv_allgather_kv`), with NCCL_MAX_NCHANNELS from the
+    environment (run the tool once per setting).
+Prints one table per shard shape: attention ms, slow-down vs alone, and the bytes/s the transfer moved meanwhile.
+    python tools/kv_contention.py            (on the GPU box; ITERS=5 repetitions per cell)
+"""
+import ctypes, math, os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from infinicube_amd import native
+from infinicube_amd.videogen.ops import HipOps
+from infinicube_amd.videogen.seqpar import chunk_bounds
+
+here = os.path.dirname(os.path.abspath(__file__))
+so = os.path.join(here, "libkvoccupy.so")
+if not os.path.exists(so):
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-w", os.path.join(here, "kv_occupy.hip"), "-o", so], check=True)
+occ = ctypes.CDLL(so)
+occ.occ_start.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+assert occ.occ_init() == 0
+
+ops = HipOps("cuda:0")
+lib = ops.lib
+H, S = 40, 37440
+d = H * 128
+SCALE = math.log(2.0)
+ITERS = int(os.environ.get("ITERS", "5"))
+WHAT = os.environ.get("WHAT", "occupy,blit,rccl").split(",")
+torch.manual_seed(0)
+kv = torch.cat([(torch.randn((S, d), device="cuda") * (128 ** -0.5 * math.log2(math.e))).to(torch.bfloat16),
+                torch.randn((S, d), device="cuda").to(torch.bfloat16)], dim=1).contiguous()
+kh, vh = kv[:, :d], kv[:, d:]
+side = torch.cuda.Stream()
+main = torch.cuda.current_stream()
+SLICE = 32 << 20                     # bytes each copy work-group loops over
+src = torch.empty((32 * SLICE,), dtype=torch.uint8, device="cuda").random_(0, 255)
+dst = torch.empty_like(src)
+copied = torch.zeros((1,), dtype=torch.int64, device="cuda")
+
+
+def chunk_call(q, kk, vv, o, acc, ml, first, last):
+    native.check(lib.icv_attention_fwd_chunk(q.data_ptr(), q.stride(0), kk.data_ptr(), kk.stride(0), vv.data_ptr(), vv.stride(0), o.data_ptr(), o.stride(0),
+                                             acc.data_ptr(), acc.stride(0), ml.data_ptr(), q.shape[0], kk.shape[0], H, SCALE, int(first), int(last),
+                                             main.cuda_stream), "chunk")
+
+
+def time_attention(run, before=None, after=None):
+    """median-of-3 of (ITERS x run) on the main stream; `before` starts the co-runner, `after` stops it and returns bytes moved."""
+    run(); torch.cuda.synchronize()
+    res = []
+    for _ in range(3):
+        if before:
+            before()
+            time.sleep(0.003)          # the co-runner is resident before the first attention work-group is dispatched
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(ITERS):
+            run()
+        e1.record()
+        e1.synchronize()
+        wall = time.perf_counter() - t0
+        moved = after() if after else 0
+        torch.cuda.synchronize()
+        res.append((e0.elapsed_time(e1) / ITERS, moved / wall if wall > 0 else 0.0))
+    return sorted(res)[1]
+
+
+def occupier(k, lds):
+    def before():
+        copied.zero_()
+        torch.cuda.synchronize()
+        rc = occ.occ_start(k, src.data_ptr(), dst.data_ptr(), SLICE, lds, copied.data_ptr(), 1 << 14, side.cuda_stream)
+        assert rc == 0, rc
+
+    def after():
+        occ.occ_stop()
+        side.synchronize()
+        return int(copied.item())
+    return before, after
+
+
+def blit_loop(nbytes):
+    state = {}
+
+    def before():
+        state["n"] = 0
+        with torch.cuda.stream(side):
+            for _ in range(64):        # queued ahead: the stream stays busy for the whole measurement
+                dst[:nbytes].copy_(src[:nbytes], non_blocking=True)
+                state["n"] += 1
+
+    def after():
+        side.synchronize()
+        return 0
+    return before, after
+
+
+rccl = None
+if "rccl" in WHAT:
+    try:
+        idbuf = ctypes.create_string_buffer(native.COMM_ID_BYTES)
+        native.check(lib.icv_comm_unique_id(idbuf), "uid")
+        hcomm = ctypes.c_void_p()
+        native.check(lib.icv_comm_create(idbuf.raw, 0, 1, ctypes.byref(hcomm)), "comm")
+        rccl = hcomm
+    except Exception as e:  # noqa: BLE001
+        print(f"(1-rank RCCL communicator unavailable: {e})")
+
+
+def rccl_loop(nbytes):
+    def before():
+        for _ in range(64):
+            native.check(lib.icv_allgather_kv(rccl, src.data_ptr(), dst.data_ptr(), nbytes // 4096, 4096, side.cuda_stream), "ag")
+
+    def after():
+        side.synchronize()
+        return 0
+    return before, after
+
+
+print(f"# attention under a co-running transfer; NCCL_MAX_NCHANNELS={os.environ.get('NCCL_MAX_NCHANNELS', '(unset)')} ITERS={ITERS}")
+for world in (4, 8):
+    n = S // world
+    q = torch.randn((n, d), device="cuda").to(torch.bfloat16)
+    o = torch.empty_like(q)
+    acc = torch.empty((n, d), device="cuda")
+    ml = torch.empty((n, H, 2), device="cuda")
+    b = [world * x for x in chunk_bounds(n, 4)]
+    fl = 4.0 * n * S * d
+
+    def run():
+        for c in range(4):
+            chunk_call(q, kh[b[c]:b[c + 1]], vh[b[c]:b[c + 1]], o, acc, ml, c == 0, c == 3)
+
+    alone, _ = time_attention(run)
+    print(f"--- n = {n} query rows (1/{world} shard), 37 440 keys in 4 ramped chunks, 40 heads: alone {alone:.3f} ms = {fl / alone / 1e9:.0f} TF/s")
+    print(f"{'co-runner':44s} {'attn ms':>8s} {'slow-down':>10s} {'moved GB/s':>11s}")
+    rows = []
+    if "occupy" in WHAT:
+        for lds, name in ((0, "light"), (65536, "64K LDS")):
+            for k in (1, 2, 4, 8, 16, 32):
+                ms, rate = time_attention(run, *occupier(k, lds))
+                rows.append((f"{k:2d} copy work-groups ({name})", ms, rate))
+    chunk_bytes = 2 * 2 * d * (n - n // 10)       # ~ one large chunk of one peer's K|V rows
+    if "blit" in WHAT:
+        ms, _ = time_attention(run, *blit_loop(min(chunk_bytes, src.numel())))
+        rows.append((f"hipMemcpyAsync D2D loop ({min(chunk_bytes, src.numel()) >> 20} MiB, same-device blit kernel)", ms, 0.0))
+    if rccl is not None:
+        ms, _ = time_attention(run, *rccl_loop(min(chunk_bytes, src.numel()) // 4096 * 4096))
+        rows.append(("1-rank RCCL all-gather loop", ms, 0.0))
+    for name, ms, rate in rows:
+        print(f"{name:44s} {ms:8.3f} {100 * (ms / alone - 1):9.1f}% {rate / 1e9:11.1f}")
