@@ -237,6 +237,11 @@ int icv_depth_to_u16(const float* depth, int64_t n, float scale, unsigned short*
  * fp32 inside, one rounding to bf16.  C % 8 == 0, C <= 2048. */
 int icv_rmsnorm_act_rows(const void* x, void* out, const float* gamma, int64_t rows, int64_t C, float scale,
                          float eps, int act, void* stream);
+/* The same norm (+ SiLU) over a PADDED NDHWC volume [Tp, Hp, Wp, C] (csrc/conv.hip's activation layout: `pt` leading padding
+ * frames, a one-pixel spatial halo): interior positions as icv_rmsnorm_act_rows, padding / halo rows are WRITTEN AS ZEROS
+ * whatever the input holds there — the output is a valid zero-padded input of the next icv_conv3d_ndhwc. */
+int icv_rmsnorm_act_volume(const void* x, void* out, const float* gamma, int64_t Tp, int64_t Hp, int64_t Wp, int64_t pt, int64_t C,
+                           float scale, float eps, int act, void* stream);
 
 /* ---- voxel ray-cast of the guidance-buffer renderer ------------------------------------------
  * Replaces the three fVDB-bound calls of `generate_infinicube_buffer_from_fvdb_grid`

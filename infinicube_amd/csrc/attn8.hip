@@ -120,6 +120,11 @@ struct Params {
   const float* amax;                       // f32 [3][H]: q, k, v
   int64_t Sq, Skv;
   int heads, nqb, ntiles;
+  // Keys / values as PIECES (sequence parallel, e4m3 on the wire: every rank quantised its own rows of the chunk and shipped
+  // kq rows + Vt tiles): piece i holds `piece_rows` keys as tpp = ceil(piece_rows / 64) tiles; its kq rows start at
+  // k + i * piece_stride, its Vt tiles [H][tpp][128][64] at vt + i * piece_stride.  One piece = the plain layout.
+  int64_t piece_stride;
+  int piece_rows, tpp;
   float thr;
   attc::Params c;   // o / ldo, carried state (acc, ldacc, ml, state_in, state_out), Sq, heads: what load_state / store_result read
 };
@@ -201,15 +206,19 @@ __global__ __launch_bounds__(512) void attn8_kernel(Params p) {
   const int nt = p.ntiles;
   const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
   const unsigned char* kh = p.k + (int64_t)head * D;
-  const unsigned char* vth = p.vt + (int64_t)head * nt * (D * KVB);
+  // tile -> (piece, tile inside the piece), advanced incrementally: A8_DMA_TILE is called once per tile index, in order
+  int d_pc = 0, d_tl = 0;
 #define A8_DMA_TILE(T_)                                                                              \
   {                                                                                                  \
-    const int tt_ = (T_) < nt ? (T_) : nt - 1;                                                       \
-    int64_t kr_ = (int64_t)tt_ * KVB + krow;                                                         \
-    kr_ = kr_ < p.Skv ? kr_ : p.Skv - 1;                                                             \
+    int kr_ = d_tl * KVB + krow;                                                                     \
+    kr_ = kr_ < p.piece_rows ? kr_ : p.piece_rows - 1;                                               \
     const unsigned l0_ = lds_base + (unsigned)(((T_) & (NSTAGE - 1)) * STAGE_BYTES + wave * 1024);   \
-    dma16(kh + kr_ * p.ldk + kcol, l0_);                                                             \
-    dma16(vth + ((int64_t)tt_ * D + vrow) * KVB + vcol, l0_ + KT_BYTES);                             \
+    const int64_t pb_ = (int64_t)d_pc * p.piece_stride;                                              \
+    dma16(kh + pb_ + (int64_t)kr_ * p.ldk + kcol, l0_);                                              \
+    dma16(p.vt + pb_ + (((int64_t)head * p.tpp + d_tl) * D + vrow) * KVB + vcol, l0_ + KT_BYTES);    \
+    if ((T_) < nt - 1) {           /* past the last tile the last one is re-loaded (uniform DMA counts) */ \
+      if (++d_tl == p.tpp) { d_tl = 0; ++d_pc; }                                                     \
+    }                                                                                                \
   }
 #define A8_VMCNT2() asm volatile("s_waitcnt vmcnt(2)" ::: "memory")
 #define A8_BARRIER()                                          \
@@ -237,10 +246,12 @@ __global__ __launch_bounds__(512) void attn8_kernel(Params p) {
   const int k_row = l31 * 128;
   const int v_sw0 = (l31 >> 2) & 3;          // ((d0*32 + l31) >> 2) & 3 == (l31 >> 2) & 3
 
+  int c_tl = 0;        // tile inside its piece of the tile being computed
   for (int t = 0; t < nt; ++t) {
     const char* ks = smem + (t & (NSTAGE - 1)) * STAGE_BYTES;
     const char* vs = ks + KT_BYTES;
-    const int64_t key0 = (int64_t)t * KVB;
+    const int key0 = c_tl * KVB;                   // first key of this tile inside its piece
+    if (++c_tl == p.tpp) c_tl = 0;
     A8_DMA_TILE(t + ahead);
 
     // ---- S^T = Kq Qq^T (4 MFMAs), scales in the MFMA, reference in the C operand of the first step ----
@@ -257,13 +268,13 @@ __global__ __launch_bounds__(512) void attn8_kernel(Params p) {
         st[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf[s], s == 0 ? cinit : st[kb], 0, 0, 0, sK, 0, sQ);
       }
     if (SETPRIO) __builtin_amdgcn_s_setprio(0);
-    if (key0 + KVB > p.Skv) {
+    if (key0 + KVB > p.piece_rows) {               // the ragged last tile of a piece: its padding keys do not exist
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int64_t key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (key >= p.Skv) st[kb][r] = NEG_BIG;
+          const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= p.piece_rows) st[kb][r] = NEG_BIG;
         }
     }
     // ---- lazy-max softmax at unit scale (attn2.hip / attn7.hip) over the whole 64-key tile: P = exp2(S) against

@@ -43,7 +43,7 @@ struct Params {
   int nt;                              // K-tiles
   int halves_per_tap;                  // cin / 32
   int ntaps;
-  unsigned magic;                      // ceil(2^32 / halves_per_tap): tap = (g * magic) >> 32 for g < 2^16
+  unsigned long long magic;            // ceil(2^32 / halves_per_tap) (= 2^32 for one half per tap): tap = (g * magic) >> 32 for g < 2^16
   int64_t tap_bytes[MAX_TAPS];         // row shift of tap i in BYTES (off_i * ldx * 2)
   int tiles_m, tiles_n;
 };
@@ -118,15 +118,20 @@ __global__ __launch_bounds__(512) void conv_shift_kernel(Params p) {
   const int last_half = p.ntaps * p.halves_per_tap - 1;
   auto half_bytes = [&](int g) -> int64_t {
     g = g < last_half ? g : last_half;
-    const int tap = (int)(((unsigned long long)(unsigned)g * p.magic) >> 32);
+    const int tap = (int)(((unsigned long long)(unsigned)g * p.magic) >> 32);          // g < 2^16, magic <= 2^32: no overflow
     const int c0 = (g - tap * p.halves_per_tap) * 32;
     return p.tap_bytes[tap] + (int64_t)c0 * 2;
   };
   const int nt = p.nt;
-  auto dma_a = [&](int h, int t, char* unit) {
+  // the A shift of K-tile t as THIS lane needs it (its chunk lies in the lower or the upper half of the tile).  The tap table is
+  // read with scalar loads, whose wait (lgkmcnt) would also drain the LDS reads of the segment that issues them: the value for
+  // tile t+3 is therefore formed right behind the segment's own `s_waitcnt lgkmcnt(0)`, a whole tile before its DMA needs it.
+  auto a_shift = [&](int t) -> int64_t {
     t = t < nt ? t : nt - 1;
     const int64_t lo = half_bytes(2 * t), hi = half_bytes(2 * t + 1);
-    const int64_t kb = upper ? hi : lo;
+    return upper ? hi : lo;
+  };
+  auto dma_a = [&](int h, int64_t kb, char* unit) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const char* src = p.X + (int64_t)offA[h][q] + kb;
@@ -161,11 +166,15 @@ __global__ __launch_bounds__(512) void conv_shift_kernel(Params p) {
   char* const st0 = smem;
   char* const st1 = smem + STAGE;
   // prologue: A0(0), B(0), A1(0) -> stage 0; A0(1), B(1) -> stage 1
-  dma_a(0, 0, st0);
-  dma_b(0, st0 + 2 * AUNIT);
-  dma_a(1, 0, st0 + AUNIT);
-  dma_a(0, 1, st1);
-  dma_b(1, st1 + 2 * AUNIT);
+  int64_t kb1 = a_shift(1), kb2 = a_shift(2);       // shifts of tile t+1 / t+2 while tile t is computed
+  {
+    const int64_t kb0 = a_shift(0);
+    dma_a(0, kb0, st0);
+    dma_b(0, st0 + 2 * AUNIT);
+    dma_a(1, kb0, st0 + AUNIT);
+    dma_a(0, kb1, st1);
+    dma_b(1, st1 + 2 * AUNIT);
+  }
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");      // A0(0), B(0) landed
   CV_BARRIER();
   if (wr >= 2) CV_BARRIER();                                          // stagger: waves 4..7 run one barrier behind
@@ -195,7 +204,7 @@ __global__ __launch_bounds__(512) void conv_shift_kernel(Params p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) af[i][ks] = *reinterpret_cast<const bf16x8*>(cur + a_off[ks] + i * 2048);
     }
-    dma_a(1, t + 1, oth + AUNIT);
+    dma_a(1, kb1, oth + AUNIT);
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WAITN) : "memory");
     CV_BARRIER();
     CV_MFMA(0);
@@ -205,9 +214,11 @@ __global__ __launch_bounds__(512) void conv_shift_kernel(Params p) {
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < 2; ++i) af[i][ks] = *reinterpret_cast<const bf16x8*>(cur + AUNIT + a_off[ks] + i * 2048);
-    dma_a(0, t + 2, cur);
+    dma_a(0, kb2, cur);
     dma_b(t + 2, cur + 2 * AUNIT);
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WAITN) : "memory");
+    kb1 = kb2;
+    kb2 = a_shift(t + 3);
     CV_BARRIER();
     CV_MFMA(1);
     CV_BARRIER();
@@ -216,25 +227,46 @@ __global__ __launch_bounds__(512) void conv_shift_kernel(Params p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the tail DMA before the LDS is released
   if (wr < 2) CV_BARRIER();                           // re-balance the stagger
 
-  // ---- epilogue: a lane owns ONE row and runs of 4 consecutive channels ----
+  // ---- epilogue: a lane owns ONE row and runs of 4 consecutive channels.  Bias once per column run; the residual rows of
+  // a half (2 x NB fragments) are requested together before any is consumed (the fragment registers are dead by now): a
+  // load -> wait -> store round trip per fragment would cost more than a third of a 96-channel tile's main loop ----
+  float4 bs[NB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int64_t m = row0 + wr * 64 + (i >> 1) * 32 + (i & 1) * 16 + fr;
-    if (m >= p.m1) continue;
+  for (int j = 0; j < NB; ++j) {
+    const int64_t n = n0 + wc * 16 * NB + j * 16 + kq * 4;
+    bs[j] = (p.bias && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const int64_t n = n0 + wc * 16 * NB + j * 16 + kq * 4;
-      if (n >= p.N) continue;
-      f32x4 v = acc[i][j];
-      if (p.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+  for (int hf = 0; hf < 2; ++hf) {
+    uint2 rs[2][NB];
+    if (p.resid) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int64_t m = row0 + wr * 64 + hf * 32 + ii * 16 + fr;
+        const int64_t mc = m < p.m1 ? m : p.m1 - 1;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const int64_t n = n0 + wc * 16 * NB + j * 16 + kq * 4;
+          const int64_t nc = n < p.N ? n : p.N - 4;
+          rs[ii][j] = *reinterpret_cast<const uint2*>(p.resid + mc * p.ldr + nc);
+        }
       }
-      if (p.resid) {
-        const uint2 r = *reinterpret_cast<const uint2*>(p.resid + m * p.ldr + n);
-        v[0] += bf16lo_to_f32(r.x); v[1] += bf16hi_to_f32(r.x); v[2] += bf16lo_to_f32(r.y); v[3] += bf16hi_to_f32(r.y);
+    }
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      const int64_t m = row0 + wr * 64 + hf * 32 + ii * 16 + fr;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int64_t n = n0 + wc * 16 * NB + j * 16 + kq * 4;
+        f32x4 v = acc[hf * 2 + ii][j];
+        v[0] += bs[j].x; v[1] += bs[j].y; v[2] += bs[j].z; v[3] += bs[j].w;
+        if (p.resid) {
+          const uint2 r = rs[ii][j];
+          v[0] += bf16lo_to_f32(r.x); v[1] += bf16hi_to_f32(r.x); v[2] += bf16lo_to_f32(r.y); v[3] += bf16hi_to_f32(r.y);
+        }
+        if (m < p.m1 && n < p.N)
+          *reinterpret_cast<uint2*>(p.out + m * p.ldo + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
       }
-      *reinterpret_cast<uint2*>(p.out + m * p.ldo + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
     }
   }
 }
@@ -266,7 +298,7 @@ extern "C" int icv_conv3d_ndhwc(const void* x, int64_t ldx, int64_t x_rows_befor
   p.X = (const char*)x; p.ldx = ldx; p.W = (const char*)w; p.ldw = K; p.bias = bias;
   p.m0 = m0; p.m1 = m1; p.N = cout; p.out = (bf16_t*)out; p.ldo = ldo; p.resid = (const bf16_t*)resid; p.ldr = ldr;
   p.nt = (int)(K / 64); p.halves_per_tap = (int)(cin / 32); p.ntaps = (int)ntaps;
-  p.magic = (unsigned)(((1ull << 32) + (uint64_t)p.halves_per_tap - 1) / (uint64_t)p.halves_per_tap);
+  p.magic = ((1ull << 32) + (uint64_t)p.halves_per_tap - 1) / (uint64_t)p.halves_per_tap;
   for (int i = 0; i < ntaps; ++i) {
     const int64_t off = tap_row_offsets[i];
     // every row the kernel touches must exist: the caller states how many addressable rows precede row 0 / follow row m1 - 1

@@ -54,6 +54,7 @@ SIGNATURES = {
                                   _F, _F, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "icv_depth_to_u16": (c_int, [_P, _I, _F, _P, _P]),
     "icv_rmsnorm_act_rows": (c_int, [_P, _P, _P, _I, _I, _F, _F, c_int, _P]),
+    "icv_rmsnorm_act_volume": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, c_int, _P]),
     "icv_conv3d_ndhwc": (c_int, [_P, _I, _I, _I, _P, _P, ctypes.POINTER(c_int64), _I, _I, _I, _I, _I, _P, _I, _P, _I, _P]),
     "icv_coord_valid_mask": (c_int, [_P, ctypes.POINTER(c_float), _P, _I, _I, _I, _P, _P]),
     "icv_coord_gather_points": (c_int, [_P, ctypes.POINTER(c_float), _P, _I, _I, _I, _P, _I, _P, _P]),

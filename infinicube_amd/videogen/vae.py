@@ -96,7 +96,10 @@ class RMS_norm(nn.Module):
             native.check(lib.icv_rmsnorm_act_rows(x.data_ptr(), out.data_ptr(), self._g32.data_ptr(), x.numel() // c, c, self.scale, 1e-12,
                                                   int(act), torch.cuda.current_stream(x.device).cuda_stream), "icv_rmsnorm_act_rows")
             return out
-        return F.normalize(x, dim=(1 if self.channel_first else -1)) * self.scale * self.gamma
+        y = F.normalize(x, dim=(1 if self.channel_first else -1)) * self.scale * self.gamma
+        # WanVAE replaced the nn.SiLU behind this norm with an Identity when it installed the fused kernel (fused[1] == 1): the
+        # activation must not depend on the layout predicate above holding (batch > 1, fp32 input, a non-NDHWC view, ...)
+        return F.silu(y) if (self.fused is not None and self.fused[1] == 1) else y
 
 
 class Upsample(nn.Upsample):
@@ -306,6 +309,20 @@ class WanVAE:
                     m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last_3d)
                 elif isinstance(m, nn.Conv2d):
                     m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+        # every convolution of the tile networks on libicvideo's shifted-row MFMA kernel (vae_hip.VaeHip, csrc/conv.hip) instead
+        # of MIOpen: no kernel search on the first call of a process, the same kernels in every process.  ICV_VAE_CONV=miopen
+        # keeps the stock convolutions (the module path above).
+        self.hip = None
+        if (torch.device(device).type == "cuda" and dtype == torch.bfloat16 and os.environ.get("ICV_VAE_CONV", "hip") == "hip"
+                and all(m.in_channels % 32 == 0 or m.in_channels < 32 for m in self.net.modules() if isinstance(m, (nn.Conv3d, nn.Conv2d)))):
+            from .vae_hip import VaeHip
+            self.hip = VaeHip(self.net, device)
+
+    def _net_encode(self, x):
+        return self.hip.encode_tile(x) if self.hip is not None else self.net.encode(x)
+
+    def _net_decode(self, z):
+        return self.hip.decode_tile(z) if self.hip is not None else self.net.decode(z)
 
     @staticmethod
     @contextlib.contextmanager
@@ -368,7 +385,7 @@ class WanVAE:
             raise ValueError("encode_many: the clips must have the same shape")
         T = (F_ - 1) // 4 + 1
         if not tiled:
-            outs = self._run_tiles(list(range(len(xs))), lambda j: self.net.encode(xs[j]),
+            outs = self._run_tiles(list(range(len(xs))), lambda j: self._net_encode(xs[j]),
                                    None if shard is None else shard.with_shape(lambda j: (1, self.net.z_dim, T, H // 8, W // 8)))
             return [o[0].float() for o in outs]
         size, stride = (tile_size[0] * 8, tile_size[1] * 8), (tile_stride[0] * 8, tile_stride[1] * 8)
@@ -379,7 +396,7 @@ class WanVAE:
             _, (h0, h1, w0, w1) = task
             return (1, self.net.z_dim, T, (min(h1, H) - h0) // 8, (min(w1, W) - w0) // 8)
 
-        zs = self._run_tiles(tasks, lambda t: self.net.encode(xs[t[0]][:, :, :, t[1][0]:t[1][1], t[1][2]:t[1][3]]),
+        zs = self._run_tiles(tasks, lambda t: self._net_encode(xs[t[0]][:, :, :, t[1][0]:t[1][1], t[1][2]:t[1][3]]),
                              None if shard is None else shard.with_shape(shape_of))
         results = []
         for j in range(len(xs)):
@@ -402,14 +419,14 @@ class WanVAE:
             z = z.contiguous(memory_format=torch.channels_last_3d)
         _, _, T, H, W = z.shape
         if not tiled:
-            return self.net.decode(z)[0].float()
+            return self._net_decode(z)[0].float()
         tasks = _tile_tasks(H, W, tile_size, tile_stride)
 
         def shape_of(task):
             h0, h1, w0, w1 = task
             return (1, 3, T * 4 - 3, (min(h1, H) - h0) * 8, (min(w1, W) - w0) * 8)
 
-        ys = self._run_tiles(tasks, lambda t: self.net.decode(z[:, :, :, t[0]:t[1], t[2]:t[3]]),
+        ys = self._run_tiles(tasks, lambda t: self._net_decode(z[:, :, :, t[0]:t[1], t[2]:t[3]]),
                              None if shard is None else shard.with_shape(shape_of))
         if not blend:          # a rank that only contributes its tiles (WorkerPool workers)
             return None
