@@ -161,6 +161,23 @@ int icv_attention_fp8_fwd(const void* qq, int64_t ldqq, const void* kq, int64_t 
 int icv_attention_fp8_fwd_chunk(const void* qq, int64_t ldqq, const void* kq, int64_t ldkq, const void* vt,
                                 const float* amax, void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml,
                                 int64_t Sq, int64_t Skv, int64_t heads, int first, int last, void* stream);
+/* e4m3 K|V ON THE WIRE (sequence parallel; config #5): every rank quantises its own K|V rows once and the exchange (K13) moves
+ * e4m3 bytes — half the xGMI traffic of bf16 rows, 1/world of the quantise work of "gather, then quantise on every rank".
+ * icv_attention_fp8_kv_amax: amax[1][h], amax[2][h] <- per-head abs-max of this rank's k / v rows (bf16 [rows, H*128]; row 0 of
+ *   amax, the queries', is left alone).  The host max-reduces these 2*H floats over the ranks: every rank then uses the scale
+ *   of the UNSHARDED launch, so the e4m3 values are the single-GPU ones.
+ * icv_attention_fp8_quantize_kv: rows of k / v -> one "blob" = [ kq e4m3 [rows_pad, H*128] | vt tiles [H][rows_pad/64][128][64] ],
+ *   rows_pad = rows rounded up to 64, icv_attention_fp8_blob_bytes(rows, H) bytes, with the scales derived from amax.
+ * icv_attention_fp8_fwd_pieces: icv_attention_fp8_fwd_chunk over `n_pieces` such blobs back to back (the gathered chunk,
+ *   rank-major), piece_rows real keys in each; padding keys of a piece's last tile are masked. */
+int64_t icv_attention_fp8_blob_bytes(int64_t rows, int64_t heads);
+int icv_attention_fp8_kv_amax(const void* k, int64_t ldk, const void* v, int64_t ldv, int64_t rows, int64_t heads, float* amax,
+                              void* stream);
+int icv_attention_fp8_quantize_kv(const void* k, int64_t ldk, const void* v, int64_t ldv, int64_t rows, int64_t heads,
+                                  const float* amax, void* blob, void* stream);
+int icv_attention_fp8_fwd_pieces(const void* qq, int64_t ldqq, const void* blobs, int64_t piece_rows, int64_t n_pieces,
+                                 const float* amax, void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml, int64_t Sq,
+                                 int64_t heads, int first, int last, void* stream);
 
 /* ---- K6 split along the KEY axis (K13 overlap): attention over one chunk of keys with a carried
  * online-softmax state, so the sequence-parallel path can consume K/V chunks as the RCCL all-gather

@@ -387,18 +387,22 @@ extern "C" int icv_attention_fp8_prepare(const void* q, int64_t ldq, const void*
 }
 
 static int attn8_run(const void* qq, int64_t ldqq, const void* kq, int64_t ldkq, const void* vt, const float* amax, void* o,
-                     int64_t ldo, float* acc, int64_t ldacc, float* ml, int state_in, int state_out, int64_t Sq, int64_t Skv,
-                     int64_t heads, hipStream_t st) {
+                     int64_t ldo, float* acc, int64_t ldacc, float* ml, int state_in, int state_out, int64_t Sq, int64_t piece_rows,
+                     int64_t n_pieces, int64_t piece_stride, int64_t heads, hipStream_t st) {
   att8::Params p;
+  const int64_t Skv = piece_rows * n_pieces;
   p.q = (const unsigned char*)qq; p.ldq = ldqq; p.k = (const unsigned char*)kq; p.ldk = ldkq; p.vt = (const unsigned char*)vt;
   p.amax = amax; p.Sq = Sq; p.Skv = Skv; p.heads = (int)heads;
   p.nqb = (int)((Sq + att8::QB - 1) / att8::QB);
-  p.ntiles = (int)((Skv + att8::KVB - 1) / att8::KVB);
+  p.tpp = (int)((piece_rows + att8::KVB - 1) / att8::KVB);
+  p.piece_rows = (int)piece_rows;
+  p.piece_stride = piece_stride;
+  p.ntiles = (int)(p.tpp * n_pieces);
   p.thr = (float)icv_get_option_int("attn_defer_max_log2", 8);
   p.c = attc::Params{};
   p.c.o = (bf16_t*)o; p.c.ldo = ldo; p.c.acc = acc; p.c.ldacc = ldacc; p.c.ml = ml; p.c.state_in = state_in; p.c.state_out = state_out;
   p.c.Sq = Sq; p.c.Skv = Skv; p.c.heads = (int)heads; p.c.nqb = p.nqb; p.c.sc = 1.0f; p.c.thr = p.thr;
-  ICV_REQUIRE((int64_t)p.heads * p.nqb < (1LL << 31), "icv_attention_fp8_fwd: grid too large");
+  ICV_REQUIRE((int64_t)p.heads * p.nqb < (1LL << 31) && piece_rows < (1LL << 30), "icv_attention_fp8_fwd: grid too large");
   switch (icv_get_option_int("attn8_variant", 0)) {
     case 0: return att8::launch<0>(p, st);
     case 1: return att8::launch<1>(p, st);
@@ -415,7 +419,7 @@ extern "C" int icv_attention_fp8_fwd(const void* qq, int64_t ldqq, const void* k
   ICV_REQUIRE(qq && kq && vt && amax && o, "icv_attention_fp8_fwd: null pointer");
   ICV_REQUIRE(Sq > 0 && Skv > 0 && heads > 0, "icv_attention_fp8_fwd: empty problem");
   ICV_REQUIRE(ldqq % 16 == 0 && ldkq % 16 == 0 && ldo % 4 == 0, "icv_attention_fp8_fwd: leading dims must keep 16-byte row alignment");
-  return attn8_run(qq, ldqq, kq, ldkq, vt, amax, o, ldo, nullptr, 0, nullptr, 0, 0, Sq, Skv, heads, (hipStream_t)stream);
+  return attn8_run(qq, ldqq, kq, ldkq, vt, amax, o, ldo, nullptr, 0, nullptr, 0, 0, Sq, Skv, 1, 0, heads, (hipStream_t)stream);
 }
 
 extern "C" int icv_attention_fp8_fwd_chunk(const void* qq, int64_t ldqq, const void* kq, int64_t ldkq, const void* vt,
@@ -426,5 +430,62 @@ extern "C" int icv_attention_fp8_fwd_chunk(const void* qq, int64_t ldqq, const v
   ICV_REQUIRE(ldqq % 16 == 0 && ldkq % 16 == 0, "icv_attention_fp8_fwd_chunk: leading dims must keep 16-byte row alignment");
   ICV_REQUIRE((first && last) || (acc && ml && ldacc % 4 == 0), "icv_attention_fp8_fwd_chunk: carried state buffers required unless first && last");
   ICV_REQUIRE(!last || (o && ldo % 4 == 0), "icv_attention_fp8_fwd_chunk: output required for the last chunk");
-  return attn8_run(qq, ldqq, kq, ldkq, vt, amax, o, ldo, acc, ldacc, ml, first ? 0 : 1, last ? 0 : 1, Sq, Skv, heads, (hipStream_t)stream);
+  return attn8_run(qq, ldqq, kq, ldkq, vt, amax, o, ldo, acc, ldacc, ml, first ? 0 : 1, last ? 0 : 1, Sq, Skv, 1, 0, heads, (hipStream_t)stream);
+}
+
+// ---- e4m3 K|V ON THE WIRE (sequence parallel, BASELINE.json config #5) ------------------------------------------------------
+// Each rank quantises its OWN rows of a K|V chunk once and ships e4m3 bytes (half the xGMI traffic of bf16 rows, 1/world of the
+// quantise work of "gather bf16, quantise the gathered chunk on every rank").  For that the scales must be known before the
+// exchange: icv_attention_fp8_kv_amax gives this rank's per-head abs-max of its whole K and V shard, the host max-reduces the
+// 2 x H floats over the sequence-parallel group (one tiny collective per layer), and every rank then quantises with the SAME
+// per-head scale — the scale of the unsharded launch, so the e4m3 values are exactly the single-GPU ones.
+// A rank's piece of a chunk ("blob") = [ kq: rows_pad x (H*128) e4m3 row-major | vt: [H][rows_pad / 64][128][64] ],
+// rows_pad = rows rounded up to 64; blob bytes = 2 * rows_pad * H * 128 (icv_attention_fp8_blob_bytes).  The gathered chunk is
+// `n_pieces` blobs back to back (rank-major) and icv_attention_fp8_fwd_pieces consumes it in place.
+extern "C" int64_t icv_attention_fp8_blob_bytes(int64_t rows, int64_t heads) {
+  const int64_t rp = (rows + att8::KVB - 1) / att8::KVB * att8::KVB;
+  return 2 * rp * heads * att8::D;
+}
+
+extern "C" int icv_attention_fp8_kv_amax(const void* k, int64_t ldk, const void* v, int64_t ldv, int64_t rows, int64_t heads, float* amax,
+                                         void* stream) {
+  ICV_REQUIRE(k && v && amax && rows > 0 && heads > 0, "icv_attention_fp8_kv_amax: null pointer / empty problem");
+  ICV_REQUIRE(ldk % 8 == 0 && ldv % 8 == 0, "icv_attention_fp8_kv_amax: leading dims must keep 16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  ICV_REQUIRE(hipMemsetAsync(amax + heads, 0, sizeof(float) * 2 * heads, st) == hipSuccess, "icv_attention_fp8_kv_amax: memset failed");
+  const dim3 grid((unsigned)heads, (unsigned)((rows + 255) / 256));
+  int* ab = reinterpret_cast<int*>(amax);
+  hipLaunchKernelGGL(att8::amax_kernel, grid, dim3(256), 0, st, (const bf16_t*)k, ldk, rows, ab + heads);
+  hipLaunchKernelGGL(att8::amax_kernel, grid, dim3(256), 0, st, (const bf16_t*)v, ldv, rows, ab + 2 * heads);
+  return icv_check_launch("icv_attention_fp8_kv_amax");
+}
+
+extern "C" int icv_attention_fp8_quantize_kv(const void* k, int64_t ldk, const void* v, int64_t ldv, int64_t rows, int64_t heads,
+                                             const float* amax, void* blob, void* stream) {
+  ICV_REQUIRE(k && v && amax && blob && rows > 0 && heads > 0, "icv_attention_fp8_quantize_kv: null pointer / empty problem");
+  ICV_REQUIRE(ldk % 8 == 0 && ldv % 8 == 0, "icv_attention_fp8_quantize_kv: leading dims must keep 16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  const int nt = (int)((rows + att8::KVB - 1) / att8::KVB);
+  const int64_t ldkq = heads * att8::D;
+  unsigned char* kq = (unsigned char*)blob;
+  unsigned char* vt = kq + (int64_t)nt * att8::KVB * ldkq;
+  const dim3 grid((unsigned)heads, (unsigned)((rows + 255) / 256));
+  hipLaunchKernelGGL(att8::quant_rows_kernel, grid, dim3(256), 0, st, (const bf16_t*)k, ldk, rows, amax + heads, kq, ldkq);
+  hipLaunchKernelGGL(att8::quant_vt_kernel, dim3((unsigned)nt, (unsigned)heads), dim3(256), 0, st, (const bf16_t*)v, ldv, rows, amax + 2 * heads, vt, nt);
+  return icv_check_launch("icv_attention_fp8_quantize_kv");
+}
+
+extern "C" int icv_attention_fp8_fwd_pieces(const void* qq, int64_t ldqq, const void* blobs, int64_t piece_rows, int64_t n_pieces,
+                                            const float* amax, void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml, int64_t Sq,
+                                            int64_t heads, int first, int last, void* stream) {
+  ICV_REQUIRE(qq && blobs && amax, "icv_attention_fp8_fwd_pieces: null pointer");
+  ICV_REQUIRE(Sq > 0 && piece_rows > 0 && n_pieces > 0 && heads > 0, "icv_attention_fp8_fwd_pieces: empty problem");
+  ICV_REQUIRE(ldqq % 16 == 0, "icv_attention_fp8_fwd_pieces: leading dims must keep 16-byte row alignment");
+  ICV_REQUIRE((first && last) || (acc && ml && ldacc % 4 == 0), "icv_attention_fp8_fwd_pieces: carried state buffers required unless first && last");
+  ICV_REQUIRE(!last || (o && ldo % 4 == 0), "icv_attention_fp8_fwd_pieces: output required for the last chunk");
+  const int64_t rp = (piece_rows + att8::KVB - 1) / att8::KVB * att8::KVB;
+  const int64_t ldkq = heads * att8::D;
+  const unsigned char* kq = (const unsigned char*)blobs;
+  return attn8_run(qq, ldqq, kq, ldkq, kq + rp * ldkq, amax, o, ldo, acc, ldacc, ml, first ? 0 : 1, last ? 0 : 1, Sq, piece_rows, n_pieces,
+                   icv_attention_fp8_blob_bytes(piece_rows, heads), heads, (hipStream_t)stream);
 }

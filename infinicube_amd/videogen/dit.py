@@ -308,11 +308,15 @@ class WanDiT:
             if old is not None and old is not kv_gather and hasattr(old, "close"):
                 old.close()                                        # a copy-engine transport owns a heap and streams
             self.kv_gather = kv_gather or KVGather(self.plan, group, kv_exchange)
+            self.sp_bounds = chunk_bounds(n, sp_chunks)
+            # e4m3 attention under sequence parallelism: ship e4m3 K|V (each rank quantises its own rows once) instead of bf16
+            # rows that every rank re-quantises (ICV_FP8_WIRE=bf16 restores that order of operations)
+            self.fp8_wire = (self.attn_fp8 and os.environ.get("ICV_FP8_WIRE", "e4m3") == "e4m3" and hasattr(ops, "attention_fp8_quantize_kv")
+                             and hasattr(self.kv_gather, "allreduce_max"))
             self._sp_local_rows()                                  # kv_loc: local k | v rows (one exchange moves both)
             self.kv_full = a((self.plan.world * n, 2 * d), BF16)   # gathered rows (chunk-major, rank-major inside)
             self.sp_acc = a((n, d), F32)                           # carried O accumulator between key chunks
             self.sp_ml = a((n, cfg.num_heads, 2), F32)             # carried (running max, row sum)
-            self.sp_bounds = chunk_bounds(n, sp_chunks)
         else:
             self.kv_loc, self.kv_full, self.kv_gather = None, None, None
         return self
@@ -320,15 +324,34 @@ class WanDiT:
     def _sp_local_rows(self):
         """(Re)place the matrices this rank writes its K|V rows into where the current transport wants them: plain workspace
         for the collective modes, the symmetric heap the peers pull from for KVGather mode "ipc" (seqpar._IpcHeap) - sized
-        for this engine's [n, 2d] rows plus the [2n, 2d] rows of its CFG-batched pair twin (forward_pair)."""
-        n, d, kg = self.plan.n_tok, self.cfg.dim, self.kv_gather
+        for this engine's [n, 2d] rows plus the [2n, 2d] rows of its CFG-batched pair twin (forward_pair).  With e4m3 on the
+        wire (``fp8_wire``) what travels is one e4m3 blob per row chunk (ops.attention_fp8_quantize_kv): those blobs are the
+        rows that must live where the transport can reach them, one set per CFG branch of the pair twin."""
+        n, d, kg, H = self.plan.n_tok, self.cfg.dim, self.kv_gather, self.cfg.num_heads
+        U8 = torch.uint8
+        self._kv8_chunks, tot8 = [], 0
+        if getattr(self, "fp8_wire", False):
+            for b0, b1 in zip(self.sp_bounds[:-1], self.sp_bounds[1:]):
+                rows8 = self.ops.attention_fp8_blob_bytes(b1 - b0, H) // d          # blob as [rows8, d] bytes
+                self._kv8_chunks.append((tot8, rows8, b0, b1))
+                tot8 += rows8
         if hasattr(kg, "reserve"):
-            kg.reserve(3 * n * 2 * d * 2 + 1024, self.ops.device)
-        rows = (lambda r: kg.local_rows(r, 2 * d, BF16, self.ops.alloc)) if hasattr(kg, "local_rows") else (lambda r: self.ops.alloc((r, 2 * d), BF16))
+            kg.reserve(3 * n * 2 * d * 2 + 3 * tot8 * d + 4096, self.ops.device)
+        if hasattr(kg, "local_rows"):
+            rows = lambda r, cols=2 * d, dt=BF16: kg.local_rows(r, cols, dt, self.ops.alloc)      # noqa: E731
+        else:
+            rows = lambda r, cols=2 * d, dt=BF16: self.ops.alloc((r, cols), dt)                  # noqa: E731
         self.kv_loc = rows(n)
         self._kv_rows = rows
+        self.kv8 = self._sp_wire_set(rows, tot8) if tot8 else None
         if getattr(self, "_pair", None) is not None:
             self._pair.kv_loc = rows(2 * n)
+            self._pair.kv8 = [self._sp_wire_set(rows, tot8) for _ in range(2)] if tot8 else None
+
+    def _sp_wire_set(self, rows, tot8):
+        """(local blobs [tot8, d] bytes, gathered blobs [world * tot8, d] bytes chunk-major, abs-max table f32 [3, H])."""
+        d = self.cfg.dim
+        return (rows(tot8, d, torch.uint8), self.ops.alloc((self.plan.world * tot8, d), torch.uint8), self.ops.alloc((3, self.cfg.num_heads), F32))
 
     def _sp_acquire(self):
         """Before the K|V GEMM overwrites the local rows: wait for the peers' pulls of the previous layer (mode "ipc" only)."""
@@ -444,13 +467,29 @@ class WanDiT:
         dev = getattr(self.ops, "device", None)
         return dev is not None and torch.device(dev).type == "cuda"
 
-    def _sp_start_gather(self, kv_loc=None, kv_full=None):
+    def _sp_start_gather(self, kv_loc=None, kv_full=None, kv8=None):
         """K13: enqueue the exchange of every K|V row-chunk (RCCL runs them back to back on its own
-        stream; chunk c = rows [r0, r1) of EVERY rank's shard, rank-major)."""
+        stream; chunk c = rows [r0, r1) of EVERY rank's shard, rank-major).
+        e4m3 on the wire (``fp8_wire``; ``kv8`` = this branch's wire set): the per-head abs-max of the local K and V rows is
+        max-reduced over the group first (2 x H floats, one tiny collective per layer), every rank quantises its own rows of
+        each chunk ONCE with those scales - the scales of the unsharded launch, so the e4m3 values are the single-GPU ones -
+        and the exchange moves the e4m3 blobs: half the bytes of bf16 rows, 1/world of the quantise work."""
         world, b, d = self.plan.world, self.sp_bounds, self.cfg.dim
         kv_loc = self.kv_loc if kv_loc is None else kv_loc
-        kv_full = self.kv_full if kv_full is None else kv_full
         handles, bufs = [], []
+        if getattr(self, "fp8_wire", False):
+            loc8, full8, amax = self.kv8 if kv8 is None else kv8
+            H = self.cfg.num_heads
+            self.ops.attention_fp8_kv_amax(kv_loc[:, :d], kv_loc[:, d:], H, amax)
+            self.kv_gather.allreduce_max(amax[1:3])
+            for off8, rows8, r0, r1 in self._kv8_chunks:
+                blob = loc8[off8: off8 + rows8]
+                self.ops.attention_fp8_quantize_kv(kv_loc[r0:r1, :d], kv_loc[r0:r1, d:], H, amax, blob.view(-1))
+                full = full8[world * off8: world * (off8 + rows8)]
+                bufs.append((full, r1 - r0, amax))
+                handles.append(self.kv_gather.start(blob, full))
+            return handles, bufs
+        kv_full = self.kv_full if kv_full is None else kv_full
         for c in range(len(b) - 1):
             r0, r1 = b[c], b[c + 1]
             full = kv_full[world * r0: world * r1]
@@ -464,13 +503,21 @@ class WanDiT:
         ops = self.ops
         att = self.att if att is None else att
         C = len(bufs)
-        if self.attn8_ws is not None:
-            ops.attention_fp8_prepare(self.attn8_ws, H, q=q)            # queries once per layer, under the first transfer
+        wire = getattr(self, "fp8_wire", False)
+        ws = self.attn8_ws
+        if ws is not None:
+            if wire:
+                ws = ops.attention_fp8_with_amax(ws, bufs[0][2])     # this branch's abs-max table (queries' row written here)
+            ops.attention_fp8_prepare(ws, H, q=q)                       # queries once per layer, under the first transfer
         for c in range(C):
             self.kv_gather.wait(handles[c])
-            if self.attn8_ws is not None:
-                ops.attention_fp8_prepare(self.attn8_ws, H, k=bufs[c][0], v=bufs[c][1])
-                ops.attention_fp8_chunk(self.attn8_ws, q.shape[0], bufs[c][0].shape[0], att, self.sp_acc, self.sp_ml, H,
+            if wire:
+                full, m, amax = bufs[c]
+                ops.attention_fp8_pieces(ws, amax, full.view(-1), m, self.plan.world, q.shape[0], att, self.sp_acc, self.sp_ml, H,
+                                         first=(c == 0), last=(c == C - 1))
+            elif ws is not None:
+                ops.attention_fp8_prepare(ws, H, k=bufs[c][0], v=bufs[c][1])
+                ops.attention_fp8_chunk(ws, q.shape[0], bufs[c][0].shape[0], att, self.sp_acc, self.sp_ml, H,
                                         first=(c == 0), last=(c == C - 1))
             else:
                 ops.attention_chunk(q, bufs[c][0], bufs[c][1], att, self.sp_acc, self.sp_ml, H, scale,
@@ -717,6 +764,7 @@ class WanDiT:
                 t.ff8, t.ff8s = a((n2, cfg.ffn_dim), FP8), a((n2,), F32)
             if self.sp_on:      # both branches' K|V rows: local [2n, 2d] (cond rows, then uncond rows), gathered [2, world*n, 2d]
                 t.kv_loc = self._kv_rows(n2)
+                t.kv8 = [self._sp_wire_set(self._kv_rows, self.kv8[0].shape[0]) for _ in range(2)] if self.kv8 is not None else None
                 t.kv_full = a((2, self.plan.world * self.plan.n_tok, 2 * d), BF16)
             self._pair = t
         return self._pair
@@ -760,7 +808,7 @@ class WanDiT:
                     if r not in rows_list:
                         continue
                     ops.rmsnorm_rope(t.kv_loc[r][:, :d], lw["nk"], eps=eps, rope=self.rope, tok0=plan.tok0)   # K5 (k)
-                    pend.append((r,) + self._sp_start_gather(t.kv_loc[r], t.kv_full[bi]))                  # K13
+                    pend.append((r,) + self._sp_start_gather(t.kv_loc[r], t.kv_full[bi], t.kv8[bi] if t.kv8 is not None else None))   # K13
                 t._mm(h, lw["wqkv"], lw["bqkv"], q[rs], EPI_BF16, rows=slice(0, d))                       # K4 (q)
                 for r, handles, bufs in pend:
                     ops.rmsnorm_rope(q[r], lw["nq"], eps=eps, rope=self.rope, tok0=plan.tok0)             # K5 (q)

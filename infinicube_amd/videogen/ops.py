@@ -263,6 +263,36 @@ class HipOps:
             o.stride(0) if o is not None else 0, native.ptr(acc), acc.stride(0) if acc is not None else 0, native.ptr(ml),
             Sq, Skv, heads, int(first), int(last), self._stream()), "icv_attention_fp8_fwd_chunk")
 
+    # e4m3 K|V on the wire (sequence parallel): quantise the LOCAL rows once, exchange e4m3 blobs, attend over the pieces
+    def attention_fp8_blob_bytes(self, rows: int, heads: int) -> int:
+        return int(self.lib.icv_attention_fp8_blob_bytes(rows, heads))
+
+    def attention_fp8_kv_amax(self, k, v, heads: int, amax):
+        """amax f32 [3, H]: rows 1 / 2 <- per-head abs-max of this rank's k / v rows (row 0, the queries', is left alone)."""
+        _chk(k, BF16, "attention_fp8_kv_amax.k"); _chk(v, BF16, "attention_fp8_kv_amax.v"); _chk(amax, F32, "attention_fp8_kv_amax.amax")
+        native.check(self.lib.icv_attention_fp8_kv_amax(k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), k.shape[0], heads, amax.data_ptr(),
+                                                        self._stream()), "icv_attention_fp8_kv_amax")
+
+    def attention_fp8_quantize_kv(self, k, v, heads: int, amax, blob):
+        """rows of k / v -> one e4m3 blob (kq rows | transposed V tiles) with the per-head scales of ``amax``."""
+        assert blob.dtype == torch.uint8 and blob.is_contiguous() and blob.numel() >= self.attention_fp8_blob_bytes(k.shape[0], heads)
+        native.check(self.lib.icv_attention_fp8_quantize_kv(k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), k.shape[0], heads, amax.data_ptr(),
+                                                            blob.data_ptr(), self._stream()), "icv_attention_fp8_quantize_kv")
+
+    def attention_fp8_pieces(self, ws, amax, blobs, piece_rows: int, n_pieces: int, Sq: int, o, acc, ml, heads: int, first: bool, last: bool):
+        """fp8 attention of the prepared queries (ws) over ``n_pieces`` blobs back to back (the gathered chunk), carried state as
+        attention_chunk."""
+        qq = ws[0]
+        assert blobs.dtype == torch.uint8 and blobs.is_contiguous() and blobs.numel() >= n_pieces * self.attention_fp8_blob_bytes(piece_rows, heads)
+        native.check(self.lib.icv_attention_fp8_fwd_pieces(
+            qq.data_ptr(), qq.stride(0), blobs.data_ptr(), piece_rows, n_pieces, amax.data_ptr(), native.ptr(o), o.stride(0) if o is not None else 0,
+            native.ptr(acc), acc.stride(0) if acc is not None else 0, native.ptr(ml), Sq, heads, int(first), int(last), self._stream()),
+            "icv_attention_fp8_fwd_pieces")
+
+    def attention_fp8_with_amax(self, ws, amax):
+        """The same workspace with another abs-max table (one per CFG branch: the branches' K / V scales differ)."""
+        return (ws[0], ws[1], ws[2], amax)
+
     def attention_chunk(self, q, k, v, o, acc, ml, heads: int, scale: float, first: bool, last: bool):
         """Attention over one chunk of keys with carried softmax state (acc f32 [Sq, H*128], ml f32
         [Sq, H, 2]); ``first`` starts from the empty state, ``last`` normalises into ``o``."""

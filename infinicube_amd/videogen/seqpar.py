@@ -199,6 +199,12 @@ class KVGather:
         if self._heap is not None:
             self._heap.acquire()
 
+    def allreduce_max(self, t: torch.Tensor) -> None:
+        """In-place max over the ranks of the group (the e4m3 wire format's per-head K / V abs-max: 2 x heads floats per layer).
+        Stream-ordered on nccl groups (RCCL); a blocking host call on gloo groups."""
+        if self.plan.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+
     def close(self) -> None:
         if self._heap is not None:
             self._heap.close()

@@ -153,6 +153,42 @@ class OracleOps:
             acc.copy_(a_new.transpose(0, 1).reshape(Sq, d))
             ml[:, :, 0] = m_new.t(); ml[:, :, 1] = l_new.t()
 
+    # e4m3 K|V on the wire: the same three steps as HipOps (the blob layout is private to an operator set: here kq rows | vq rows)
+    def attention_fp8_blob_bytes(self, rows, heads):
+        return 2 * ((rows + 63) // 64 * 64) * heads * 128
+
+    def attention_fp8_kv_amax(self, k, v, heads, amax):
+        for row, x in ((1, k), (2, v)):
+            amax[row] = x.float().reshape(x.shape[0], heads, -1).abs().amax(dim=(0, 2))
+
+    @staticmethod
+    def _exp(amax_row):
+        return torch.where(amax_row > 0, torch.ceil(torch.log2(amax_row / R.FP8_MAX)), torch.zeros_like(amax_row))
+
+    def attention_fp8_quantize_kv(self, k, v, heads, amax, blob):
+        m, d = k.shape
+        mp = (m + 63) // 64 * 64
+        blob[: 2 * mp * d].zero_()
+        for part, (row, x) in enumerate(((1, k), (2, v))):
+            e = self._exp(amax[row])
+            q8 = (x.float().reshape(m, heads, -1) * torch.exp2(-e)[None, :, None]).to(FP8).reshape(m, d)
+            blob[part * mp * d: part * mp * d + m * d] = q8.view(torch.uint8).reshape(-1)
+
+    def attention_fp8_pieces(self, ws, amax, blobs, piece_rows, n_pieces, Sq, o, acc, ml, heads, first, last):
+        d = heads * 128
+        mp = (piece_rows + 63) // 64 * 64
+        ks, vs = [], []
+        for i in range(n_pieces):
+            b = blobs.reshape(-1)[i * 2 * mp * d: (i + 1) * 2 * mp * d]
+            for part, (row, dst) in enumerate(((1, ks), (2, vs))):
+                x8 = b[part * mp * d: part * mp * d + piece_rows * d].view(FP8).float().reshape(piece_rows, heads, -1)
+                dst.append((x8 * torch.exp2(self._exp(amax[row]))[None, :, None]).reshape(piece_rows, d))
+        tmp = dict(ws, k=torch.cat(ks, 0), v=torch.cat(vs, 0))
+        self.attention_fp8_chunk(tmp, Sq, n_pieces * piece_rows, o, acc, ml, heads, first, last)
+
+    def attention_fp8_with_amax(self, ws, amax):
+        return ws
+
     def attention_add(self, q, k, v, o, heads, scale):
         o.copy_((o.float() + R.attention(q.float(), k.float(), v.float(), heads, scale=scale)).to(BF16))
 

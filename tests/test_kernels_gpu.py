@@ -898,6 +898,64 @@ def test_attention_fp8(hip_ops, Sq, Skv, H):
         assert e3 <= 0.08, f"chunked fp8 attention vs unquantised: {e3:.4f}"
 
 
+@pytest.mark.parametrize("Sq,m,W,H", [(300, 128, 3, 2), (130, 100, 4, 2), (257, 37, 2, 1), (64, 585, 8, 1)])
+def test_attention_fp8_pieces_e4m3_on_the_wire(hip_ops, Sq, m, W, H):
+    """The e4m3 wire format of the sequence-parallel fp8 mode (icv_attention_fp8_kv_amax / _quantize_kv / _fwd_pieces): W ranks'
+    pieces of m keys each, every piece quantised on its own from its own rows with the GLOBAL per-head scales, consumed in place.
+    (a) the e4m3 K codes inside every blob are exactly the oracle's; (b) with m a multiple of 64 the tiles of the piece-wise launch
+    are the tiles of the unsharded launch in the same order, so the output is BIT-IDENTICAL to icv_attention_fp8_fwd on the
+    concatenated rows; (c) ragged pieces (padding keys masked) meet the fp8 bars against the oracle; (d) two chunks of pieces
+    with carried state agree with one."""
+    d, Skv = H * 128, m * W
+    fold = (1.0 / math.sqrt(128)) * math.log2(math.e)
+    q = rnd((Sq, d), 541).to(torch.bfloat16)
+    kf = rnd((Skv, d), 542)
+    kf[Skv - 1] = q[min(3, Sq - 1)].float() * 3.0
+    k = (kf * fold).to(torch.bfloat16)
+    v = (rnd((Skv, d), 543) * torch.linspace(0.5, 2.0, d)[None, :]).to(torch.bfloat16)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    ws = hip_ops.attention_fp8_buffers(Sq, Skv, d, H)
+    o_ref = torch.empty((Sq, d), dtype=torch.bfloat16, device=DEV)
+    hip_ops.attention_fp8(qd, kd, vd, o_ref, H, ws)                       # unsharded launch: also leaves the global abs-max in ws[3]
+    amax = torch.zeros((3, H), device=DEV)
+    hip_ops.attention_fp8_kv_amax(kd, vd, H, amax)
+    assert torch.equal(amax[1:], ws[3][1:]), "per-head abs-max of K / V differs from the prepare pass"
+    bb = hip_ops.attention_fp8_blob_bytes(m, H)
+    mp = (m + 63) // 64 * 64
+    assert bb == 2 * mp * d
+    blobs = torch.full((W * bb + 64,), 0xAB, dtype=torch.uint8, device=DEV)
+    for i in range(W):                                                     # "rank i" quantises its own rows
+        hip_ops.attention_fp8_quantize_kv(kd[i * m:(i + 1) * m], vd[i * m:(i + 1) * m], H, amax, blobs[i * bb:(i + 1) * bb])
+    assert bool((blobs[W * bb:] == 0xAB).all()), "wrote past the last blob"
+    e = torch.ceil(torch.log2(amax[1].cpu() / 448.0))
+    kq_ref = (k.float().reshape(Skv, H, 128) * torch.exp2(-e)[None, :, None]).to(torch.float8_e4m3fn).reshape(Skv, d).view(torch.uint8)
+    for i in range(W):
+        got_codes = blobs[i * bb: i * bb + m * d].cpu().reshape(m, d)
+        assert torch.equal(got_codes, kq_ref[i * m:(i + 1) * m]), f"piece {i}: K e4m3 codes differ from the oracle"
+    ws2 = hip_ops.attention_fp8_with_amax(ws, amax)
+    hip_ops.attention_fp8_prepare(ws2, H, q=qd)
+    o = torch.full((Sq + 2, d), 9.0, dtype=torch.bfloat16, device=DEV)
+    hip_ops.attention_fp8_pieces(ws2, amax, blobs[: W * bb], m, W, Sq, o[:Sq], None, None, H, first=True, last=True)
+    assert bool((o[Sq:] == 9.0).all()), "wrote past the last query row"
+    got = o[:Sq].float().cpu()
+    assert torch.isfinite(got).all()
+    if m % 64 == 0:
+        assert torch.equal(o[:Sq], o_ref), "tile-aligned pieces must reproduce the unsharded launch bit for bit"
+    ref8 = R.attention_fp8(q.float(), k.float(), v.float(), H)
+    ref = R.attention(q.float(), k.float(), v.float(), H, scale=math.log(2.0))
+    rms = float(ref.pow(2).mean().sqrt())
+    e8 = float((got - ref8).pow(2).mean().sqrt()) / rms
+    e0 = float((got - ref).pow(2).mean().sqrt()) / rms
+    assert e8 <= 0.03 and e0 <= 0.08, f"fp8 pieces Sq={Sq} m={m} W={W}: rms err vs fp8 oracle {e8:.4f}, vs unquantised {e0:.4f}"
+    if W >= 2:      # two chunks of pieces (the first W-1 pieces, then the last one) with carried state
+        acc = torch.empty((Sq, d), device=DEV); ml = torch.empty((Sq, H, 2), device=DEV)
+        o3 = torch.zeros((Sq, d), dtype=torch.bfloat16, device=DEV)
+        hip_ops.attention_fp8_pieces(ws2, amax, blobs[: (W - 1) * bb], m, W - 1, Sq, None, acc, ml, H, first=True, last=False)
+        hip_ops.attention_fp8_pieces(ws2, amax, blobs[(W - 1) * bb: W * bb], m, 1, Sq, o3, acc, ml, H, first=False, last=True)
+        e3 = float((o3.float().cpu() - got).pow(2).mean().sqrt()) / rms
+        assert e3 <= 0.02, f"two chunks of pieces vs one: {e3:.4f}"
+
+
 @pytest.mark.parametrize("Sq,Skv,H", [(300, 257, 2), (1, 1, 1), (513, 64, 3)])
 def test_attention_add_into_output(hip_ops, Sq, Skv, H):
     """icv_attention_fwd_add: o += softmax(q k^T) v (the i2v image cross-attention; 257 = CLIP tokens)."""
