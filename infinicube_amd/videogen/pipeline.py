@@ -246,7 +246,12 @@ class WanVideoPipeline:
         # multi-GPU layout when torch.distributed is initialised (seqpar.ParallelLayout): "auto" | "sp" | "cfg+sp"
         self.parallelism = os.environ.get("ICV_PARALLELISM", "auto")
         self.sp_chunks = int(os.environ.get("ICV_SP_CHUNKS", "4"))       # K/V exchange chunks per layer (overlap depth)
-        self.kv_exchange = os.environ.get("ICV_KV_EXCHANGE") or None     # "allgather" | "p2p" (seqpar.KVGather)
+        # K|V transport of the sequence-parallel path (seqpar.KVGather): "allgather" | "p2p" | "native" | "ipc", or "auto" = a
+        # start-up autotune on the first call (seqpar.autotune_kv_exchange: two real layers per candidate, the ranks agree on
+        # the fastest; cached per layout).  Unset: "auto" on RCCL ranks (what the transports cost on a given node is not
+        # known before first contact), "allgather" elsewhere (gloo: CPU tests, ranks sharing one GPU).
+        self.kv_exchange = os.environ.get("ICV_KV_EXCHANGE") or None
+        self._kv_tuned = {}
         self._layouts = {}
         self.torch_dtype = torch_dtype
         self.dit = dit
@@ -345,6 +350,38 @@ class WanVideoPipeline:
             self._engine_key = key
         return self._engine
 
+    def _autotune_kv(self, engine, latent, ctx, buf_tokens, ops):
+        """First sequence-parallel call of this layout: time every K|V transport x {sp_chunks, 2} chunks on two real layers of
+        THIS generation's shard and keep the fastest (every rank runs this at the same point and ends with the same choice)."""
+        import sys
+        import time
+        import torch.distributed as dist
+        from .seqpar import autotune_kv_exchange
+        on_dev = dist.get_backend() == "nccl"
+
+        def sync():
+            if torch.device(ops.device).type == "cuda":
+                torch.cuda.synchronize(ops.device)
+            dist.barrier()
+
+        def reduce_max(vals):
+            t = torch.tensor(vals, dtype=torch.float64, device=ops.device if on_dev else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return t.tolist()
+
+        def two_layers():
+            engine.forward_tokens(latent, ctx, 500.0, buf_tokens, engine.head_own, num_layers=min(2, engine.cfg.num_layers))
+
+        modes = ("allgather", "p2p", "native", "ipc") if on_dev else ("allgather", "p2p")
+        cands = [(m, c) for m in modes for c in sorted({self.sp_chunks, 2}, reverse=True)]
+        t0 = time.perf_counter()
+        best, table = autotune_kv_exchange(engine, two_layers, sync, cands, reps=2, reduce_max=reduce_max)
+        self.kv_autotune = dict(chosen=best, table=table, seconds=time.perf_counter() - t0)
+        if dist.get_rank() == 0 and os.environ.get("ICV_QUIET", "0") != "1":
+            print(f"[icv] K|V exchange autotune: {best[0]} x {best[1]} chunks ({self.kv_autotune['seconds']:.1f} s; "
+                  + ", ".join(f"{r['kv_exchange']}/{r['sp_chunks']}: " + (f"{r['ms']:.2f} ms" if r['ms'] else 'n/a') for r in table) + ")", file=sys.stderr, flush=True)
+        return best
+
     def _image_cond_latents(self, image, grid: TokenGrid, tiled, tile_size, tile_stride) -> torch.Tensor:
         """i2v conditioning latent y [4 + 16, T, H/8, W/8] ([EXT] Wan2.1 / diffsynth ``encode_image``): the
         VAE encoding of [image, 0, 0, ...] under a 4-channel mask that marks the first latent frame."""
@@ -393,7 +430,15 @@ class WanVideoPipeline:
             layouts[lkey] = ParallelLayout.make(world, rank, self.parallelism, use_cfg=cfg_scale != 1.0)
         layout = layouts[lkey]
         plan = layout.shard_plan(grid.S)
-        engine.prepare(grid, plan, group=layout.sp_group, sp_chunks=self.sp_chunks, kv_exchange=self.kv_exchange)
+        kv_exchange, sp_chunks = self.kv_exchange, self.sp_chunks
+        tune_key = None
+        if layout.sp_world > 1:
+            if kv_exchange is None:
+                kv_exchange = "auto" if dist.get_backend() == "nccl" else "allgather"
+            if kv_exchange == "auto":
+                tune_key = (lkey, grid.S)
+                kv_exchange, sp_chunks = self._kv_tuned.get(tune_key, ("allgather", sp_chunks))
+        engine.prepare(grid, plan, group=layout.sp_group, sp_chunks=sp_chunks, kv_exchange=kv_exchange if layout.sp_world > 1 else None)
         self.scheduler = FlowMatchScheduler(num_inference_steps, sigma_shift, self.reference_rounding)
         # i2v (BASELINE.json config #5): CLIP tokens + conditioning latent of the first frame, once per call
         i2v = engine.cfg.has_image_input
@@ -447,6 +492,8 @@ class WanVideoPipeline:
         if i2v:
             y = self._image_cond_latents(input_image, grid, tiled, tile_size, tile_stride)
             buf_tokens = engine.embed_cond_latents(y, add_to=buf_tokens)
+        if tune_key is not None and tune_key not in self._kv_tuned:
+            self._kv_tuned[tune_key] = self._autotune_kv(engine, latent, ctx_c if ctx_c is not None else ctx_u, buf_tokens, ops)
         # the hot loop (HIP)
         it = range(num_inference_steps)
         if progress_bar_cmd is not None:
