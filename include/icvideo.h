@@ -179,6 +179,11 @@ int icv_attention_fp8_fwd_pieces(const void* qq, int64_t ldqq, const void* blobs
                                  const float* amax, void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml, int64_t Sq,
                                  int64_t heads, int first, int last, void* stream);
 
+/* Diagnostics: buf = device u64 [capacity][4] (NULL = off).  While set, every work-group b < capacity of the following
+ * icv_attention_fwd / _fwd_chunk launches (attn7 kernel) writes {start, end in 100 MHz s_memrealtime ticks, HW_ID, XCC_ID}
+ * to buf[b]: the round structure of a launch and its work-group -> XCD placement (tools/attn_round_trace.py). */
+int icv_attention_trace(void* buf, int64_t capacity);
+
 /* ---- K6 split along the KEY axis (K13 overlap): attention over one chunk of keys with a carried
  * online-softmax state, so the sequence-parallel path can consume K/V chunks as the RCCL all-gather
  * delivers them.  State = acc f32 [Sq, H*128] (ldacc; un-normalised O) + ml f32 [Sq, H, 2] (running

@@ -106,3 +106,22 @@ extern "C" int icv_attention_fwd_add(const void* q, int64_t ldq, const void* k, 
   ICV_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "icv_attention_fwd_add: leading dims must keep 16-byte row alignment");
   return attn_route(q, ldq, k, ldk, v, ldv, o, ldo, nullptr, 0, nullptr, 0, 2, Sq, Skv, heads, scale, (hipStream_t)stream);
 }
+
+// ---- diagnostics: where and when every work-group of the NEXT attn7 launches runs -----------------------------------------
+// icv_attention_trace(buf, capacity): buf = device u64 [capacity][4] (NULL switches tracing off).  While set, every attn7
+// work-group b < capacity writes buf[b] = {start, end (s_memrealtime ticks, 100 MHz), HW_ID, XCC_ID} - the round structure and
+// the work-group -> XCD placement of a launch (tools/attn_round_trace.py; profiles/r05/attn_round_occupancy.md).
+namespace {
+unsigned long long* g_trace = nullptr;
+int g_trace_cap = 0;
+}  // namespace
+unsigned long long* icv_attention_trace_buffer(int* capacity) {
+  *capacity = g_trace_cap;
+  return g_trace;
+}
+extern "C" int icv_attention_trace(void* buf, int64_t capacity) {
+  ICV_REQUIRE(capacity >= 0 && capacity < (1LL << 31), "icv_attention_trace: bad capacity");
+  g_trace = (unsigned long long*)buf;
+  g_trace_cap = buf ? (int)capacity : 0;
+  return 0;
+}

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
   int head, qb;
   attc::work_item(p, head, qb);
   const int64_t q0 = (int64_t)qb * QB + wave * 32;
+  const unsigned long long t_start = p.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
   const bf16_t* qh = p.q + (int64_t)head * D;
   const bf16_t* kh = p.k + (int64_t)head * D;
@@ -361,6 +362,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
   if (grp == 0 && STAGGER) A7_BARRIER();             // re-balance the stagger
 
   attc::store_result(p, q0 + l31, head, hi, ot, m_run, l_run);
+  if (p.trace && tid == 0 && (int)blockIdx.x < p.trace_cap) {      // diagnostics: where and when did this work-group run
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* t = p.trace + (size_t)blockIdx.x * 4;
+    t[0] = t_start; t[1] = __builtin_amdgcn_s_memrealtime(); t[2] = hwid; t[3] = xcc;
+  }
 }
 
 template <int VAR, int NW = 8, int NST = 4>
@@ -388,6 +396,7 @@ int icv_attn7_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, c
   attc::fill_params(p, q, ldq, k, ldk, v, ldv, o, ldo, acc, ldacc, ml, state_in, state_out, Sq, Skv, heads, scale, short_kv ? 128 : 256);
   if (p.sc == 1.0f && icv_get_option_int("attn_unit_scale", 1)) var |= 16;
   p.ablate = icv_get_option_int("attn7_ablate", 0);   // timing experiments only (tools/attn_bench.py)
+  p.trace = icv_attention_trace_buffer(&p.trace_cap);
   if (short_kv) return (var & 16) ? att7::launch<16, 4, 2>(p, st) : att7::launch<0, 4, 2>(p, st);
   switch (var) {
     case 0: return att7::launch<0>(p, st);

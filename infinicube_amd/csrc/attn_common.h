@@ -7,6 +7,8 @@
 #pragma once
 #include "icv_common.h"
 
+unsigned long long* icv_attention_trace_buffer(int* capacity);   // attention.hip (icv_attention_trace)
+
 namespace attc {
 
 constexpr int D = 128;
@@ -25,7 +27,11 @@ struct Params {
   float sc;   // scale * log2(e)
   float thr;  // defer-max threshold, log2 units
   int ablate; // timing ablations (attn7: 1 = no K/V DMA after the prologue, 2 = no per-tile barrier); results are then WRONG
+  // diagnostics (icv_attention_trace; attn7 only): per work-group {start, end} in 100 MHz s_memrealtime ticks, HW_ID, XCC_ID
+  unsigned long long* trace;
+  int trace_cap;
 };
+
 
 inline void fill_params(Params& p, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
                         int64_t ldv, void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml, int state_in,
@@ -39,6 +45,8 @@ inline void fill_params(Params& p, const void* q, int64_t ldq, const void* k, in
   if (fabsf(p.sc - 1.0f) < 1e-6f) p.sc = 1.0f;   // "unit scale": the caller folded scale * log2(e) into K (scale = ln 2)
   p.thr = (float)icv_get_option_int("attn_defer_max_log2", 8);
   p.ablate = 0;
+  p.trace = nullptr;
+  p.trace_cap = 0;
 }
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;

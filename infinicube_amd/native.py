@@ -47,6 +47,7 @@ SIGNATURES = {
     "icv_attention_fp8_kv_amax": (c_int, [_P, _I, _P, _I, _I, _I, _P, _P]),
     "icv_attention_fp8_quantize_kv": (c_int, [_P, _I, _P, _I, _I, _I, _P, _P, _P]),
     "icv_attention_fp8_fwd_pieces": (c_int, [_P, _I, _P, _I, _I, _P, _P, _I, _P, _I, _P, _I, _I, c_int, c_int, _P]),
+    "icv_attention_trace": (c_int, [_P, _I]),
     "icv_attention_fwd_chunk": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _F, c_int, c_int, _P]),
     "icv_patchify": (c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
     "icv_unpatchify_cfg_euler": (c_int, [_P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _I, _I, c_int, _P]),

@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from infinicube_amd.videogen import synthetic as syn
-from infinicube_amd.videogen.config import GRID_480P, preset
+from infinicube_amd.videogen.config import GRID_480P, GRID_720P, preset
 from infinicube_amd.videogen.dit import WanDiT
 from infinicube_amd.videogen.ops import HipOps
 from infinicube_amd.videogen.seqpar import ShardPlan
@@ -34,8 +34,10 @@ from infinicube_amd.videogen.seqpar import ShardPlan
 DEV = "cuda:0"
 LAYERS = int(os.environ.get("LAYERS", "4"))
 ops = HipOps(DEV)
-cfg_full = preset("14b")
-cfg, grid = dataclasses.replace(cfg_full, num_layers=LAYERS), GRID_480P
+# MODEL=14b|14b-i2v  GRID=480p|720p  GEMM=bf16|fp8  ATTN=bf16|fp8 (with ICV_FP8_WIRE=e4m3|bf16: what travels in the fp8 mode)
+MODEL, GEMM, ATTN = os.environ.get("MODEL", "14b"), os.environ.get("GEMM", "bf16"), os.environ.get("ATTN", "bf16")
+cfg_full = preset(MODEL)
+cfg, grid = dataclasses.replace(cfg_full, num_layers=LAYERS), (GRID_720P if os.environ.get("GRID", "480p") == "720p" else GRID_480P)
 sd = syn.make_dit_state_dict(cfg, seed=0, device=DEV, dtype=torch.bfloat16)
 bsd = syn.make_buffer_embedder_state_dict(cfg, device=DEV, dtype=torch.bfloat16)
 noise, ctx, bl = syn.make_latent_noise(grid).to(DEV), syn.make_text_context(cfg, 1), syn.make_buffer_latents(cfg, grid)
@@ -55,10 +57,17 @@ class ServedGather:
         self.side = torch.cuda.Stream()
         self.filled = set()
 
+    def allreduce_max(self, t):           # e4m3 wire format: the abs-max exchange (2 x heads floats) - nothing to time on one rank
+        pass
+
     def start(self, rows, out):
         m = rows.shape[0]
         if out.data_ptr() not in self.filled:            # first use of this slice of the gathered buffer: the peers' rows
-            out.copy_(peers[: out.shape[0]])
+            if rows.dtype == torch.uint8:                # e4m3 blobs: every "peer" piece = a copy of this rank's valid blob
+                for j in range(out.shape[0] // m):
+                    out[j * m:(j + 1) * m].copy_(rows)
+            else:
+                out.copy_(peers[: out.shape[0]])
             self.filled.add(out.data_ptr())
         ready = torch.cuda.Event()
         ready.record()
@@ -78,9 +87,13 @@ def time_forward(world, chunks, iters=3, pair=False):
     """ms per layer of ONE forward on the shard (pair=False), or of BOTH CFG forwards issued as WanDiT.forward_pair (pair=True:
     what a rank of the `sp` layout runs per step - projections over 2n rows, exchange + attention per branch)."""
     plan = ShardPlan.make(grid.S, world, 0)
-    m = WanDiT(cfg, sd, ops, bsd).prepare(grid, plan, kv_gather=ServedGather(world) if world > 1 else None, sp_chunks=chunks, graphs=False)
-    ck, bt = m.encode_context(ctx), m.embed_buffers(bl)
-    cu = m.encode_context(ctx2) if pair else None
+    m = WanDiT(cfg, sd, ops, bsd, gemm_dtype=GEMM, attn_dtype=ATTN).prepare(grid, plan, kv_gather=ServedGather(world) if world > 1 else None,
+                                                                           sp_chunks=chunks, graphs=False)
+    clip = syn.make_clip_features(cfg) if cfg.has_image_input else None
+    ck, bt = m.encode_context(ctx, clip), m.embed_buffers(bl)
+    if cfg.has_image_input:
+        bt = m.embed_cond_latents(syn.make_cond_latents(cfg, grid), add_to=bt)
+    cu = m.encode_context(ctx2, clip) if pair else None
 
     def run():
         if pair:
@@ -106,7 +119,7 @@ ONLY = os.environ.get("ONLY")          # "world:chunks[:pair]" -> time just that
 if ONLY:
     w, c, *rest = ONLY.split(":")
     t = time_forward(int(w), int(c), iters=int(os.environ.get("ITERS", "3")), pair=bool(rest))
-    print(f"shard 1/{w} chunks {c}{' pair' if rest else ''}: {t:.3f} ms per layer")
+    print(f"{MODEL} S={grid.S} gemm {GEMM} attn {ATTN} wire {os.environ.get('ICV_FP8_WIRE', 'e4m3') if ATTN == 'fp8' else 'bf16'}: shard 1/{w} chunks {c}{' pair' if rest else ''}: {t:.3f} ms per layer")
     sys.exit(0)
 L = cfg_full.num_layers
 # one GPU: the product's default step = the CFG-batched pair (bench.py's `cfg_forwards_batched`)
@@ -127,4 +140,4 @@ for n_gpus, layout, world, pair in ((2, "cfg+sp", 1, False), (4, "cfg+sp", 2, Fa
         print(f"N = {n_gpus} {layout:14s} shard 1/{world} chunks {chunks}: {t:6.2f} ms per layer per step -> {step:7.1f} ms per step, "
               f"{1e3 / step:.3f} steps/s, x{one_gpu_step / step:.2f} of one GPU (compute only, exchange fully hidden)")
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(dict(model="wan2.1-t2v-14b", S=grid.S, layers_timed=LAYERS, one_gpu_ms_per_step=one_gpu_step, rows=rows), open("gpurun_out/sp_compute_only_projection.json", "w"), indent=1)
+json.dump(dict(model=cfg_full.name, gemm=GEMM, attn=ATTN, S=grid.S, layers_timed=LAYERS, one_gpu_ms_per_step=one_gpu_step, rows=rows), open("gpurun_out/sp_compute_only_projection.json", "w"), indent=1)
