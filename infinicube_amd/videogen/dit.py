@@ -434,10 +434,24 @@ class WanDiT:
             if nc is None:     # the Python driver's exchange runs in torch.distributed: the C driver brings its own communicator
                 nc = _NativeComm.for_group(getattr(kg, "dist", None), kg.group, kg.peers, plan.rank, plan.world)
             self._native_comm = nc                      # keep it (and its side stream) alive as long as the context
+            nc.add_dependent(self)                      # ... and let it take the context down with it (_NativeComm.close)
             for name in ("kv_loc", "kv_full", "sp_acc", "sp_ml"):
                 bind(name, getattr(self, name))
             b = (ctypes.c_int64 * len(self.sp_bounds))(*self.sp_bounds)
             native.check(lib.icv_dit_set_seqpar(h, nc.handle, plan.world, len(self.sp_bounds) - 1, b, nc.stream.cuda_stream), "icv_dit_set_seqpar")
+
+    def _drop_native_context(self):
+        """The communicator the C driver's context points at is going away (seqpar._NativeComm.close): destroy the context; the
+        next native forward rebuilds it against a live communicator or fails in icv_comm_create, never in a freed handle."""
+        h, self._native = getattr(self, "_native", None), None
+        self._native_comm = None
+        if h is not None:
+            try:
+                if self._is_gpu():
+                    torch.cuda.synchronize(self.ops.device)
+                self.ops.lib.icv_dit_destroy(h)
+            except Exception:  # pragma: no cover - interpreter shutdown
+                pass
 
     def _native_eligible(self) -> bool:
         return self.native_forward and self._is_gpu() and hasattr(self.ops, "lib") and (not self.sp_on or isinstance(self.kv_gather, KVGather))

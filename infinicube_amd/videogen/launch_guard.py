@@ -68,7 +68,9 @@ class PhaseReporter:
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else rank
         self.current = "start"
         self._inject = []
-        for item in filter(None, os.environ.get("ICV_GUARD_INJECT", "").split(",")):
+        # failure injection: honoured only when the test harness also sets ICV_TEST_HOOKS=1
+        inject = os.environ.get("ICV_GUARD_INJECT", "") if os.environ.get("ICV_TEST_HOOKS") == "1" else ""
+        for item in filter(None, inject.split(",")):
             a, r, ph, kind = item.split(":")
             self._inject.append((int(a), int(r), ph, kind))
 
@@ -202,6 +204,8 @@ class Supervisor:
     def _run_attempt(self, k: int, att: Attempt) -> Optional[dict]:
         """None = every rank finished; otherwise the failure record (shared by all supervisors)."""
         if self.rank == 0:
+            # the port is free NOW; the worker binds it a moment later.  A collision shows up as a failed rendezvous of this
+            # attempt (phase "init"), which the ladder treats like any other failure and retries on a fresh port
             self.store.set(f"port{k}", str(_free_port()))
         port = self.store.get(f"port{k}").decode()
         phase_file = os.path.join(self.dir, f"phase{k}.txt")
@@ -241,14 +245,35 @@ class Supervisor:
             time.sleep(0.2)
         if not failed:
             self.store.set(f"done{k}_{self.rank}", "1")
-            # the slowest rank may still be in its last phase: give it that phase's budget
-            state = self._wait_all(f"done{k}_", self.budgets.get("report", FALLBACK_BUDGET_S) * self.scale + 60.0, abort_key=f"fail{k}")
-            if state == "ok":
-                logf.close()
-                sys.stderr.write(_tail(log_file, 4000))
-                return None
-            if state == "timeout":
-                self._fail(k, "report", "not every rank reported completion")
+        # ONE verdict per attempt, decided by rank 0's supervisor alone and published through the store: every supervisor follows it,
+        # so a rank that finished long before the slowest cannot time the others out on its own clock, and no rank can read "ok"
+        # while another has moved on to the next attempt.
+        report_budget = self.budgets.get("report", FALLBACK_BUDGET_S) * self.scale + 60.0
+        if self.rank == 0:
+            if failed:
+                verdict = "fail"
+            else:
+                # every other rank either reports completion or publishes fail{k}; the slowest may still be in its last phase
+                state = self._wait_all(f"done{k}_", report_budget, abort_key=f"fail{k}")
+                if state == "timeout":
+                    self._fail(k, "report", "not every rank reported completion")
+                verdict = "ok" if state == "ok" else "fail"
+            self.store.set(f"verdict{k}", verdict)
+        else:
+            # rank 0 decides; it publishes within its own worker's phase budgets + the report budget (a dead rank 0 = the store is
+            # gone: the get raises, which ends this supervisor too)
+            t_end = time.time() + max(self.budgets.values()) * self.scale + report_budget + 120.0
+            while not self._has(f"verdict{k}") and time.time() < t_end:
+                if self.proc.poll() is not None and self.proc.returncode != 0 and not self._has(f"fail{k}"):
+                    self._fail(k, (_last_phase(phase_file) or ("?",))[0], f"worker exited with code {self.proc.returncode}: {_tail(log_file)}")
+                time.sleep(0.1)
+            verdict = self.store.get(f"verdict{k}").decode() if self._has(f"verdict{k}") else "fail"
+            if verdict != "ok" and not self._has(f"fail{k}"):
+                self._fail(k, "report", "rank 0 published no verdict for this attempt")
+        if verdict == "ok":
+            logf.close()
+            sys.stderr.write(_tail(log_file, 4000))
+            return None
         self.log(f"attempt {k}: stopping the worker (last phase '{(_last_phase(phase_file) or ('?',))[0]}')")
         _kill_group(self.proc)
         self.log(f"attempt {k}: worker gone")

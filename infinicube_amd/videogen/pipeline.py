@@ -502,6 +502,12 @@ class WanVideoPipeline:
                        branch_exchange=BranchExchange(layout) if layout.mode == "cfg+sp" else None,
                        round_bf16=self.reference_rounding)
         latent = gather_latent(latent, plan, grid, group=layout.sp_group)
+        # The DECODE is sharded (a collective of every rank: vae.TileShard broadcasts the tiles) only where every rank is known to
+        # take part: behind a multigpu.WorkerPool (its workers pass join_decode=True) or when the caller says so
+        # (ICV_VAE_SHARD_DECODE=1: every rank calls the pipeline with return_latents=False, or with join_decode=True).  A
+        # torchrun-style script that decodes on rank 0 only and asks the other ranks for latents gets the unsharded decode.
+        if multigpu.layout_cache() is None and os.environ.get("ICV_VAE_SHARD_DECODE", "0") != "1":
+            vshard = {}
         if return_latents:
             if join_decode and vshard.get("shard") is not None:
                 # a worker rank of multigpu.WorkerPool: it needs no frames, but its share of the decode tiles is part of

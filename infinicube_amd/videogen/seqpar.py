@@ -294,6 +294,14 @@ class _NativeComm:
         native.check(self.lib.icv_comm_create(bytes(t.cpu().tolist()), rank, world, ctypes.byref(h)), "icv_comm_create")
         self.handle = h
         self.stream = torch.cuda.Stream(device=dev)
+        self._dependents = []          # weak references to engines whose C driver context holds this handle (WanDiT._native)
+
+    def add_dependent(self, engine) -> None:
+        """An engine whose icv_dit context was given this communicator's raw handle and side stream (icv_dit_set_seqpar):
+        ``close()`` destroys that context first, so a later native forward rebuilds it (or fails cleanly) instead of
+        dereferencing a freed communicator."""
+        import weakref
+        self._dependents.append(weakref.ref(engine))
 
     def allgather(self, rows: torch.Tensor, out: torch.Tensor):
         ready = torch.cuda.Event()
@@ -308,6 +316,11 @@ class _NativeComm:
     def close(self):
         """Drain the side stream, then destroy the communicator (queued transfers must not outlive it)."""
         h, self.handle = getattr(self, "handle", None), None
+        for ref in getattr(self, "_dependents", []):
+            eng = ref()
+            if eng is not None and getattr(eng, "_native_comm", None) is self:
+                eng._drop_native_context()
+        self._dependents = []
         if h is not None:
             try:
                 self.stream.synchronize()

@@ -40,6 +40,7 @@ def _free_port():
 
 
 def _launch(world, extra_env, plans=PLANS, timeout=240):
+    extra_env = dict(extra_env, ICV_TEST_HOOKS="1")
     port = _free_port()
     procs = []
     for r in range(world):

@@ -265,7 +265,7 @@ def test_bench_falls_back_and_says_so(inject, plan_prefix, n_failed):
     cmd = [sys.executable, "bench.py", "--gpus", "4", "--model", "tiny", "--frames", "9", "--height", "128", "--width", "160", "--steps", "1",
            "--warmup", "1", "--no-cpu-baseline"]      # tiny: the last plan is plain `sp` over gloo with device tensors - seconds per all-gather
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    env.update(ICV_BENCH_SHARE_GPU="1", ICV_DIST_BACKEND="gloo", ICV_GUARD_INJECT=inject, ICV_BENCH_DIST_TIMEOUT_S="40",
+    env.update(ICV_BENCH_SHARE_GPU="1", ICV_DIST_BACKEND="gloo", ICV_GUARD_INJECT=inject, ICV_TEST_HOOKS="1", ICV_BENCH_DIST_TIMEOUT_S="40",
                ICV_GUARD_BUDGETS="autotune=12,warmup=400,timed=400" if "hang" in inject else "autotune=400,warmup=400,timed=400")
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]

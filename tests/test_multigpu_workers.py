@@ -156,6 +156,7 @@ def test_pool_start_falls_back_plan_by_plan(tmp_path, monkeypatch, capfd, inject
     monkeypatch.setenv("ICV_WORLD_TIMEOUT_S", "300")
     monkeypatch.setenv("ICV_WORLD_PROBE_TIMEOUT_S", "8")
     monkeypatch.setenv("ICV_TEST_POOL_INJECT", inject)
+    monkeypatch.setenv("ICV_TEST_HOOKS", "1")
     monkeypatch.setenv("PYTHONPATH", os.pathsep.join([os.path.dirname(HERE), HERE, os.environ.get("PYTHONPATH", "")]))
     g = None
     try:
