@@ -77,11 +77,20 @@ def analyse(tr, ms, nwg, label):
     # the tail: from the moment the last work-group has STARTED (no more work to hand out) to the end
     tail = span - float(st.max())
     xcc = tr[:, 3] & 0xF
-    placed = float((xcc == (torch.arange(nwg) % 8)).double().mean())
+    # the dispatcher deals work-groups to the XCDs round-robin but continues where the previous launch stopped: the map the kernel
+    # relies on is "b mod 8 -> ONE physical XCD" (any fixed rotation), so measure the share of the most common (xcc - b) mod 8
+    rot = (xcc - torch.arange(nwg)) % 8
+    placed = float(torch.bincount(rot, minlength=8).max()) / nwg
     per_xcd = [int((xcc == i).sum()) for i in range(8)]
+    # per-XCD finish time and mean work-group duration: does ONE XCD lag (a CU short) or all of them (a global effect)?
+    xcd_end = [float(en[xcc == i].max()) if per_xcd[i] else 0.0 for i in range(8)]
+    xcd_dur = [float(dur[xcc == i].mean()) if per_xcd[i] else 0.0 for i in range(8)]
+    cus = tr[:, 2] & 0xFFFF          # HW_ID low bits (wave / simd / cu / sh / se ids): distinct values ~ distinct (se, sh, cu, simd, wave) slots
+    n_slots = int(torch.unique(torch.stack([xcc, (tr[:, 2] >> 8) & 0xF, (tr[:, 2] >> 12) & 0x1, (tr[:, 2] >> 13) & 0x7], 1), dim=0).shape[0])
     ideal = busy_area / 256.0
     return dict(label=label, nwg=nwg, rounds=nwg / 256.0, launch_us=ms * 1e3, span_us=span, mean_wg_us=float(dur.mean()), p95_wg_us=float(dur.quantile(0.95)),
-                busy_cu_equiv=busy_area / span, ideal_us=ideal, tail_us=tail, placed=placed, per_xcd=per_xcd, peak=peak)
+                busy_cu_equiv=busy_area / span, ideal_us=ideal, tail_us=tail, placed=placed, per_xcd=per_xcd, peak=peak,
+                xcd_end=xcd_end, xcd_dur=xcd_dur, n_cus=n_slots)
 
 
 rows = []
@@ -89,10 +98,10 @@ for n, what in ((37440, "full S (1 GPU)"), (9360, "1/4 shard (cfg2 x sp4)"), (46
     for co, cname in ((None, "alone"), ((1, 0), "+ 1 light copy work-group"), ((1, 65536), "+ 1 copy work-group holding 64 KiB LDS")):
         tr, ms, nwg = traced_launch(n, co)
         rows.append(analyse(tr, ms, nwg, f"n = {n} {what}, {cname}"))
-print("| launch | work-groups (rounds of 256 CUs) | launch | mean / p95 work-group | CUs busy (time average) | perfectly packed | tail after the last work-group started | work-group b on XCD b mod 8 | work-groups per XCD |")
-print("|---|---|---|---|---|---|---|---|---|")
+print("| launch | work-groups (rounds of 256 CUs) | launch | mean / p95 work-group | CUs busy (time average) | perfectly packed | tail after the last work-group started | b mod 8 -> one XCD (any rotation) | distinct CUs used | per-XCD finish (us) | per-XCD mean work-group (us) |")
+print("|---|---|---|---|---|---|---|---|---|---|---|")
 for r in rows:
     fl = 4.0 * (r["nwg"] // 40 * 256) * 0  # (flops are in DESIGN.md; this table is about occupancy)
     print(f"| {r['label']} | {r['nwg']} ({r['rounds']:.2f}) | {r['launch_us'] / 1e3:.3f} ms | {r['mean_wg_us']:.0f} / {r['p95_wg_us']:.0f} us | {r['busy_cu_equiv']:.1f} of 256 "
           f"| {r['ideal_us'] / 1e3:.3f} ms ({100 * r['ideal_us'] / r['span_us']:.1f} % of the span) | {r['tail_us']:.0f} us ({100 * r['tail_us'] / r['span_us']:.1f} %) "
-          f"| {100 * r['placed']:.1f} % | {min(r['per_xcd'])}-{max(r['per_xcd'])} |")
+          f"| {100 * r['placed']:.1f} % | {r['n_cus']} | {' '.join(f'{x:.0f}' for x in r['xcd_end'])} | {' '.join(f'{x:.0f}' for x in r['xcd_dur'])} |")
