@@ -508,9 +508,9 @@ def test_configs_2_and_3_at_50_steps(hip_ops, model, need):
     pipeline's default, which the reference never overrides [R infinicube/videogen/inference.py:216-226]), bf16 product and
     the e4m3 mode against the fp32 oracle loop run by stock PyTorch on the GPU.  Bars: latent and decoded-frame PSNR >= 40 dB.
     Opt-in (the oracle's 100 forwards take ~10 GPU-minutes for 1.3B, ~50 for 14B): ICV_SLOW_TESTS=1 runs 1.3B, =2 both;
-    recorded in profiles/r03/parity_config{2,3}_50_steps.txt."""
+    recorded in profiles/r05/parity_config{2,3}_50_steps.txt."""
     if SLOW < need:
-        pytest.skip(f"50 oracle steps at S = 37 440 for Wan2.1-{model}: run with ICV_SLOW_TESTS={need} (recorded in profiles/r03/parity_config{2 if model == '1.3b' else 3}_50_steps.txt)")
+        pytest.skip(f"50 oracle steps at S = 37 440 for Wan2.1-{model}: run with ICV_SLOW_TESTS={need} (recorded in profiles/r05/parity_config{2 if model == '1.3b' else 3}_50_steps.txt)")
     from standins import PoolVAE
     cfg, grid, steps = preset(model), GRID_480P, 50
     sd = syn.make_dit_state_dict(cfg, seed=0, device=DEV, dtype=torch.bfloat16)
@@ -535,18 +535,30 @@ def test_configs_2_and_3_at_50_steps(hip_ops, model, need):
     bsdr = {k: v.float() for k, v in bsd.items()}
     del sd, bsd
     torch.cuda.empty_cache()
-    t0 = time.time()
-    ref = R.denoise_loop(sdr, bsdr, cfg, noise.to(DEV), c1.to(DEV), c2.to(DEV), bl.to(DEV), num_steps=steps).cpu()
-    torch.cuda.synchronize()
-    t_ref = time.time() - t0
+    # The 14B oracle loop takes ~49 GPU-minutes and a lease is one hour: its final latent (a pure function of the seeds above) is
+    # written to gpurun_out/ and, when a copy is found under oracle/_ref/ (git-ignored, travels to the GPU box), reused - the second
+    # arm then runs in its own lease against the SAME oracle run.
+    cache_name = f"oracle_latent_config{2 if model == '1.3b' else 3}_{steps}_steps.pt"
+    cached = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", cache_name)
+    if os.path.exists(cached):
+        blob = torch.load(cached)
+        ref, t_ref = blob["latent"], blob["seconds"]
+        del sdr, bsdr
+    else:
+        t0 = time.time()
+        ref = R.denoise_loop(sdr, bsdr, cfg, noise.to(DEV), c1.to(DEV), c2.to(DEV), bl.to(DEV), num_steps=steps).cpu()
+        torch.cuda.synchronize()
+        t_ref = time.time() - t0
+        os.makedirs("gpurun_out", exist_ok=True)
+        torch.save(dict(latent=ref, seconds=t_ref), os.path.join("gpurun_out", cache_name))
     lines = []
     for mode, (lat, t_hip) in got.items():
         p, pf = R.psnr(lat, ref), frame_psnr(lat, ref, PoolVAE())
         lines.append(f"config #{2 if model == '1.3b' else 3}, Wan2.1-{model} 93f 480x832 (S = {grid.S}), {steps} steps CFG 5, product {mode}: HIP {t_hip:.1f}s, "
-                     f"fp32 torch oracle on GPU {t_ref:.1f}s; latent PSNR {p:.1f} dB, decoded-frame PSNR {pf:.1f} dB")
+                     f"fp32 torch oracle on GPU {t_ref:.1f}s{' (same oracle run, reused)' if os.path.exists(cached) else ''}; latent PSNR {p:.1f} dB, decoded-frame PSNR {pf:.1f} dB")
         print(lines[-1])
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(f"gpurun_out/parity_config{2 if model == '1.3b' else 3}_50_steps.txt", "w") as f:
+    with open(f"gpurun_out/parity_config{2 if model == '1.3b' else 3}_50_steps{'_' + '_'.join(arms) if len(arms) < 2 else ''}.txt", "w") as f:
         f.write("\n".join(lines) + "\n")
     for mode, (lat, _) in got.items():
         assert torch.isfinite(lat).all() and R.psnr(lat, ref) >= 40.0 and frame_psnr(lat, ref, PoolVAE()) >= 40.0, f"50 steps ({mode}) under the 40 dB bar: {lines}"
