@@ -62,7 +62,11 @@ class ClipVisionEncoder(nn.Module):
         mean = torch.tensor(CLIP_MEAN, device=x.device).view(1, 3, 1, 1)
         std = torch.tensor(CLIP_STD, device=x.device).view(1, 3, 1, 1)
         x = ((x - mean) / std).to(self.patch_embedding.weight.dtype)
-        x = self.patch_embedding(x).flatten(2).transpose(1, 2)
+        # the patch embedding is a convolution whose stride equals its kernel: a reshape + one matmul computes exactly the same sums
+        # and keeps MIOpen (and its first-call kernel search) out of the i2v path; the parameter stays a Conv2d weight (state-dict layout)
+        w = self.patch_embedding.weight
+        p, g = w.shape[-1], x.shape[-1] // w.shape[-1]
+        x = x.reshape(x.shape[0], 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(x.shape[0], g * g, 3 * p * p) @ w.reshape(w.shape[0], -1).t()
         x = torch.cat([self.cls_embedding.expand(x.shape[0], -1, -1), x], dim=1) + self.pos_embedding
         x = self.pre_norm(x)
         for blk in self.transformer[: self.use_blocks]:
