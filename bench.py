@@ -172,7 +172,7 @@ def parse_args(argv=None):
     ap.add_argument("--parallelism", default=os.environ.get("ICV_PARALLELISM", "auto"), choices=["auto", "sp", "cfg+sp"],
                     help="N>1: 'sp' = token shards over all N ranks, both CFG forwards on every rank; 'cfg+sp' = cond / "
                          "uncond forwards on two groups of N/2 ranks, token shards inside a group (auto when N is even)")
-    ap.add_argument("--kv-exchange", default=os.environ.get("ICV_KV_EXCHANGE", "auto"), choices=["auto", "allgather", "p2p", "native"],
+    ap.add_argument("--kv-exchange", default=os.environ.get("ICV_KV_EXCHANGE", "auto"), choices=["auto", "allgather", "p2p", "native", "ipc"],
                     help="N>1: K|V rows travel by all_gather_into_tensor (RCCL's schedule) or by grouped send/recv to every "
                          "peer (the direct, fully-connected schedule), or by libicvideo's own RCCL communicator (icv_allgather_kv; "
                          "seqpar.KVGather); 'auto' (default) = a start-up autotune times two real layers with each transport x "
@@ -471,7 +471,7 @@ def run_rank(args, world, rank, phase, stdout_fd):
                 return t.tolist()
 
             t_tune = time.perf_counter()
-            cands = [(m, c) for m in ("allgather", "p2p", "native") for c in sorted({args.sp_chunks, 2}, reverse=True)]
+            cands = [(m, c) for m in ("allgather", "p2p", "native", "ipc") for c in sorted({args.sp_chunks, 2}, reverse=True)]
             if share:      # several ranks on ONE GPU (development boxes): RCCL refuses duplicate devices in a communicator
                 cands = [mc for mc in cands if mc[0] != "native"]
             def exchange_only():          # one layer's K|V exchange with nothing to hide under: the raw transfer
@@ -541,7 +541,7 @@ def run_rank(args, world, rank, phase, stdout_fd):
         tt = torch.tensor([exposed_ms, float(len(waits)), float(n_coll)], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         comm = {"rccl_ranks": world, "backend": dist.get_backend(), "kv_exchange": args.kv_exchange, "sp_chunks": args.sp_chunks,
-                "kv_group_ranks": layout.sp_world,
+                "kv_group_ranks": layout.sp_world, "rccl_max_channels": os.environ.get("NCCL_MAX_NCHANNELS") or "rccl default",
                 "kv_exchanges_per_step_per_rank": tt[2].item() / args.steps,
                 "kv_bytes_sent_per_exchange_layer": 2 * 2 * plan.n_tok * cfg.dim if layout.sp_world > 1 else 0,
                 "exposed_kv_wait_ms_per_step": tt[0].item() / args.steps,      # max over ranks of the compute-stream stalls
