@@ -335,6 +335,10 @@ def run_rank(args, world, rank, phase, stdout_fd):
     # one process per GPU.  ICV_BENCH_SHARE_GPU=1 (+ ICV_DIST_BACKEND=gloo) lets several ranks share the only GPU of a
     # development box so the N>1 code path can be exercised there; it is never a measurement mode.
     share = os.environ.get("ICV_BENCH_SHARE_GPU", "0") == "1"
+    if world > 1:
+        # the copy-engine K|V transport keeps one pull stream per peer next to the launch stream: give the runtime enough hardware
+        # queues that a pull waiting for one peer's flag does not sit in front of another peer's copy (read when HIP initialises)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     dev_index = local_rank % torch.cuda.device_count() if share else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)

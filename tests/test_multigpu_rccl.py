@@ -209,6 +209,17 @@ def test_rccl_14b_layer_full_S_ranks_equal_single_gpu(tmp_path, big_layer_single
 
 
 @pytest.mark.gpu
+def test_shared_gpu_14b_layer_full_S_over_the_copy_engine_transport(tmp_path, big_layer_single):
+    """Config #4's layer at its real size through the copy-engine transport: ONE Wan2.1-14B block at S = 37 440 as two ranks
+    (18 720 tokens each, 4 ramped chunks: 383 MB of K|V rows pulled per rank per layer through hipIpc, the 1.15 GB symmetric heap
+    carved for kv_loc) sharing the one GPU, against the same block on one rank."""
+    args = ["--backend", "gloo", "--share-gpu"] + BIG_LAYER[2:] + ["--kv-exchange", "ipc"]
+    got = run_ranks(2, str(tmp_path / "multi.pt"), args, timeout=600)
+    assert got["info"]["sp_world"] == 2 and got["info"]["kv_collectives"] == 4 and got["info"]["kv_exchange"] == "ipc"
+    _close(got, big_layer_single, "2 ranks on one GPU, 14B block S=37440, copy-engine transport")
+
+
+@pytest.mark.gpu
 @needs_gpus(2)
 def test_rccl_fp8_mode_ranks_equal_single_gpu(tmp_path):
     """Config #5's kernels (e4m3 projections + e4m3 self-attention) on the sharded path: every gathered K|V chunk is
