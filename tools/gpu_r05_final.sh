@@ -6,6 +6,7 @@ mkdir -p gpurun_out
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 STAGE=${1:-all}
 if [[ $STAGE == all || $STAGE == suite ]]; then
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/r05_smoke.txt
   timeout 2400 python -m pytest tests -m gpu -q --durations=12 2>&1 | grep -v "MIOpen(HIP)" | tail -40 | tee gpurun_out/r05_gpu_suite_summary.txt
 fi
 if [[ $STAGE == all || $STAGE == bench ]]; then
