@@ -33,7 +33,7 @@ v = torch.randn((S, d), device="cuda").to(torch.bfloat16)
 side = torch.cuda.Stream()
 src = torch.empty((64 << 20,), dtype=torch.uint8, device="cuda").random_(0, 255)
 dst = torch.empty_like(src)
-copied = torch.zeros((1,), dtype=torch.int64, device="cuda")
+copied = torch.zeros((129,), dtype=torch.int64, device="cuda")      # [0] = bytes moved, then (XCC_ID, HW_ID) per work-group
 
 
 def traced_launch(n, co_runner=None):

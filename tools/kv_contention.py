@@ -45,7 +45,7 @@ main = torch.cuda.current_stream()
 SLICE = 32 << 20                     # bytes each copy work-group loops over
 src = torch.empty((32 * SLICE,), dtype=torch.uint8, device="cuda").random_(0, 255)
 dst = torch.empty_like(src)
-copied = torch.zeros((1,), dtype=torch.int64, device="cuda")
+copied = torch.zeros((129,), dtype=torch.int64, device="cuda")      # [0] = bytes moved, then (XCC_ID, HW_ID) per work-group
 
 
 def chunk_call(q, kk, vv, o, acc, ml, first, last):
@@ -86,7 +86,7 @@ def occupier(k, lds):
     def after():
         occ.occ_stop()
         side.synchronize()
-        return int(copied.item())
+        return int(copied[0].item())
     return before, after
 
 

@@ -14,6 +14,12 @@ volatile int* g_stop = nullptr;          // host-pinned, device-visible
 __global__ __launch_bounds__(256) void occupy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t vec_per_block,
                                                      volatile int* stop, unsigned long long* copied, int64_t max_rounds, int use_lds) {
   extern __shared__ char lds[];
+  if (threadIdx.x == 0) {           // where did this work-group land: copied[1 + 2b] = XCC_ID, copied[2 + 2b] = HW_ID (b < 64)
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (blockIdx.x < 64) { copied[1 + 2 * blockIdx.x] = xcc; copied[2 + 2 * blockIdx.x] = hwid; }
+  }
   if (use_lds && threadIdx.x == 0) lds[0] = 0;          // keep the dynamic LDS allocation alive
   const uint4* s = src + (int64_t)blockIdx.x * vec_per_block;
   uint4* d = dst + (int64_t)blockIdx.x * vec_per_block;
@@ -55,3 +61,12 @@ extern "C" int occ_start(int k, const void* src, void* dst, int64_t bytes_per_bl
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 extern "C" void occ_stop() { if (g_stop) *g_stop = 1; }
+
+// A stream whose kernels may only run on the CUs whose bit is set in `mask` (hipExtStreamCreateWithCUMask) - tools/cu_mask_probe.py
+extern "C" int occ_masked_stream(const unsigned* mask, int words, void** stream) {
+  hipStream_t s = nullptr;
+  if (hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask) != hipSuccess) return 1;
+  *stream = s;
+  return 0;
+}
+extern "C" void occ_stream_destroy(void* s) { if (s) (void)hipStreamDestroy((hipStream_t)s); }
