@@ -118,18 +118,22 @@ class VaeHip:
         self._g: Dict[int, torch.Tensor] = {}
 
     # ---- parameters -------------------------------------------------------------------------------------------------------
+    # Re-laid-out parameters are cached per module OBJECT: the key is id(module), guarded by a weak reference (a collected module's
+    # id can be handed to a new one) and by the parameter's version counter (a later load_state_dict writes it in place).
     def _conv_w(self, mod: nn.Module, taps) -> _ConvW:
+        import weakref
         rec = self._w.get(id(mod))
-        if rec is None or rec.version != mod.weight._version:
+        if rec is None or rec.owner() is not mod or rec.version != mod.weight._version or rec.taps != taps:
             rec = _ConvW(mod, self.device, taps, mod.weight.shape[1])
-            rec.version = mod.weight._version
+            rec.version, rec.owner = mod.weight._version, weakref.ref(mod)
             self._w[id(mod)] = rec
         return rec
 
     def _gamma(self, norm: nn.Module) -> torch.Tensor:
+        import weakref
         g = self._g.get(id(norm))
-        if g is None or g[1] != norm.gamma._version:
-            g = (norm.gamma.detach().reshape(-1).to(device=self.device, dtype=torch.float32).contiguous(), norm.gamma._version)
+        if g is None or g[2]() is not norm or g[1] != norm.gamma._version:
+            g = (norm.gamma.detach().reshape(-1).to(device=self.device, dtype=torch.float32).contiguous(), norm.gamma._version, weakref.ref(norm))
             self._g[id(norm)] = g
         return g[0]
 

@@ -310,6 +310,37 @@ def test_copy_engine_transport_one_rank_rehearsal(hip_ops):
     assert torch.isfinite(lats["ipc"]).all() and torch.equal(lats["ipc"], lats["allgather"])
 
 
+def test_copy_engine_transport_refuses_misuse(hip_ops):
+    """icv_ipc_* error paths on one rank: rows outside the symmetric heap, a heap that is too small for what is carved from it,
+    more than ICV_IPC_SLOTS exchanges without a wait, a wait for a ticket that is not in flight - each a clean error, not a hang."""
+    import ctypes
+    from infinicube_amd import native
+    from infinicube_amd.videogen.seqpar import KVGather, ShardPlan
+    kg = KVGather(ShardPlan.make(64, 1, 0), None, "ipc")
+    kg.reserve(1 << 20, "cuda:0")
+    heap = kg._heap
+    rows = kg.local_rows(64, 256, torch.bfloat16, hip_ops.alloc)
+    out = torch.empty_like(rows)
+    with pytest.raises(ValueError, match="not inside the symmetric heap"):
+        kg.start(torch.zeros_like(rows), out)
+    with pytest.raises(RuntimeError, match="heap exhausted"):
+        kg.local_rows(1 << 20, 256, torch.bfloat16, hip_ops.alloc)
+    base = hip_ops.lib.icv_ipc_tickets(heap.handle)
+    handles = [kg.start(rows, out) for _ in range(native.IPC_SLOTS - (base % native.IPC_SLOTS))]       # fill what is left of the ring ...
+    handles += [kg.start(rows, out) for _ in range(base % native.IPC_SLOTS)]                           # ... exactly IPC_SLOTS un-waited tickets
+    assert len(handles) == native.IPC_SLOTS
+    with pytest.raises(native.NativeError, match="exchanges in flight without a wait"):
+        kg.start(rows, out)
+    for h in handles:
+        kg.wait(h)
+    kg.wait(kg.start(rows, out))                     # the ring is free again
+    with pytest.raises(native.NativeError, match="not in flight"):
+        native.check(hip_ops.lib.icv_ipc_gather_wait(heap.handle, 10 ** 6, torch.cuda.current_stream().cuda_stream), "icv_ipc_gather_wait")
+    torch.cuda.synchronize()
+    assert torch.equal(out, rows)
+    kg.close()
+
+
 @pytest.mark.parametrize("transport", ["torch", "native"])
 def test_sequence_parallel_gather_on_rccl_stream(hip_ops, transport):
     """transport = "torch": torch.distributed's collective; "native": libicvideo's own RCCL communicator and side stream

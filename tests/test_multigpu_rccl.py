@@ -157,6 +157,17 @@ def test_shared_gpu_copy_engine_transport_is_bit_identical_to_allgather(tmp_path
 
 
 @pytest.mark.gpu
+def test_shared_gpu_fp8_mode_cfg_sp_subgroups(tmp_path):
+    """The e4m3 wire format under the `cfg+sp` layout: 4 ranks = two branch groups of 2; the abs-max reduction and the blob exchange
+    run inside each branch's sub-group (copy-engine transport), the branches swap velocity tokens per step."""
+    args = GPU_TINY[2:] + ["--scenario", "loop", "--gemm-dtype", "fp8", "--attn-dtype", "fp8"]
+    ref = run_ranks(1, str(tmp_path / "single.pt"), ["--backend", "nccl"] + args)
+    got = run_ranks(4, str(tmp_path / "multi.pt"), ["--backend", "gloo", "--share-gpu"] + args + ["--parallelism", "cfg+sp", "--kv-exchange", "ipc"])
+    assert got["info"]["mode"] == "cfg+sp" and got["info"]["sp_world"] == 2
+    _close(got, ref, "gloo x4 on one GPU, cfg+sp, fp8 mode, e4m3 on the wire via ipc", rel_bound=2e-2, psnr_bound=45.0)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kv_exchange", ["allgather", "ipc"])
 def test_shared_gpu_fp8_mode_e4m3_on_the_wire(tmp_path, kv_exchange):
     """Config #5's kernels on the sharded path between real processes (2 ranks sharing the GPU): every rank quantises its own K|V

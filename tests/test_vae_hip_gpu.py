@@ -72,6 +72,33 @@ def test_conv_shift_matches_torch_conv(name, make, taps, with_resid):
     assert float(out.vol()[: VH.PT].abs().max()) == 0.0
 
 
+def test_conv_shift_fuzz_random_geometries():
+    """Random volumes and channel counts (every block width of the kernel, K-tiles that straddle taps, single-tile and
+    many-tile row ranges, tails of every kind), each against the stock convolution in fp32 on the CPU."""
+    import random
+    dev = _dev()
+    rng = random.Random(1234)
+    hip = VH.VaeHip(nn.Identity(), dev)
+    kinds = [("333", VH.TAPS_333), ("311", VH.TAPS_311), ("133", VH.TAPS_133), ("111", VH.TAPS_111)]
+    for case in range(14):
+        kind, taps = kinds[case % 4]
+        cin = rng.choice([32, 64, 96, 160, 192])
+        cout = rng.choice([4, 16, 32, 48, 96, 100, 192, 224, 384])
+        T, H, W = rng.randint(1, 6), rng.randint(1, 19), rng.randint(1, 23)
+        torch.manual_seed(100 + case)
+        mod = {"333": lambda: V.CausalConv3d(cin, cout, 3, padding=1), "311": lambda: V.CausalConv3d(cin, cout, (3, 1, 1), padding=(1, 0, 0)),
+               "133": lambda: nn.Conv2d(cin, cout, 3, padding=1), "111": lambda: V.CausalConv3d(cin, cout, 1)}[kind]()
+        with torch.no_grad():
+            mod.weight.copy_(mod.weight.to(torch.bfloat16).float())
+        x = (torch.randn(1, cin, T, H, W) * 0.5).to(torch.bfloat16)
+        out = hip.conv(hip._to_vol(x.to(dev), cin), mod, taps)
+        torch.cuda.synchronize()
+        got = out.interior()[..., :cout].permute(3, 0, 1, 2)[None]
+        with torch.no_grad():
+            ref = mod(x.float()) if isinstance(mod, V.CausalConv3d) else V._per_frame(mod, x.float())
+        _per_op_ok(got, ref, f"fuzz case {case}: {kind} {cin}->{cout} on {T}x{H}x{W}")
+
+
 def test_stride2_forms_match_torch():
     """The encoder's two strided convolutions through their stride-1 evaluation + subsampling (VaeHip.downsample)."""
     dev = _dev()
