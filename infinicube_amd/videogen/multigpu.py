@@ -118,7 +118,9 @@ class WorkerPool:
         # before any weights are loaded: every rank builds the plan's process groups and runs one small collective on each
         # plus one K|V exchange with the plan's transport, under a deadline; a raised error or a hung rank abandons that
         # process group (workers killed, group destroyed) and the next plan starts from fresh processes.
-        req = (os.environ.get("ICV_PARALLELISM", "auto"), os.environ.get("ICV_KV_EXCHANGE") or "allgather")
+        # K|V transport: what the caller asked for, else "auto" on RCCL ranks (the pipeline's start-up autotune measures the
+        # transports on its first sequence-parallel call; the probe below checks the plain all-gather for it), "allgather" elsewhere
+        req = (os.environ.get("ICV_PARALLELISM", "auto"), os.environ.get("ICV_KV_EXCHANGE") or ("auto" if self.backend == "nccl" else "allgather"))
         plans = [req]
         if os.environ.get("ICV_WORLD_FALLBACK", "1") == "1":
             plans += [(req[0], "allgather"), ("sp", "allgather")]
@@ -355,13 +357,16 @@ def probe_plan(plan, plan_index: int, rank: int, world: int, backend: str, layou
                     raise RuntimeError(f"group smoke test returned {dst.view(m, 4)[:, 0].tolist()}, expected {want}")
             if lay.sp_world > 1:       # the K|V transport of the plan, on 8 rows per rank
                 plan_s = lay.shard_plan(8 * lay.sp_world)
-                kg = KVGather(plan_s, lay.sp_group, kv)
-                rows = torch.full((8, 16), float(lay.sp_rank + 1), device=dev, dtype=torch.bfloat16)
+                kg = KVGather(plan_s, lay.sp_group, "allgather" if kv == "auto" else kv)
+                kg.reserve(1 << 16, dev)                 # the copy-engine transport keeps the rows in its symmetric heap
+                rows = kg.local_rows(8, 16, torch.bfloat16, lambda shape, dt: torch.empty(shape, dtype=dt, device=dev))
+                rows.fill_(float(lay.sp_rank + 1))
                 out = torch.zeros((8 * lay.sp_world, 16), device=dev, dtype=torch.bfloat16)
                 kg.wait(kg.start(rows, out))
                 if dev.type == "cuda":
                     torch.cuda.synchronize(dev)
                 got = out.view(lay.sp_world, 8, 16)[:, 0, 0].float().tolist()
+                kg.close()
                 if got != [float(r + 1) for r in range(lay.sp_world)]:
                     raise RuntimeError(f"K|V exchange '{kv}' returned shard order {got}")
             box.append("ok")

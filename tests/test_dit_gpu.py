@@ -419,7 +419,7 @@ def test_config1_wan_1p3b_17f_256p_10_steps(hip_ops):
     """BASELINE.json config #1 at the REAL Wan2.1-1.3B dimensions (d=1536, 12 heads, 30 layers, text 512x4096):
     17 frames 256x448 (S = 2240 tokens), 10 flow-match steps with CFG, guidance-buffer tokens from the dummy
     buffers' stand-in latents; HIP loop vs the fp32 oracle fed the same bf16-rounded weights (run by stock PyTorch on the GPU,
-    cross-checked against the CPU execution of the same code on a full CFG step).
+    cross-checked against the CPU execution of the same code on a full CFG step of the same model on a smaller grid).
     Bar: final-latent PSNR >= 40 dB (north star), per-step velocity cosine >= 0.999."""
     import time
     from infinicube_amd.videogen.config import GRID_CFG1
@@ -443,11 +443,16 @@ def test_config1_wan_1p3b_17f_256p_10_steps(hip_ops):
     t0 = time.time()
     ref = R.denoise_loop({k: v.to(dev) for k, v in sdr.items()}, {k: v.to(dev) for k, v in bsdr.items()}, cfg, noise.to(dev), c1.to(dev), c2.to(dev),
                          bl.to(dev), num_steps=steps).cpu()
-    one_gpu = R.denoise_loop({k: v.to(dev) for k, v in sdr.items()}, {k: v.to(dev) for k, v in bsdr.items()}, cfg, noise.to(dev), c1.to(dev), c2.to(dev),
-                             bl.to(dev), num_steps=1).cpu()
+    # ... on a SMALL grid (5 latent frames of 8 x 12 tokens: the same 30 layers, 1.3B widths and code path; one full CFG step takes
+    # about a second on the host instead of twenty at S = 2240)
+    from infinicube_amd.videogen.config import TokenGrid
+    g_small = TokenGrid(17, 128, 192)
+    n_small, bl_small = syn.make_latent_noise(g_small), syn.make_buffer_latents(cfg, g_small)
+    one_gpu = R.denoise_loop({k: v.to(dev) for k, v in sdr.items()}, {k: v.to(dev) for k, v in bsdr.items()}, cfg, n_small.to(dev), c1.to(dev), c2.to(dev),
+                             bl_small.to(dev), num_steps=1).cpu()
     torch.cuda.synchronize()
     torch.set_num_threads(min(32, torch.get_num_threads()))
-    one_cpu = R.denoise_loop(sdr, bsdr, cfg, noise, c1, c2, bl, num_steps=1)
+    one_cpu = R.denoise_loop(sdr, bsdr, cfg, n_small, c1, c2, bl_small, num_steps=1)
     t_cpu = time.time() - t0
     assert float((one_gpu - one_cpu).norm() / one_cpu.norm()) < 1e-4, "the oracle on GPU tensors and on CPU tensors disagree"
     p = R.psnr(lat.cpu(), ref)
