@@ -99,6 +99,45 @@ def test_conv_shift_fuzz_random_geometries():
         _per_op_ok(got, ref, f"fuzz case {case}: {kind} {cin}->{cout} on {T}x{H}x{W}")
 
 
+def test_conv_full_tile_size_sampled_rows_and_linearity():
+    """The decoder's largest layer at the size a 480p tile really has: a causal 3x3x3 convolution 96 -> 96 over a padded volume of
+    [93 + 2, 240 + 2, 416 + 2] positions (9.6 M rows, 37 k row tiles, 41 K-tiles of which every third straddles two taps).
+    (a) 768 sampled output positions (corners, edges, frame 0, random interior) against a direct fp32 evaluation of the 27 taps;
+    (b) size-independent property: the kernel is exactly linear under scaling by a power of two - conv(2x) == 2 conv(x) BIT FOR BIT
+    on every one of the 9.3 M real positions (no bias): any row mixed up between tiles, taps or K-halves would break it."""
+    dev = _dev()
+    torch.manual_seed(7)
+    T, H, W, C = 93, 240, 416, 96
+    mod = V.CausalConv3d(C, C, 3, padding=1, bias=False)
+    with torch.no_grad():
+        mod.weight.copy_((mod.weight * 4).to(torch.bfloat16).float())
+    hip = VH.VaeHip(nn.Identity(), dev)
+    xv = VH.Vol(T, H, W, C, dev)
+    xv.interior().copy_((torch.randn((T, H, W, C), device=dev) * 0.5).to(torch.bfloat16))
+    xv.zero_halo()
+    out = hip.conv(xv, mod, VH.TAPS_333)
+    torch.cuda.synchronize()
+    g = torch.Generator().manual_seed(3)
+    pos = [(0, 0, 0), (0, H - 1, W - 1), (T - 1, 0, W - 1), (T - 1, H - 1, 0), (1, 0, 5), (2, 7, 0), (T - 1, H - 1, W - 1)]
+    pos += [(int(torch.randint(0, T, (1,), generator=g)), int(torch.randint(0, H, (1,), generator=g)), int(torch.randint(0, W, (1,), generator=g))) for _ in range(761)]
+    t_i, h_i, w_i = (torch.tensor(v, device=dev) for v in zip(*pos))
+    xp = xv.vol().float()                                                    # padded: frame t -> t + 2, pixel -> + 1
+    w = mod.weight.detach().to(dev).float()                                  # [co, ci, 3, 3, 3]
+    ref = torch.zeros((len(pos), C), device=dev)
+    for dt in range(3):
+        for dh in range(3):
+            for dw in range(3):
+                ref += xp[t_i + dt, h_i + dh, w_i + dw] @ w[:, :, dt, dh, dw].t()       # causal: frames t-2..t = padded t..t+2
+    got = out.interior()[t_i, h_i, w_i].float()
+    _per_op_ok(got, ref, "3x3x3 96->96 at the full 480p tile size, sampled positions")
+    xv.mat.mul_(2)                                                           # exact in bf16
+    out2 = hip.conv(xv, mod, VH.TAPS_333)
+    torch.cuda.synchronize()
+    a, b = out.interior(), out2.interior()
+    assert torch.equal((a.float() * 2).to(torch.bfloat16), b), "conv(2x) != 2 conv(x): rows mixed up between tiles / taps / K-halves"
+    assert float(a.float().abs().mean()) > 0.1
+
+
 def test_stride2_forms_match_torch():
     """The encoder's two strided convolutions through their stride-1 evaluation + subsampling (VaeHip.downsample)."""
     dev = _dev()
