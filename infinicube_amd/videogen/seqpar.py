@@ -223,6 +223,10 @@ class KVGather:
         if self.mode == "allgather":
             return (self.dist.all_gather_into_tensor(out, rows, group=self.group, async_op=True),)
         m, dist = rows.shape[0], self.dist
+        if rows.is_cuda and dist.get_backend(self.group) != "nccl":
+            # development set-ups only (gloo ranks sharing a GPU): gloo's send reads the device buffer from the host with no
+            # regard for the stream that is still producing it - RCCL's send is stream-ordered, gloo's is not
+            torch.cuda.current_stream(rows.device).synchronize()
         p2p = []
         for j, peer in enumerate(self.peers):
             if j == self.plan.rank:

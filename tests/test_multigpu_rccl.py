@@ -129,6 +129,15 @@ def gpu_single(tmp_path_factory):
 
 
 @pytest.mark.gpu
+def test_shared_gpu_gloo_p2p_transport_four_ranks_sp(tmp_path, gpu_single):
+    """The grouped send / recv transport under the `sp` layout with 4 ranks (both CFG branches' exchanges of a layer in flight
+    together, 3 peers each) between processes sharing the GPU - the combination bench.py's autotune picks on such a box."""
+    args = ["--backend", "gloo", "--share-gpu"] + GPU_TINY[2:] + ["--scenario", "loop", "--parallelism", "sp", "--kv-exchange", "p2p"]
+    got = run_ranks(4, str(tmp_path / "multi.pt"), args)
+    _close(got, gpu_single["loop"], "gloo x4 on one GPU, sp / p2p", rel_bound=1e-2, psnr_bound=50.0)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world,parallelism", [(2, "sp"), (4, "cfg+sp")])
 def test_shared_gpu_gloo_ranks_equal_single_gpu(tmp_path, gpu_single, world, parallelism):
     """What a ONE-GPU box can run of the multi-process path: N real processes, each with the PRODUCT operator set (HIP
