@@ -227,11 +227,90 @@ def fuzz_attention():
         fails.append(what + ": two identical launches differ (race?)")
 
 
-t0, n = time.time(), {"gemm": 0, "attention": 0, "gemm_fp8": 0, "attention_fp8": 0}
+def fuzz_conv():
+    """icv_conv3d_ndhwc through the padded-volume executor: random geometry / channels / tap set / fused residual against an explicit
+    fp32 tap sum on the GPU (slices of the padded volume times the tap's weight matrix: no MIOpen anywhere)."""
+    import torch.nn as nn
+    from infinicube_amd.videogen import vae as V, vae_hip as VH
+    global _hip
+    if "_hip" not in globals():
+        _hip = VH.VaeHip(nn.Identity(), DEV)
+    kind, taps = rng.choice([("333", VH.TAPS_333), ("311", VH.TAPS_311), ("133", VH.TAPS_133), ("111", VH.TAPS_111), ("133d", VH.TAPS_133_DOWN)])
+    cin = 32 * rng.choice([1, 2, 3, 4, 6, 12])
+    cout = rng.choice([3, 4, 12, 16, 32, 33, 64, 96, 100, 128, 192, 200, 384, 768])
+    T, H, W = rng.randint(1, 7), rng.randint(1, 40), rng.randint(1, 50)
+    shape = {"333": (3, 3, 3), "311": (3, 1, 1), "133": (1, 3, 3), "133d": (1, 3, 3), "111": (1, 1, 1)}[kind]
+    g = torch.Generator(device=DEV).manual_seed(rng.randint(0, 2 ** 31))
+    conv = nn.Conv3d(cin, cout, shape).to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_((torch.randn(conv.weight.shape, device=DEV, generator=g) * (2.0 / (cin * len(taps)) ** 0.5)).to(torch.bfloat16).float())
+        conv.bias.copy_(torch.randn((cout,), device=DEV, generator=g) * 0.1)
+    x = (torch.randn((1, cin, T, H, W), device=DEV, generator=g) * 0.7).to(torch.bfloat16)
+    xv = _hip._to_vol(x, cin)
+    resid = None
+    if rng.random() < 0.4:
+        r = torch.randn((1, (cout + 3) // 4 * 4, T, H, W), device=DEV, generator=g).to(torch.bfloat16)
+        resid = _hip._to_vol(r, (cout + 3) // 4 * 4)
+    outs = [_hip.conv(xv, conv, taps, resid=resid).interior()[..., :cout].clone() for _ in range(2)]
+    xp = F.pad(x[0].permute(1, 2, 3, 0).float(), (0, 0, 2, 2, 2, 2, 2, 2))              # [T+4, H+4, W+4, C]: room for every tap
+    w = conv.weight.detach().float().reshape(cout, cin, -1)
+    ref = conv.bias.detach().float().expand(T, H, W, cout).clone()
+    for i, (dt, dh, dw) in enumerate(taps):
+        ref += xp[2 + dt: 2 + dt + T, 2 + dh: 2 + dh + H, 2 + dw: 2 + dw + W] @ w[:, :, i].t()
+    if resid is not None:
+        ref += r[0, :cout].permute(1, 2, 3, 0).float()
+    what = f"conv {kind} {cin}->{cout} on {T}x{H}x{W} resid={resid is not None}"
+    if close_bf16(outs[0], ref, what) and not torch.equal(outs[0], outs[1]):
+        fails.append(what + ": two identical launches differ (race?)")
+
+
+def fuzz_attention_fp8_pieces():
+    """the e4m3 wire format: W pieces of m keys quantised piece by piece with the global scales must reproduce the unsharded
+    e4m3 launch BIT FOR BIT when m is a multiple of 64, and stay inside the e4m3 noise bar against exact attention otherwise."""
+    H, W = rng.choice([1, 2, 3]), rng.choice([1, 2, 3, 4, 8])
+    m = 64 * rng.randint(1, 12) if rng.random() < 0.5 else rng.randint(1, 700)
+    Sq = rng.choice([1, 33, 256, 257, 300]) if rng.random() < 0.7 else rng.randint(1, 900)
+    d, Skv = H * 128, m * W
+    g = torch.Generator(device=DEV).manual_seed(rng.randint(0, 2 ** 31))
+    q = torch.randn((Sq, d), device=DEV, generator=g).to(torch.bfloat16)
+    k = (torch.randn((Skv, d), device=DEV, generator=g) * (128 ** -0.5 * math.log2(math.e))).to(torch.bfloat16)
+    v = torch.randn((Skv, d), device=DEV, generator=g).to(torch.bfloat16)
+    ws = ops.attention_fp8_buffers(Sq, Skv, d, H)
+    o_ref = torch.zeros((Sq, d), dtype=torch.bfloat16, device=DEV)
+    ops.attention_fp8(q, k, v, o_ref, H, ws)
+    amax = torch.zeros((3, H), device=DEV)
+    ops.attention_fp8_kv_amax(k, v, H, amax)
+    bb = ops.attention_fp8_blob_bytes(m, H)
+    blobs = torch.empty((W * bb,), dtype=torch.uint8, device=DEV)
+    for i in range(W):
+        ops.attention_fp8_quantize_kv(k[i * m:(i + 1) * m], v[i * m:(i + 1) * m], H, amax, blobs[i * bb:(i + 1) * bb])
+    ws2 = ops.attention_fp8_with_amax(ws, amax)
+    ops.attention_fp8_prepare(ws2, H, q=q)
+    o = torch.zeros((Sq, d), dtype=torch.bfloat16, device=DEV)
+    ops.attention_fp8_pieces(ws2, amax, blobs, m, W, Sq, o, None, None, H, first=True, last=True)
+    what = f"attention_fp8_pieces Sq={Sq} m={m} W={W} H={H}"
+    if m % 64 == 0:
+        if not torch.equal(o, o_ref):
+            fails.append(what + ": tile-aligned pieces differ from the unsharded launch")
+        return
+    ref = ref_attention(q, k, v, H, math.log(2.0))
+    rms = float(ref.pow(2).mean().sqrt())
+    err = float((o.float() - ref).pow(2).mean().sqrt())
+    if not torch.isfinite(o.float()).all() or err > (0.06 if Sq * H >= 64 else 0.15) * rms:
+        fails.append(f"{what}: rms err {err:.3g} vs rms {rms:.3g}")
+
+
+t0, n = time.time(), {"gemm": 0, "attention": 0, "gemm_fp8": 0, "attention_fp8": 0, "conv": 0, "fp8_pieces": 0}
+R5_TOO = os.environ.get("FUZZ_R5", "0") == "1"       # FUZZ_R5=1 adds round 5's entry points: the convolution and the e4m3 pieces
 FP8_TOO = os.environ.get("FUZZ_FP8", "0") == "1"     # FUZZ_FP8=1 adds the e4m3 entry points (a different case sequence)
 try:
     while (sum(n.values()) < max_cases) if max_cases > 0 else (time.time() - t0 < budget):
-        if FP8_TOO and rng.random() < 0.3:
+        if R5_TOO and rng.random() < 0.5:
+            if rng.random() < 0.6:
+                fuzz_conv(); n["conv"] += 1
+            else:
+                fuzz_attention_fp8_pieces(); n["fp8_pieces"] += 1
+        elif FP8_TOO and rng.random() < 0.3:
             if rng.random() < 0.6:
                 fuzz_gemm_fp8(); n["gemm_fp8"] += 1
             else:
@@ -249,5 +328,6 @@ for f in fails[:40]:
     print("FAIL", f)
 print(f"fuzz seed {seed}: {n['gemm']} GEMM cases, {n['attention']} attention cases" +
       (f", {n['gemm_fp8']} e4m3 GEMM cases, {n['attention_fp8']} e4m3 attention cases" if FP8_TOO else "") +
+      (f", {n['conv']} convolution cases, {n['fp8_pieces']} e4m3-pieces cases" if R5_TOO else "") +
       f" in {time.time() - t0:.0f} s, {len(fails)} failures")
 sys.exit(1 if fails else 0)
