@@ -15,7 +15,7 @@ mkdir -p "$here/build"
 srcs=(api elementwise gemm gemm256 gemm_fp8 fp8 attention attn2 attn7 attn8 buffers voxels vae_ops dit_forward comm ipc conv)
 tag=""
 if [[ "${ICV_EXPERIMENTS:-0}" == "1" ]]; then
-  srcs+=(experiments/attn1 experiments/attn3 experiments/attn4 experiments/attn5 experiments/attn6 experiments/attn9 experiments/gemm256w experiments/gemm256x)
+  srcs+=(experiments/attn1 experiments/attn3 experiments/attn4 experiments/attn5 experiments/attn6 experiments/attn9 experiments/gemm256w experiments/gemm256x experiments/gemm256p)
   FLAGS+=(-DICV_EXPERIMENTS)
   tag="x"          # separate object files: the two configurations differ in -DICV_EXPERIMENTS
 fi

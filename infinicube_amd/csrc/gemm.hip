@@ -180,6 +180,10 @@ int icv_gemm256_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw,
                          int64_t M, int64_t N, int64_t K, int epilogue, void* out, int64_t ldo,
                          int64_t nsplit, int64_t split_stride, const float* resid, int64_t ldr,
                          const float* gate, hipStream_t st);
+int icv_gemm256p_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                          int64_t M, int64_t N, int64_t K, int epilogue, void* out, int64_t ldo,
+                          int64_t nsplit, int64_t split_stride, const float* resid, int64_t ldr,
+                          const float* gate, hipStream_t st);
 
 extern "C" int icv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw,
                              const float* bias, int64_t M, int64_t N, int64_t K, int epilogue,
@@ -216,6 +220,15 @@ extern "C" int icv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t 
                                    resid, ldr, gate, (hipStream_t)stream);
 #else
       icv_set_error("gemm256 = 4 is an experiment: rebuild libicvideo with ICV_EXPERIMENTS=1");
+      return 1;
+#endif
+    }
+    if (mode == 5 || mode == 6) {  // experiment (round 5): gemm256's default schedule as a persistent kernel (5: static stride, 6: per-XCD work counter)
+#ifdef ICV_EXPERIMENTS
+      return icv_gemm256p_dispatch(A, lda, W, ldw, bias, M, N, K, epilogue, out, ldo, nsplit, split_stride,
+                                   resid, ldr, gate, (hipStream_t)stream);
+#else
+      icv_set_error("gemm256 = 5 / 6 is an experiment: rebuild libicvideo with ICV_EXPERIMENTS=1");
       return 1;
 #endif
     }

@@ -973,10 +973,11 @@ def test_attention_add_into_output(hip_ops, Sq, Skv, H):
 @pytest.mark.parametrize("M,N,K,epi", [(256, 256, 64, "f32"), (300, 512, 192, "f32"), (1000, 768, 1536, "bf16"), (513, 1024, 512, "gelu"),
                                        (640, 512, 1280, "resid"), (515, 768, 384, "split")])
 @pytest.mark.experiments
-@pytest.mark.parametrize("kernel", [3, 4])
+@pytest.mark.parametrize("kernel", [3, 4, 5, 6])
 def test_gemm_4wave_variant(hip_ops, M, N, K, epi, kernel):
     """gemm256w.hip (option gemm256 = 3): 4 waves x 128x128 wave tiles, accumulators pinned to AGPRs, fragments read one
-    half-phase ahead; gemm256x.hip (= 4): the same wave tiles with whole-tile double buffering and one barrier per K-tile.
+    half-phase ahead; gemm256x.hip (= 4): the same wave tiles with whole-tile double buffering and one barrier per K-tile;
+    gemm256p.hip (= 5 / 6, round 5): gemm256's default schedule as a persistent kernel (static stride / per-XCD work counter).
     Same results as the default kernels for every epilogue and for ragged M."""
     need_experiments(hip_ops)
     a = rnd((M, K), 431).to(torch.bfloat16)
