@@ -196,10 +196,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(Params p) {
 
     // ---- the NEXT tile's first operands start moving now, under this tile's epilogue ----
     const int64_t cm0 = m0, cn0 = n0;
-    if (li_next < len) {
+    const bool has_next = li_next < len;
+    if (has_next) {
       tile_of(start + li_next, m0, n0);
       offsets(m0, n0, offA, offB);
-      prologue(offA, offB);
+      // gated-residual epilogue: its first half's 16 residual loads go out FIRST (they are consumed first and would otherwise queue
+      // behind 96 KB of prologue traffic); the other epilogues only store, so their prologue starts right away
+      if (EPI != ICV_EPI_RESID_F32) prologue(offA, offB);
     }
 
     // ---- epilogue of the tile just computed (gemm256.hip's, for the four epilogues) ----
@@ -222,6 +225,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(Params p) {
           for (int j = 0; j < 4; ++j)
             rs[ii][j] = *reinterpret_cast<const float4*>(p.resid + mc * p.ldr + cn0 + wc * 64 + (j >> 1) * 32 + (j & 1) * 16 + kq * 4);
         }
+        if (hf == 0 && has_next) prologue(offA, offB);
       }
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii) {
