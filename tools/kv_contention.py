@@ -35,7 +35,7 @@ H, S = 40, 37440
 d = H * 128
 SCALE = math.log(2.0)
 ITERS = int(os.environ.get("ITERS", "5"))
-WHAT = os.environ.get("WHAT", "occupy,blit,rccl").split(",")
+WHAT = os.environ.get("WHAT", "occupy,blit,rccl,gemm").split(",")
 torch.manual_seed(0)
 kv = torch.cat([(torch.randn((S, d), device="cuda") * (128 ** -0.5 * math.log2(math.e))).to(torch.bfloat16),
                 torch.randn((S, d), device="cuda").to(torch.bfloat16)], dim=1).contiguous()
@@ -161,3 +161,21 @@ for world in (4, 8):
         rows.append(("1-rank RCCL all-gather loop", ms, 0.0))
     for name, ms, rate in rows:
         print(f"{name:44s} {ms:8.3f} {100 * (ms / alone - 1):9.1f}% {rate / 1e9:11.1f}")
+    if "gemm" in WHAT:
+        # the other kernel a transfer overlaps with: the Q projection [n, d] x [d, d] that runs while the first K|V chunks travel
+        from infinicube_amd.videogen.ops import EPI_BF16
+        a = torch.randn((n, d), device="cuda").to(torch.bfloat16)
+        w = (torch.randn((d, d), device="cuda") / math.sqrt(d)).to(torch.bfloat16)
+        bias = torch.randn((d,), device="cuda")
+        og = torch.empty((n, d), dtype=torch.bfloat16, device="cuda")
+
+        def run_g():
+            for _ in range(4):
+                ops.gemm(a, w, bias, og, EPI_BF16)
+
+        g_alone, _ = time_attention(run_g)
+        print(f"    Q-projection GEMM [{n}, {d}] x [{d}, {d}] (x4 per sample): alone {g_alone / 4:.3f} ms = {2.0 * n * d * d / (g_alone / 4) / 1e9:.0f} TF/s")
+        for lds, nm in ((0, "light"), (65536, "64K LDS")):
+            for k in (1, 8, 32):
+                ms, _ = time_attention(run_g, *occupier(k, lds))
+                print(f"    {k:2d} copy work-groups ({nm:7s}): {ms / 4:.3f} ms ({100 * (ms / g_alone - 1):+.1f} %)")
