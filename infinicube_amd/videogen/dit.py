@@ -82,7 +82,7 @@ class WanDiT:
         self.fp8 = gemm_dtype == "fp8"
         # which of the six per-layer projections run in e4m3 when gemm_dtype == "fp8" (default FP8_DEFAULT; ICV_FP8_WEIGHTS=
         # "wqkv,f0_w,..." or the fp8_weights argument overrides it: e4m3 has 3 mantissa bits, so every quantised GEMM adds
-        # ~3-5 % relative noise to its output however fine the scales are - DESIGN.md §8 has the accuracy / speed table)
+        # ~3-5 % relative noise to its output however fine the scales are - DESIGN.md §7 and profiles/r03/fp8_projection_subsets_psnr_14b_depth.txt have the accuracy / speed table)
         env = os.environ.get("ICV_FP8_WEIGHTS")
         sel = fp8_weights if fp8_weights is not None else (tuple(x for x in env.split(",") if x) if env else self.FP8_DEFAULT)
         bad = [x for x in sel if x not in self.FP8_WEIGHTS]
@@ -291,7 +291,7 @@ class WanDiT:
         # ICV_NATIVE_FORWARD=1 / self.native_forward = True: one C call (icv_dit_forward) enqueues the whole forward instead of
         # ~13 C-ABI calls per layer from Python — the same launchers in the same order, so bit-identical, in every mode (bf16 /
         # e4m3, one rank / sequence-parallel with libicvideo's own RCCL communicator).  Off by default: host issue time is
-        # 0.3 % of a 14B step either way.
+        # 0.3 % of a 14B step either way (profiles/r03).
         self.native_forward = os.environ.get("ICV_NATIVE_FORWARD", "0") == "1"
         if getattr(self, "_native", None) is not None:      # a new workspace: the old context points at freed buffers
             self.ops.lib.icv_dit_destroy(self._native)
