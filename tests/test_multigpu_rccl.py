@@ -194,8 +194,8 @@ def test_shared_gpu_fp8_mode_e4m3_on_the_wire(tmp_path, kv_exchange):
 @pytest.mark.gpu
 @needs_gpus(2)
 @pytest.mark.parametrize("world,parallelism,kv_exchange", [
-    (2, "sp", "allgather"), (2, "sp", "native"), (2, "cfg+sp", "allgather"),
-    (4, "cfg+sp", "p2p"), (4, "sp", "native"), (8, "auto", "allgather"), (8, "sp", "p2p")])
+    (2, "sp", "allgather"), (2, "sp", "native"), (2, "sp", "ipc"), (2, "cfg+sp", "allgather"),
+    (4, "cfg+sp", "p2p"), (4, "sp", "native"), (4, "cfg+sp", "ipc"), (8, "auto", "allgather"), (8, "sp", "p2p"), (8, "sp", "ipc")])
 def test_rccl_loop_ranks_equal_single_gpu(tmp_path, gpu_single, world, parallelism, kv_exchange):
     """A full CFG loop on N GPUs over RCCL — `sp` and `cfg+sp`, the three K|V transports — against the 1-GPU latent."""
     if _n_gpus() < world:
@@ -217,7 +217,7 @@ def big_layer_single(tmp_path_factory):
 
 @pytest.mark.gpu
 @needs_gpus(2)
-@pytest.mark.parametrize("kv_exchange", ["allgather", "p2p", "native"])
+@pytest.mark.parametrize("kv_exchange", ["allgather", "p2p", "native", "ipc"])
 def test_rccl_14b_layer_full_S_ranks_equal_single_gpu(tmp_path, big_layer_single, kv_exchange):
     """Config #4's layer: ONE Wan2.1-14B block at S = 37 440 sharded over every GPU of the box, K|V rows over RCCL,
     against the same block on one GPU."""
@@ -241,14 +241,16 @@ def test_shared_gpu_14b_layer_full_S_over_the_copy_engine_transport(tmp_path, bi
 
 @pytest.mark.gpu
 @needs_gpus(2)
-def test_rccl_fp8_mode_ranks_equal_single_gpu(tmp_path):
-    """Config #5's kernels (e4m3 projections + e4m3 self-attention) on the sharded path: every gathered K|V chunk is
-    quantised on its own, so the N-GPU result differs from the 1-GPU one at the e4m3 level, not the bf16 one."""
+@pytest.mark.parametrize("kv_exchange", ["allgather", "ipc"])
+def test_rccl_fp8_mode_ranks_equal_single_gpu(tmp_path, kv_exchange):
+    """Config #5's kernels (e4m3 projections + e4m3 self-attention) on the sharded path with e4m3 K|V on the wire: every rank
+    quantises its own rows with the group's scales (= the unsharded launch's), so the N-GPU result differs from the 1-GPU one by the
+    softmax merge order only (bar: the bf16 path's; rounds 2-4 re-quantised every gathered chunk: 6e-2 / 30 dB)."""
     n = max(w for w in (2, 4, 8) if w <= _n_gpus())
     args = GPU_TINY + ["--scenario", "loop", "--gemm-dtype", "fp8", "--attn-dtype", "fp8"]
     ref = run_ranks(1, str(tmp_path / "single.pt"), args)
-    got = run_ranks(n, str(tmp_path / "multi.pt"), args + ["--parallelism", "sp"])
-    _close(got, ref, f"RCCL x{n} fp8 mode", rel_bound=6e-2, psnr_bound=30.0)
+    got = run_ranks(n, str(tmp_path / "multi.pt"), args + ["--parallelism", "sp", "--kv-exchange", kv_exchange])
+    _close(got, ref, f"RCCL x{n} fp8 mode, e4m3 on the wire via {kv_exchange}", rel_bound=2e-2, psnr_bound=45.0)
 
 
 @pytest.mark.gpu
