@@ -523,6 +523,48 @@ def test_generator_end_to_end_on_gpu(tmp_path, monkeypatch):
     assert not np.array_equal(a1, a3), "guidance buffers must condition the output"
 
 
+def test_pipeline_i2v_with_the_real_vae_and_clip_modules_on_gpu(monkeypatch):
+    """The pipeline end to end on the GPU with the REAL module classes either side of the loop at small widths: the Wan-VAE
+    (tiled encode of both guidance buffers and of the image-conditioning clip, tiled decode - every convolution on libicvideo's
+    kernel) and the CLIP vision tower (patch embedding as a matmul), the image-to-video branch of the DiT in between.  Same call
+    twice = the same frames; the same call with the VAE's convolutions on MIOpen = the same video to bf16 rounding through a
+    2-step loop."""
+    from PIL import Image
+    import numpy as np
+    from infinicube_amd.videogen.clip_vision import ClipVisionEncoder
+    from infinicube_amd.videogen.pipeline import DiTHolder, WanVideoPipeline
+    from infinicube_amd.videogen.vae import WanVAE, WanVAENet
+    from standins import HashTextEncoder
+    cfg, grid = preset("tiny-i2v"), TokenGrid(9, 64, 96)
+    sd = syn.make_dit_state_dict(cfg)
+    torch.manual_seed(21)
+    net = WanVAENet(dim=32, z_dim=16).eval()
+    clip = ClipVisionEncoder(image_size=224, patch=14, dim=cfg.img_dim, heads=2, layers=2, use_blocks=1).to("cuda:0", torch.bfloat16).eval()
+    rng = np.random.default_rng(0)
+    img = Image.fromarray(rng.integers(0, 255, (grid.height, grid.width, 3), dtype=np.uint8), mode="RGB")
+    sem, co = syn.make_dummy_buffers(grid)
+    to_pil = lambda a: [Image.fromarray(f, mode="RGB") for f in a]      # noqa: E731
+
+    def run(conv):
+        import copy
+        monkeypatch.setenv("ICV_VAE_CONV", conv)
+        vae = WanVAE(copy.deepcopy(net), "cuda:0", torch.bfloat16)
+        assert (vae.hip is not None) == (conv == "hip")
+        pipe = WanVideoPipeline("cuda:0", torch.bfloat16, DiTHolder(sd, cfg), HashTextEncoder(cfg), vae, image_encoder=clip)
+        pipe.initialize_buffer_embedder(16, zero_init=False)
+        out = pipe(prompt="a street", negative_prompt="bad", semantic_buffer_video=to_pil(sem), coordinate_buffer_video=to_pil(co), input_image=img,
+                   height=grid.height, width=grid.width, num_frames=grid.num_frames, seed=0, num_inference_steps=2, tiled=True,
+                   tile_size=(6, 8), tile_stride=(3, 4))
+        return np.stack([np.asarray(f) for f in out]).astype(np.int16)
+
+    a, a2, b = run("hip"), run("hip"), run("miopen")
+    assert a.shape == (grid.num_frames, grid.height, grid.width, 3)
+    assert np.array_equal(a, a2), "the same call must reproduce the same frames"
+    d = np.abs(a - b)
+    print(f"i2v pipeline with the real VAE / CLIP: HIP vs MIOpen convolutions: mean |d| {d.mean():.3f}, max {d.max()} of 255")
+    assert d.mean() < 2.0, f"HIP-convolution pipeline drifts from the MIOpen one: mean |d| {d.mean():.2f}"
+
+
 @pytest.mark.parametrize("name,mode", [("tiny", "bf16"), ("tiny-i2v", "bf16"), ("tiny", "fp8"), ("tiny-i2v", "fp8"),
                                        ("tiny", "sp"), ("tiny", "sp-torch"), ("tiny-i2v", "sp+fp8")])
 def test_native_forward_matches_python_driver(hip_ops, name, mode):
