@@ -2,11 +2,10 @@
 MIOpen's best kernel (stock F.conv3d, bf16, NDHWC, find mode) on the same operands.  Run on the GPU box.
 TF/s = algorithmic flops of the REAL positions (2 * T*H*W * taps * Cin * Cout) / time: the halo rows the shifted-row form also
 computes (1.3 % at 240 x 416, 10 % at 30 x 52) count as overhead, not as work."""
-import os, sys, time
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 from infinicube_amd.videogen import vae as V, vae_hip as VH
 
 dev = torch.device("cuda", 0)
