@@ -378,7 +378,8 @@ int icv_allgather_kv(icv_comm* comm, const void* rows, void* out, int64_t m, int
  * HEAP (same size everywhere) that holds its K|V rows; peers open it through hipIpc and PULL row chunks with
  * hipMemcpyAsync on one stream per peer (SDMA over the pair's xGMI link); readiness and reuse are flag words in a POSIX
  * shared-memory segment `shm_name` (mapped and hipHostRegister'ed by every rank) written with hipStreamWriteValue32 and
- * waited for with hipStreamWaitValue32 — no wave and no host round trip anywhere in the per-layer path.
+ * waited for with hipStreamWaitValue32 — no host round trip anywhere in the per-layer path (on current ROCm both stream
+ * operations are small runtime kernels: the wait spins on one wave for the skew between two ranks; the ROWS move by SDMA).
  *   every rank:  icv_ipc_create(name, rank, world, heap, heap_bytes, &ipc) — `heap` = a BORROWED device buffer of heap_bytes
  *                (it must stay alive until icv_ipc_destroy; the allocation containing it is what gets exported), or NULL
  *                to let the library hipMalloc one (icv_ipc_heap returns it); icv_ipc_export(ipc, handle) -> host ships the

@@ -13,8 +13,11 @@
 //   * readiness is a FLAG WORD per (rank, slot) in a small POSIX shared-memory segment that every rank maps and registers
 //     with hipHostRegister: the producer's launch stream writes a sequence number behind the kernels that produced the rows
 //     (hipStreamWriteValue32), the consumer's pull stream waits for ">= that number" in front of its copy
-//     (hipStreamWaitValue32: a wait packet executed by the command processor — no wave, no host round trip).  Sequence
-//     numbers only grow, so a late waiter can never miss a publish and no host handshake is needed;
+//     (hipStreamWaitValue32) — no host round trip.  MEASURED on this runtime (tools/probe_streamops.py under rocprofv3): the write is
+//     a 1-2 us kernel (__amd_rocclr_streamOpsWrite) and the wait is a ONE-WAVE KERNEL THAT SPINS (__amd_rocclr_streamOpsWait), not a
+//     command-processor packet: it is resident only for the skew between the two ranks (they run the same program), and it is
+//     the rows, not the flags, whose movement would otherwise occupy CUs for the whole transfer.  Sequence numbers only grow, so a
+//     late waiter can never miss a publish and no host handshake is needed;
 //   * the reverse hazard (the producer's next layer overwriting rows a slow peer is still pulling) is closed the same way:
 //     each pull stream writes "pulled up to ticket k" into done[consumer][producer] behind its copy, and
 //     icv_ipc_acquire makes the producer's launch stream wait for every peer's counter before the K|V GEMM of the next layer.
@@ -24,7 +27,7 @@
 // hardware queues: every wait a rank enqueues is for a flag whose write the peer enqueued EARLIER in its own program order
 // than its own waits of the same ticket, so processing each rank's packets in submission order always terminates.
 //
-// The host side (infinicube_amd/videogen/seqpar.py, KVGather mode "ipc") ships the 64-byte handles and the segment name
+// The host side (infinicube_amd/videogen/seqpar.py, KVGather mode "ipc") ships the 72-byte handles and the segment name
 // through the torch.distributed group once, runs a pattern self-test, and joins the start-up autotune as one more candidate.
 #include <errno.h>
 #include <fcntl.h>
@@ -51,6 +54,15 @@ constexpr int kSlots = ICV_IPC_SLOTS;
   } while (0)
 
 size_t flags_bytes(int world) { return sizeof(uint32_t) * ((size_t)world * kSlots + (size_t)world * world); }
+
+// icv_ipc_acquire: ONE launch in which lane p waits for peer p's "pulled up to ticket k" counter (the runtime's hipStreamWaitValue32 is
+// a spinning kernel per call as well - measured - so (world - 1) of them would be (world - 1) launches per layer on the launch stream)
+__global__ void wait_done_kernel(const uint32_t* done_col, int world, int rank, uint32_t value) {
+  const int p = threadIdx.x;
+  if (p >= world || p == rank) return;
+  const uint32_t* f = done_col + (size_t)p * world;          // done[p][rank]
+  while ((int32_t)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0) __builtin_amdgcn_s_sleep(8);
+}
 
 }  // namespace
 
@@ -227,13 +239,10 @@ extern "C" int icv_ipc_gather_wait(icv_ipc* c, int64_t ticket, void* stream) {
 
 extern "C" int icv_ipc_acquire(icv_ipc* c, void* stream) {
   ICV_REQUIRE(c, "icv_ipc_acquire: null argument");
-  if (c->next_ticket == 0) return 0;
-  for (int p = 0; p < c->world; ++p) {
-    if (p == c->rank) continue;
-    ICV_HIP_OK(hipStreamWaitValue32((hipStream_t)stream, c->done(p, c->rank), (uint32_t)c->next_ticket, hipStreamWaitValueGte, 0xffffffffu),
-               "hipStreamWaitValue32(done)");
-  }
-  return 0;
+  if (c->next_ticket == 0 || c->world == 1) return 0;
+  ICV_REQUIRE(c->world <= 64, "icv_ipc_acquire: at most 64 ranks");
+  hipLaunchKernelGGL(wait_done_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint32_t*)c->done(0, c->rank), c->world, c->rank, (uint32_t)c->next_ticket);
+  return icv_check_launch("icv_ipc_acquire");
 }
 
 extern "C" int64_t icv_ipc_tickets(const icv_ipc* c) { return c ? c->next_ticket : -1; }

@@ -140,12 +140,15 @@ class KVGather:
       * ``"native"``: ``icv_allgather_kv`` of libicvideo on this group's own RCCL communicator (``icv_comm_create``; the id
         travels through the torch.distributed group once) and a dedicated HIP stream fenced with events — the same
         transfer without torch.distributed in the per-layer path (SURVEY §8b's C export; GPU ranks only);
-      * ``"ipc"``: NO compute unit and no RCCL in the per-layer path (csrc/ipc.hip, ``icv_ipc_*``): the local rows live in a
-        symmetric heap every peer has opened through hipIpc, each rank PULLS its peers' chunks with copy-engine
-        ``hipMemcpyAsync`` on one stream per peer, readiness / reuse are flag words waited for by the command processor
-        (``hipStreamWaitValue32``).  The RCCL modes run channel kernels on CUs that the one-work-group-per-CU attention also
-        wants (profiles/r05/kv_contention.md); this one leaves the CUs alone.  GPU ranks only; the torch.distributed group
-        carries the 72-byte handles once.  The rows handed to ``start`` must come from ``local_rows`` (the heap)."""
+      * ``"ipc"``: no RCCL and no kernel MOVING ROWS in the per-layer path (csrc/ipc.hip, ``icv_ipc_*``): the local rows live
+        in a symmetric heap every peer has opened through hipIpc, each rank PULLS its peers' chunks with copy-engine
+        ``hipMemcpyAsync`` on one stream per peer; readiness / reuse are flag words in shared host memory
+        (``hipStreamWriteValue32`` / ``hipStreamWaitValue32``: on this runtime small kernels - the wait spins on ONE wave for
+        the skew between two ranks, measured with tools/probe_streamops.py).  The RCCL modes run channel kernels that stay
+        resident for the whole transfer on CUs the one-work-group-per-CU attention also wants
+        (profiles/r05/kv_contention.md); this one leaves the CUs to the attention while the rows travel.  GPU ranks only; the
+        torch.distributed group carries the 72-byte handles once.  The rows handed to ``start`` must come from
+        ``local_rows`` (the heap)."""
 
     MODES = ("allgather", "p2p", "native", "ipc")
 
