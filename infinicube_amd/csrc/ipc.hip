@@ -1,7 +1,8 @@
-// K13 without compute units (SURVEY.md §8e "hide it"): the per-layer exchange of the post-RoPE K|V rows as PULLS by the copy
-// engines.  An RCCL all-gather is a kernel: every channel is a work-group pinned on a CU for the whole transfer, and the
-// attention it is supposed to hide under runs exactly one 8-wave work-group per CU — a taken CU stretches a whole round of
-// that launch (measured: profiles/r05/kv_contention.md).  Here nothing of the exchange runs on a CU:
+// K13 with the rows moved by the copy engines (SURVEY.md §8e "hide it"): the per-layer exchange of the post-RoPE K|V rows as PULLS.
+// An RCCL all-gather is a kernel: every channel is a work-group pinned on a CU for the whole transfer, and the attention it is
+// supposed to hide under runs exactly one 8-wave work-group per CU — a taken CU stretches a whole round of that launch
+// (measured: profiles/r05/kv_contention.md).  Here no kernel moves a row; what does run on a CU is one wave per flag operation
+// (see "MEASURED" below), resident for the skew between two ranks instead of for the transfer:
 //
 //   * every rank keeps its K|V rows in a SYMMETRIC HEAP — one device buffer of the same size on every rank (the caller's own,
 //     e.g. a torch tensor: the allocation that contains it is found with hipMemGetAddressRange and exported whole, the offset

@@ -51,6 +51,11 @@ def test_ops_against_stock_torch_primitives():
     qh, kh, vh = (t.reshape(40, 2, 128).transpose(0, 1) for t in (q, k, v))
     manual = (torch.softmax(qh @ kh.transpose(1, 2) / math.sqrt(128), -1) @ vh).transpose(0, 1).reshape(40, 256)
     assert torch.allclose(R.attention(q, k, v, 2), manual, atol=1e-5)
+    # the chunked explicit form the full-size GPU checker runs (scale in the GEMM's alpha) against torch's SDPA
+    sdpa = F.scaled_dot_product_attention(qh[None], kh[None], vh[None])[0]
+    assert torch.allclose(R.attention_explicit(qh, kh, vh, 1.0 / math.sqrt(128)), sdpa, atol=1e-5)
+    qb, kb, vb = (torch.randn((3, 70, 64), generator=g) for _ in range(3))
+    assert torch.allclose(R.attention_explicit(qb, kb, vb, 0.31), F.scaled_dot_product_attention(qb[None], kb[None], vb[None], scale=0.31)[0], atol=1e-5)
     lat = torch.randn((16, 2, 8, 12), generator=g)
     wt = torch.randn((32, 16, 1, 2, 2), generator=g)
     tok = R.patchify_tokens(lat, wt, None)
