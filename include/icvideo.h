@@ -406,6 +406,10 @@ int icv_ipc_gather_start(icv_ipc* ipc, int64_t src_offset, int64_t bytes, void* 
 int icv_ipc_gather_wait(icv_ipc* ipc, int64_t ticket, void* stream);
 int icv_ipc_acquire(icv_ipc* ipc, void* stream);
 int64_t icv_ipc_tickets(const icv_ipc* ipc);
+/* a rank that cannot go on releases every peer wait that depends on it (its flag words jump past every sequence number: the
+ * peers pull undefined bytes instead of spinning forever) and refuses further exchanges; the error itself travels by the host's
+ * own channel.  Turns "one rank failed" from a hang on the others into an error on all. */
+int icv_ipc_abort(icv_ipc* ipc);
 
 /* ---- dtype plumbing: f32 -> bf16 (round-to-nearest-even), n elements ---------------------- */
 int icv_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);

@@ -83,6 +83,9 @@ struct icv_ipc {
   bool registered = false;
   int64_t next_ticket = 0;
   bool waited[kSlots];
+  bool aborted = false;
+  hipStream_t last_stream = nullptr;   // the launch stream of the latest gather_start (icv_ipc_abort drains it)
+  bool last_stream_valid = false;
   uint32_t* ready(int r, int slot) const { return flags_dev + (size_t)r * kSlots + slot; }
   uint32_t* done(int consumer, int producer) const { return flags_dev + (size_t)world * kSlots + (size_t)consumer * world + producer; }
 };
@@ -191,12 +194,15 @@ extern "C" int icv_ipc_open_peer(icv_ipc* c, int peer, const char* handle) {
   return 0;
 }
 
+extern "C" int icv_ipc_abort(icv_ipc* c);
+
 extern "C" int icv_ipc_gather_start(icv_ipc* c, int64_t src_offset, int64_t bytes, void* out, void* stream, int64_t* ticket) {
   ICV_REQUIRE(c && out && ticket, "icv_ipc_gather_start: null argument");
   ICV_REQUIRE(bytes > 0 && src_offset >= 0 && src_offset + bytes <= c->heap_bytes,
               "icv_ipc_gather_start: rows [%lld, +%lld) are outside the %lld-byte symmetric heap", (long long)src_offset, (long long)bytes,
               (long long)c->heap_bytes);
   for (int p = 0; p < c->world; ++p) ICV_REQUIRE(c->peer[p], "icv_ipc_gather_start: peer %d's heap was never opened", p);
+  ICV_REQUIRE(!c->aborted, "icv_ipc_gather_start: this transport was aborted (icv_ipc_abort)");
   const int64_t k = c->next_ticket;
   const int slot = (int)(k % kSlots);
   ICV_REQUIRE(c->waited[slot], "icv_ipc_gather_start: %d exchanges in flight without a wait (ticket %lld was never waited for)", kSlots,
@@ -204,25 +210,38 @@ extern "C" int icv_ipc_gather_start(icv_ipc* c, int64_t src_offset, int64_t byte
   const uint32_t seq = (uint32_t)(k / kSlots + 1);
   hipStream_t s = (hipStream_t)stream;
   char* dst = (char*)out;
+  c->last_stream = s;
+  c->last_stream_valid = true;
+  // a runtime failure from here on leaves this rank's exchange half-enqueued while the peers wait for it: release them (icv_ipc_abort)
+#define ICV_IPC_RUN(call, what)                                                                                  \
+  do {                                                                                                           \
+    const hipError_t e_ = (call);                                                                                \
+    if (e_ != hipSuccess) {                                                                                      \
+      (void)icv_ipc_abort(c);                                                                                    \
+      icv_set_error("icv_ipc_gather_start: %s: %s (%s); transport aborted", what, hipGetErrorName(e_), hipGetErrorString(e_)); \
+      return 2;                                                                                                  \
+    }                                                                                                            \
+  } while (0)
   // the rows were produced on `s`: publish them behind their producers
-  ICV_HIP_OK(hipStreamWriteValue32(s, c->ready(c->rank, slot), seq, 0), "hipStreamWriteValue32(ready)");
+  ICV_IPC_RUN(hipStreamWriteValue32(s, c->ready(c->rank, slot), seq, 0), "hipStreamWriteValue32(ready)");
   // everything this rank still does with `out` (the previous layer's attention reads it) was enqueued on `s` before this point
-  ICV_HIP_OK(hipEventRecord(c->started[slot], s), "hipEventRecord(started)");
+  ICV_IPC_RUN(hipEventRecord(c->started[slot], s), "hipEventRecord(started)");
   for (int i = 1; i < c->world; ++i) {
     const int p = (c->rank + i) % c->world;          // start with the right-hand neighbour: at any moment every link is asked once
     hipStream_t ps = c->pull[p];
-    ICV_HIP_OK(hipStreamWaitEvent(ps, c->started[slot], 0), "hipStreamWaitEvent(started)");
-    ICV_HIP_OK(hipStreamWaitValue32(ps, c->ready(p, slot), seq, hipStreamWaitValueGte, 0xffffffffu), "hipStreamWaitValue32(ready)");
-    ICV_HIP_OK(hipMemcpyAsync(dst + (int64_t)p * bytes, c->peer[p] + src_offset, (size_t)bytes, hipMemcpyDeviceToDevice, ps), "hipMemcpyAsync(pull)");
-    ICV_HIP_OK(hipStreamWriteValue32(ps, c->done(c->rank, p), (uint32_t)(k + 1), 0), "hipStreamWriteValue32(done)");
-    ICV_HIP_OK(hipEventRecord(c->landed[(size_t)p * kSlots + slot], ps), "hipEventRecord(landed)");
+    ICV_IPC_RUN(hipStreamWaitEvent(ps, c->started[slot], 0), "hipStreamWaitEvent(started)");
+    ICV_IPC_RUN(hipStreamWaitValue32(ps, c->ready(p, slot), seq, hipStreamWaitValueGte, 0xffffffffu), "hipStreamWaitValue32(ready)");
+    ICV_IPC_RUN(hipMemcpyAsync(dst + (int64_t)p * bytes, c->peer[p] + src_offset, (size_t)bytes, hipMemcpyDeviceToDevice, ps), "hipMemcpyAsync(pull)");
+    ICV_IPC_RUN(hipStreamWriteValue32(ps, c->done(c->rank, p), (uint32_t)(k + 1), 0), "hipStreamWriteValue32(done)");
+    ICV_IPC_RUN(hipEventRecord(c->landed[(size_t)p * kSlots + slot], ps), "hipEventRecord(landed)");
   }
   // own rows: a local copy in launch-stream order
-  ICV_HIP_OK(hipMemcpyAsync(dst + (int64_t)c->rank * bytes, c->heap + src_offset, (size_t)bytes, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync(own rows)");
+  ICV_IPC_RUN(hipMemcpyAsync(dst + (int64_t)c->rank * bytes, c->heap + src_offset, (size_t)bytes, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync(own rows)");
   c->waited[slot] = false;
   c->next_ticket = k + 1;
   *ticket = k;
   return 0;
+#undef ICV_IPC_RUN
 }
 
 extern "C" int icv_ipc_gather_wait(icv_ipc* c, int64_t ticket, void* stream) {
@@ -244,6 +263,35 @@ extern "C" int icv_ipc_acquire(icv_ipc* c, void* stream) {
   ICV_REQUIRE(c->world <= 64, "icv_ipc_acquire: at most 64 ranks");
   hipLaunchKernelGGL(wait_done_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint32_t*)c->done(0, c->rank), c->world, c->rank, (uint32_t)c->next_ticket);
   return icv_check_launch("icv_ipc_acquire");
+}
+
+// A rank that cannot go on (a failed call in the middle of an exchange) must not leave its peers' queues spinning on flags it
+// will never write: every flag word this rank owns jumps to a value every present and future waiter accepts (the waits compare
+// ">= sequence number").  Peers then pull whatever bytes are there - the caller's own error report (the collective self-test, the
+// launch ladder) is what stops the run; this only guarantees that it is an ERROR everywhere and not a hang somewhere.
+// Flag writes this rank enqueued earlier (legitimate, smaller sequence numbers) may still execute AFTER the host's poison and
+// overwrite it, so: poison, let this rank's own queues drain for a bounded time (they depend only on tickets the peers have
+// published, or are released by the peers' own aborts), poison again.
+extern "C" int icv_ipc_abort(icv_ipc* c) {
+  ICV_REQUIRE(c, "icv_ipc_abort: null argument");
+  c->aborted = true;
+  if (!c->flags_host) return 0;
+  volatile uint32_t* f = c->flags_host;
+  constexpr uint32_t kPoison = 0x7fffffffu;
+  auto poison = [&]() {
+    for (int s = 0; s < kSlots; ++s) f[(size_t)c->rank * kSlots + s] = kPoison;                                   // ready[rank][*]
+    for (int p = 0; p < c->world; ++p) f[(size_t)c->world * kSlots + (size_t)c->rank * c->world + p] = kPoison;   // done[rank][*]
+    __sync_synchronize();
+  };
+  poison();
+  for (int spin = 0; spin < 2000; ++spin) {        // <= 2 s
+    bool busy = c->last_stream_valid && hipStreamQuery(c->last_stream) == hipErrorNotReady;
+    for (hipStream_t ps : c->pull) busy = busy || (ps && hipStreamQuery(ps) == hipErrorNotReady);
+    if (!busy) break;
+    usleep(1000);
+  }
+  poison();
+  return 0;
 }
 
 extern "C" int64_t icv_ipc_tickets(const icv_ipc* c) { return c ? c->next_ticket : -1; }

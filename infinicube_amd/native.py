@@ -93,6 +93,7 @@ SIGNATURES.update({
     "icv_ipc_gather_wait": (c_int, [c_void_p, _I, _P]),
     "icv_ipc_acquire": (c_int, [c_void_p, _P]),
     "icv_ipc_tickets": (c_int64, [c_void_p]),
+    "icv_ipc_abort": (c_int, [c_void_p]),
     "icv_dit_profile": (c_int, [c_void_p, c_int]),
     "icv_dit_profile_read": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
 })

@@ -415,6 +415,8 @@ class _IpcHeap:
             n = self.SELF_TEST_BYTES
             for rep in range(2):        # twice: the second round reuses the rows (acquire) and the flag words
                 self.acquire()
+                if os.environ.get("ICV_TEST_HOOKS") == "1" and os.environ.get("ICV_IPC_INJECT") == f"selftest:{self.rank}":
+                    raise RuntimeError("injected failure (test hook)")
                 self.mem[:n] = (torch.arange(n, device=self.device, dtype=torch.int32) * (2 * self.rank + 3) + 17 * rep).to(torch.uint8)
                 out = torch.zeros((self.world * n,), dtype=torch.uint8, device=self.device)
                 self.gather(self.mem[:n], out).wait()
@@ -425,7 +427,14 @@ class _IpcHeap:
                         return f"rank {self.rank}: the rows pulled from rank {p} are wrong (round {rep})"
             return ""
         except Exception as e:      # noqa: BLE001
+            self.abort()                # the peers may already be waiting for rows this rank will never publish
             return f"rank {self.rank}: {type(e).__name__}: {e}"[:300]
+
+    def abort(self):
+        """This rank cannot go on: release every peer wait that depends on it (icv_ipc_abort), so that the failure is an error
+        on every rank instead of a spinning queue on the others.  The transport is unusable afterwards."""
+        if self.handle is not None:
+            self.lib.icv_ipc_abort(self.handle)
 
     def carve(self, rows: int, cols: int, dtype) -> torch.Tensor:
         nbytes = rows * cols * torch.empty((), dtype=dtype).element_size()

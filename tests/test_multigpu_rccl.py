@@ -165,6 +165,58 @@ def test_shared_gpu_copy_engine_transport_is_bit_identical_to_allgather(tmp_path
     assert torch.equal(got["result"], ref["result"]), "the copy-engine transport moved different bytes than the collective one"
 
 
+IPC_ABORT_WORKER = r"""
+import os, sys, time, torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.cuda.set_device(0)
+from infinicube_amd.videogen.seqpar import _IpcHeap
+t0 = time.time()
+try:
+    _IpcHeap(dist, None, list(range(world)), rank, world, 1 << 20, "cuda:0")
+    print("NO ERROR")
+    rc = 1
+except RuntimeError as e:
+    print(f"rank {rank}: error after {time.time() - t0:.1f} s: {e}")
+    rc = 0 if "self-test" in str(e) and "injected failure" in str(e) else 2
+assert not _IpcHeap._live
+dist.destroy_process_group()
+sys.exit(rc)
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,bad", [(2, 1), (3, 0)])
+def test_copy_engine_transport_one_rank_failing_is_an_error_on_every_rank_not_a_hang(world, bad):
+    """One rank fails in the middle of the set-up self-test (test hook) while its peers' pull streams already spin on its
+    "rows ready" flag: icv_ipc_abort releases them (the flag words jump past every sequence number), the peers pull undefined bytes,
+    the self-test reports it, and EVERY rank raises the same RuntimeError within seconds - what lets the start-up ladder drop the
+    transport symmetrically instead of waiting for a watchdog."""
+    import time
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PYTHONPATH=os.pathsep.join([ROOT, HERE, os.environ.get("PYTHONPATH", "")]), OMP_NUM_THREADS="2",
+                   ICV_TEST_HOOKS="1", ICV_IPC_INJECT=f"selftest:{bad}")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, "-c", IPC_ABORT_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                      stdin=subprocess.DEVNULL))
+    t0, outs = time.time(), []
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=120)
+            outs.append(o.decode(errors="replace"))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()          # exactly the PIDs started here
+                p.wait()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} (rc {p.returncode}):\n{outs[r][-2000:] if r < len(outs) else ''}"
+    print(f"{world} ranks, rank {bad} failing inside the self-test: every rank raised after {time.time() - t0:.1f} s (incl. start-up)")
+
+
 @pytest.mark.gpu
 def test_shared_gpu_fp8_mode_cfg_sp_subgroups(tmp_path):
     """The e4m3 wire format under the `cfg+sp` layout: 4 ranks = two branch groups of 2; the abs-max reduction and the blob exchange
