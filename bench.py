@@ -336,9 +336,11 @@ def run_rank(args, world, rank, phase, stdout_fd):
     # development box so the N>1 code path can be exercised there; it is never a measurement mode.
     share = os.environ.get("ICV_BENCH_SHARE_GPU", "0") == "1"
     if world > 1:
-        # the copy-engine K|V transport keeps one pull stream per peer next to the launch stream: give the runtime enough hardware
-        # queues that a pull waiting for one peer's flag does not sit in front of another peer's copy (read when HIP initialises)
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        # the copy-engine K|V transport keeps one pull stream per peer next to the launch stream, and a pull that waits for its peer's
+        # flag is a spinning kernel that blocks its HARDWARE queue (measured: profiles/r05/kv_contention.md, "pending waits"): enough
+        # queues that neither the launch stream nor another peer's copy ever sits behind one (7 pulls + launch + torch / RCCL streams;
+        # read when HIP initialises)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     dev_index = local_rank % torch.cuda.device_count() if share else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)

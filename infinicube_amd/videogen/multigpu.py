@@ -167,7 +167,9 @@ class WorkerPool:
         self.procs = []
         from .seqpar import apply_rccl_channel_cap
         apply_rccl_channel_cap(int(os.environ.get("ICV_RCCL_MAX_CHANNELS", "-1")))      # this process (rank 0) and, inherited, the workers
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # one pull stream per peer (copy-engine K|V transport); read at HIP initialisation
+        # one pull stream per peer (copy-engine K|V transport) + the launch stream + torch's / RCCL's own: a pending pull blocks its
+        # hardware queue (profiles/r05/kv_contention.md, "pending waits"), so nothing else may share it; read at HIP initialisation
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
         for r in range(1, world):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), ICV_WORKER_RANK=str(r),
                        ICV_WORKER_SPEC=spec_path, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),

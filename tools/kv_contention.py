@@ -9,7 +9,11 @@ transfer that runs for its whole duration on a second stream:
   * a loop of hipMemcpyAsync device-to-device copies (same device: the runtime's blit KERNEL — not what the copy-engine
     transport does between two devices, where the copy is SDMA; here it shows what a chip-wide copy kernel costs);
   * a 1-rank RCCL all-gather loop on libicvideo's own communicator (`icv_allgather_kv`), with NCCL_MAX_NCHANNELS from the
-    environment (run the tool once per setting).
+    environment (run the tool once per setting);
+  * `k` pending hipStreamWaitValue32 on k side streams (WHAT=spin): what the copy-engine transport (csrc/ipc.hip) keeps resident
+    while a peer's rows are not published yet - on this runtime each wait is a one-wave kernel that spins
+    (profiles/r05/stream_ops_probe.txt); k = 3 / 7 = the pull streams of an sp4 / sp8 group, waiting for the WHOLE measurement
+    (the worst case: in the loop a wait lasts for the skew between two ranks).
 Prints one table per shard shape: attention ms, slow-down vs alone, and the bytes/s the transfer moved meanwhile.
     python tools/kv_contention.py            (on the GPU box; ITERS=5 repetitions per cell)
 """
@@ -106,6 +110,43 @@ def blit_loop(nbytes):
     return before, after
 
 
+hip = ctypes.CDLL("libamdhip64.so")
+hip.hipStreamWaitValue32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint, ctypes.c_uint32]
+spin_flag = torch.zeros((16,), dtype=torch.int32).pin_memory()
+spin_dp = ctypes.c_void_p()
+assert hip.hipHostGetDevicePointer(ctypes.byref(spin_dp), ctypes.c_void_p(spin_flag.data_ptr()), 0) == 0
+spin_streams = [torch.cuda.Stream() for _ in range(7)]
+spin_seq = [0]
+
+
+def spin_waits(k):
+    """NOTE: a pending wait blocks every stream that shares its HARDWARE queue (streams are dealt to GPU_MAX_HW_QUEUES queues):
+    if the measuring stream lands behind one, only the watchdog below ends the measurement (it is reported)."""
+    import threading
+    state = {}
+
+    def release(late):
+        if late:
+            print(f"    !! watchdog released the {k} waits after 20 s: the main stream was queued BEHIND a waiting stream "
+                  f"(GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', '(default)')})", flush=True)
+        spin_flag[0] = spin_seq[0]          # host write: releases every waiter
+
+    def before():
+        spin_seq[0] += 1
+        for st in spin_streams[:k]:
+            assert hip.hipStreamWaitValue32(ctypes.c_void_p(st.cuda_stream), spin_dp, spin_seq[0], 0, 0xFFFFFFFF) == 0
+        state["t"] = threading.Timer(20.0, release, args=(True,))
+        state["t"].start()
+
+    def after():
+        state["t"].cancel()
+        release(False)
+        for st in spin_streams[:k]:
+            st.synchronize()
+        return 0
+    return before, after
+
+
 rccl = None
 if "rccl" in WHAT:
     try:
@@ -152,6 +193,10 @@ for world in (4, 8):
             for k in (1, 2, 4, 8, 16, 32):
                 ms, rate = time_attention(run, *occupier(k, lds))
                 rows.append((f"{k:2d} copy work-groups ({name})", ms, rate))
+    if "spin" in WHAT:
+        for k in (1, 3, 7):
+            ms, _ = time_attention(run, *spin_waits(k))
+            rows.append((f"{k} pending hipStreamWaitValue32 (spin waves)", ms, 0.0))
     chunk_bytes = 2 * 2 * d * (n - n // 10)       # ~ one large chunk of one peer's K|V rows
     if "blit" in WHAT:
         ms, _ = time_attention(run, *blit_loop(min(chunk_bytes, src.numel())))
