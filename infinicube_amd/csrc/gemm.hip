@@ -181,9 +181,9 @@ int icv_gemm256_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw,
                          int64_t nsplit, int64_t split_stride, const float* resid, int64_t ldr,
                          const float* gate, hipStream_t st);
 int icv_gemm256p_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
-                          int64_t M, int64_t N, int64_t K, int epilogue, void* out, int64_t ldo,
-                          int64_t nsplit, int64_t split_stride, const float* resid, int64_t ldr,
-                          const float* gate, hipStream_t st);
+                          int64_t M, int64_t N, int64_t K, int epilogue, void* out, int64_t ldo, int64_t nsplit,
+                          int64_t split_stride, const float* resid, int64_t ldr, const float* gate, int mode, hipStream_t st);
+int icv_gemm256p_cus();
 
 extern "C" int icv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw,
                              const float* bias, int64_t M, int64_t N, int64_t K, int epilogue,
@@ -223,14 +223,11 @@ extern "C" int icv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t 
       return 1;
 #endif
     }
-    if (mode == 5 || mode == 6) {  // experiment (round 5): gemm256's default schedule as a persistent kernel (5: static stride, 6: per-XCD work counter)
-#ifdef ICV_EXPERIMENTS
-      return icv_gemm256p_dispatch(A, lda, W, ldw, bias, M, N, K, epilogue, out, ldo, nsplit, split_stride,
-                                   resid, ldr, gate, (hipStream_t)stream);
-#else
-      icv_set_error("gemm256 = 5 / 6 is an experiment: rebuild libicvideo with ICV_EXPERIMENTS=1");
-      return 1;
-#endif
+    if (mode == 5 || mode == 6) {  // A/B: gemm256's schedule as a persistent kernel for EVERY epilogue (5: static stride, 6: per-XCD work counter)
+      const int rc = icv_gemm256p_dispatch(A, lda, W, ldw, bias, M, N, K, epilogue, out, ldo, nsplit, split_stride, resid, ldr, gate, mode,
+                                           (hipStream_t)stream);
+      if (rc >= 0) return rc;
+      return icv_gemm256_dispatch(A, lda, W, ldw, bias, M, N, K, epilogue, out, ldo, nsplit, split_stride, resid, ldr, gate, (hipStream_t)stream);
     }
     bool use256 = mode == 1;
     if (mode == 2) {
@@ -249,6 +246,15 @@ extern "C" int icv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t 
       // padding waste of the partial last m-tile
       const double use_m256 = (double)M / (double)(((M + 255) / 256) * 256), use_m128 = (double)M / (double)(((M + 127) / 128) * 128);
       use256 = eff256 * use_m256 >= eff128 * use_m128;
+    }
+    // the persistent form of the same kernel (gemm256p.hip) where it measures faster: bf16 / GELU epilogues (nothing but stores
+    // after the main loop, so the next tile's prologue hides under them: +1.5...2.9 % at 14B, +3...5 % at 1.3B) with at least two
+    // tiles per CU; bit-identical results.  gemm256_persist = 0 switches it off.
+    if (use256 && mode == 2 && (epilogue == ICV_EPI_BF16 || epilogue == ICV_EPI_GELU_BF16) && icv_get_option_int("gemm256_persist", 1) != 0 &&
+        (int64_t)((M + 255) / 256) * (N / 256) >= 2 * (int64_t)icv_gemm256p_cus()) {
+      const int rc = icv_gemm256p_dispatch(A, lda, W, ldw, bias, M, N, K, epilogue, out, ldo, nsplit, split_stride, resid, ldr, gate, 6,
+                                           (hipStream_t)stream);
+      if (rc >= 0) return rc;      // -1: no counter block for this stream right now -> the one-tile-per-block launch below
     }
     if (use256)
       return icv_gemm256_dispatch(A, lda, W, ldw, bias, M, N, K, epilogue, out, ldo, nsplit, split_stride,

@@ -1,12 +1,26 @@
-// EXPERIMENT (round 5, VERDICT r4 item 6 "one more bounded, different attempt"): gemm256's default schedule as a PERSISTENT kernel.
-// One work-group per CU loops over its tiles; the prologue DMAs of tile i+1 (6 of the 8 units of its first two K-tiles) are issued
+// gemm256's default schedule as a PERSISTENT kernel (round 5; VERDICT r4 item 6 "one more bounded, different attempt").
+// One work-group per CU loops over tiles; the prologue DMAs of tile i+1 (6 of the 8 units of its first two K-tiles) are issued
 // BEFORE the epilogue of tile i, so the block launch, the first operand fetch and the pipeline fill of every tile but the first
-// run under the previous tile's stores / residual loads.  Per 256x256 tile of the 14B shapes the main loop is ~ 122 us of a
-// ~ 127 us tile slot; what is left outside it is what this variant can hide.
-// Same tile geometry, LDS image, swizzle, two-phase main loop, counted vmcnt and wave-group stagger as gemm256.hip (MF = 16, SCH = 3);
-// tile order: XCD x owns the same contiguous range of the grouped tile order as in the one-tile-per-block launch, its 32 work-groups
-// stride through it together, so the set of tiles in flight per XCD (and with it the L2 picture) is unchanged.
-// Selected with icv_set_option("gemm256", 5) in a library built with ICV_EXPERIMENTS=1.
+// run under the previous tile's stores.  Per 256x256 tile of the 14B shapes the main loop is ~ 122 us of a ~ 127 us tile slot;
+// what is left outside it is what this variant hides.
+// Same tile geometry, LDS image, swizzle, two-phase main loop, counted vmcnt and wave-group stagger as gemm256.hip (MF = 16, SCH = 3),
+// bit-identical results (same MFMA order per accumulator).  Tile order: XCD x owns the same contiguous range of the grouped tile
+// order as in the one-tile-per-block launch; its work-groups take the next tile of that range from a per-XCD counter when they START
+// their current tile (DYN), so tiles start in the order in which CUs free up - as with the hardware's own dispatch - and the set of
+// tiles in flight per XCD (the L2 picture) is unchanged.  With a static stride instead (DYN = false, option gemm256 = 5) the XCD's
+// work-groups drift apart and lose their shared panels: -6 % on QKV / FFN1.
+// Measured, same box, interleaved (profiles/r05/gemm_persistent_ab.txt): bf16 / GELU epilogues +1.5...2.9 % on the 14B shapes,
+// +3...5 % on the 1.3B ones, +2.2 % at the sp4 shard; gated-residual epilogue -0.5...2.1 % (its residual loads compete with the
+// prologue).  So icv_gemm_bf16 uses this kernel for the bf16 / GELU epilogues when a launch has at least two tiles per CU, and
+// gemm256.hip otherwise (option gemm256_persist = 0 switches it off; gemm256 = 5 / 6 force it for every epilogue).
+//
+// The work counters are STATELESS between launches: a 64-byte block (8 per-XCD counters + an exit counter) that every launch finds
+// zeroed and whose last-exiting work-group zeroes again - safe under hipGraph replay; one block per (device, stream) from a pool that
+// is allocated outside stream capture, so launches on different streams never share counters.
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "icv_common.h"
 
 namespace g256p {
@@ -27,11 +41,9 @@ struct Params {
   const float* gate;
   int tiles_m, tiles_n;
   int gm;
-  // DYN: the next tile of an XCD's range is taken from a per-XCD counter when a work-group starts its current tile (the order in which
-  // tiles start then follows the order in which CUs free up, as with the hardware's own dispatch); ctr[x] only ever grows, base[x] is
-  // its value before this launch (the host adds len_x + L_x per launch: every work-group ends with exactly one failing fetch)
-  unsigned long long* ctr;
-  unsigned long long base[8];
+  // DYN: the next tile of an XCD's range is taken from a per-XCD counter when a work-group starts its current tile.  ctr[0..7] = the
+  // counters, ctr[8] = work-groups that have left; all zero at launch, zeroed again by the last work-group to leave.
+  unsigned* ctr;
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -116,14 +128,27 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(Params p) {
   constexpr int FROWS = 16 * 128;
 
   auto fetch = [&]() -> int {          // DYN: index inside this XCD's range of the next tile to start (>= len: none left); block-uniform
-    if (tid == 0) next_li = (int)(atomicAdd(p.ctr + xcd, 1ull) - p.base[xcd]);
+    if (tid == 0) next_li = (int)atomicAdd(p.ctr + xcd, 1u);
     __syncthreads();
     const int v = next_li;
     __syncthreads();
     return v;
   };
+  auto leave = [&]() {                 // DYN: this work-group fetches no more; the last one to leave resets the block for the next launch
+    if (DYN && tid == 0) {
+      __threadfence();
+      if (atomicAdd(p.ctr + 8, 1u) == gridDim.x - 1) {
+        __threadfence();
+#pragma unroll
+        for (int x = 0; x < 9; ++x) atomicExch(p.ctr + x, 0u);
+      }
+    }
+  };
   int li = DYN ? fetch() : l0;
-  if (li >= len) return;
+  if (li >= len) {
+    leave();
+    return;
+  }
   int64_t m0, n0;
   unsigned offA[2][2], offB[2][2];
   tile_of(start + li, m0, n0);
@@ -252,6 +277,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(Params p) {
     if (li_next >= len) break;
     li = li_next;
   }
+  leave();
 }
 
 template <int EPI, bool DYN>
@@ -262,44 +288,60 @@ int launch1(const Params& p, unsigned grid, hipStream_t st) {
   return icv_check_launch("icv_gemm_bf16(256p)");
 }
 
+// ---- counter blocks: one per (device, stream), from a per-device pool allocated outside stream capture ----
+constexpr int kBlockWords = 16, kPoolBlocks = 64;
+struct CounterPool {
+  unsigned* base = nullptr;
+  int used = 0;
+  bool failed = false;
+};
+std::mutex g_mu;
+std::map<int, CounterPool> g_pools;
+std::map<std::pair<int, hipStream_t>, unsigned*> g_blocks;
+
+// nullptr = no block available right now (pool not yet allocated while `st` is capturing, pool exhausted, allocation failed):
+// the caller launches the one-tile-per-block kernel instead - never an error.
+unsigned* counters_for(hipStream_t st) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_blocks.find({dev, st});
+  if (it != g_blocks.end()) return it->second;
+  CounterPool& pool = g_pools[dev];
+  if (!pool.base) {
+    if (pool.failed) return nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      return nullptr;                                        // no allocation inside a capture; a later eager launch makes the pool
+    }
+    const size_t bytes = (size_t)kPoolBlocks * kBlockWords * sizeof(unsigned);
+    if (hipMalloc((void**)&pool.base, bytes) != hipSuccess || hipMemset(pool.base, 0, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      pool.base = nullptr;
+      pool.failed = true;
+      return nullptr;
+    }
+  }
+  if (pool.used >= kPoolBlocks) return nullptr;
+  unsigned* blk = pool.base + (size_t)(pool.used++) * kBlockWords;
+  g_blocks[{dev, st}] = blk;
+  return blk;
+}
+
 template <int EPI>
 int launch(Params& p, int n_cu, bool dyn, hipStream_t st) {
   const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
   const unsigned grid = (unsigned)(nwg < n_cu ? nwg : n_cu);
   if (!dyn) return launch1<EPI, false>(p, grid, st);
-  // per-XCD counters: one device allocation for the life of the process, never reset (see Params); launches of this kernel are
-  // assumed not to overlap on the device (true for the DiT's single launch stream)
-  static unsigned long long* ctr = nullptr;
-  static unsigned long long issued[8] = {};
-  if (!ctr) {
-    if (hipMalloc((void**)&ctr, 8 * sizeof(unsigned long long)) != hipSuccess || hipMemset(ctr, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
-      icv_set_error("gemm256p: counter allocation failed");
-      return 2;
-    }
-  }
-  p.ctr = ctr;
-  const int q8 = (int)(nwg >> 3), r8 = (int)(nwg & 7);
-  for (int x = 0; x < 8; ++x) {
-    p.base[x] = issued[x];
-    const int len = q8 + (x < r8 ? 1 : 0);
-    const int Lx = x < (int)grid ? (int)((grid + 7 - x) >> 3) : 0;
-    issued[x] += (unsigned long long)len + (unsigned long long)Lx;       // every work-group of XCD x fetches until it fails once
-  }
+  p.ctr = counters_for(st);
+  if (!p.ctr) return -1;                                     // caller falls back to gemm256.hip
   return launch1<EPI, true>(p, grid, st);
 }
 
 }  // namespace g256p
 
-int icv_gemm256p_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int64_t M, int64_t N, int64_t K, int epilogue,
-                          void* out, int64_t ldo, int64_t nsplit, int64_t split_stride, const float* resid, int64_t ldr, const float* gate,
-                          hipStream_t st) {
-  g256p::Params p;
-  p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.bias = bias;
-  p.M = M; p.N = N; p.K = K; p.out = out; p.ldo = ldo; p.nsplit = nsplit; p.split_stride = split_stride;
-  p.resid = resid; p.ldr = ldr; p.gate = gate;
-  p.tiles_m = (int)((M + g256p::BM - 1) / g256p::BM);
-  p.tiles_n = (int)((N + g256p::BN - 1) / g256p::BN);
-  p.gm = icv_get_option_int("gemm256_gm", 4);
+int icv_gemm256p_cus() {
   static int n_cu = 0;
   if (!n_cu) {
     int dev = 0;
@@ -307,8 +349,24 @@ int icv_gemm256p_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
     if (n_cu <= 0) n_cu = 256;
   }
+  return n_cu;
+}
+
+// mode: 5 = static stride, 6 = per-XCD work counter.  Returns -1 (no error text) when mode 6 has no counter block for `st` right
+// now: the caller launches the one-tile-per-block kernel.
+int icv_gemm256p_dispatch(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int64_t M, int64_t N, int64_t K, int epilogue,
+                          void* out, int64_t ldo, int64_t nsplit, int64_t split_stride, const float* resid, int64_t ldr, const float* gate,
+                          int mode, hipStream_t st) {
+  g256p::Params p;
+  p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.bias = bias;
+  p.M = M; p.N = N; p.K = K; p.out = out; p.ldo = ldo; p.nsplit = nsplit; p.split_stride = split_stride;
+  p.resid = resid; p.ldr = ldr; p.gate = gate;
+  p.tiles_m = (int)((M + g256p::BM - 1) / g256p::BM);
+  p.tiles_n = (int)((N + g256p::BN - 1) / g256p::BN);
+  p.gm = icv_get_option_int("gemm256_gm", 4);
+  const int n_cu = icv_gemm256p_cus();
   const int cus = icv_get_option_int("gemm256p_cus", n_cu);
-  const bool dyn = icv_get_option_int("gemm256", 5) == 6;          // 5 = static stride, 6 = per-XCD work counter
+  const bool dyn = mode == 6;
   p.ctr = nullptr;
   switch (epilogue) {
     case ICV_EPI_BF16: return g256p::launch<ICV_EPI_BF16>(p, cus, dyn, st);

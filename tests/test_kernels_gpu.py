@@ -970,16 +970,31 @@ def test_attention_add_into_output(hip_ops, Sq, Skv, H):
     assert bool((o[Sq:] == 9.0).all()), "wrote past the last query row"
 
 
-@pytest.mark.parametrize("M,N,K,epi", [(256, 256, 64, "f32"), (300, 512, 192, "f32"), (1000, 768, 1536, "bf16"), (513, 1024, 512, "gelu"),
-                                       (640, 512, 1280, "resid"), (515, 768, 384, "split")])
+GEMM_VARIANT_CASES = [(256, 256, 64, "f32"), (300, 512, 192, "f32"), (1000, 768, 1536, "bf16"), (513, 1024, 512, "gelu"),
+                      (640, 512, 1280, "resid"), (515, 768, 384, "split")]
+
+
+@pytest.mark.parametrize("M,N,K,epi", GEMM_VARIANT_CASES)
 @pytest.mark.experiments
-@pytest.mark.parametrize("kernel", [3, 4, 5, 6])
+@pytest.mark.parametrize("kernel", [3, 4])
 def test_gemm_4wave_variant(hip_ops, M, N, K, epi, kernel):
     """gemm256w.hip (option gemm256 = 3): 4 waves x 128x128 wave tiles, accumulators pinned to AGPRs, fragments read one
-    half-phase ahead; gemm256x.hip (= 4): the same wave tiles with whole-tile double buffering and one barrier per K-tile;
-    gemm256p.hip (= 5 / 6, round 5): gemm256's default schedule as a persistent kernel (static stride / per-XCD work counter).
+    half-phase ahead; gemm256x.hip (= 4): the same wave tiles with whole-tile double buffering and one barrier per K-tile.
     Same results as the default kernels for every epilogue and for ragged M."""
     need_experiments(hip_ops)
+    _gemm_variant_case(hip_ops, M, N, K, epi, kernel)
+
+
+@pytest.mark.parametrize("M,N,K,epi", GEMM_VARIANT_CASES + [(5000, 2560, 128, "resid"), (6000, 2304, 192, "split"), (30000, 5120, 64, "resid")])
+@pytest.mark.parametrize("kernel", [5, 6])
+def test_gemm_persistent_forced_for_every_epilogue(hip_ops, M, N, K, epi, kernel):
+    """gemm256p.hip forced through the A/B switch (gemm256 = 5 static stride / 6 per-XCD work counter) for EVERY epilogue and for
+    launches smaller than the chip (the default uses it for the bf16 / GELU epilogues of large launches only): same results as
+    the fp32 reference for every epilogue, ragged M, the split-plane layout, one tile and several tiles per work-group."""
+    _gemm_variant_case(hip_ops, M, N, K, epi, kernel)
+
+
+def _gemm_variant_case(hip_ops, M, N, K, epi, kernel):
     a = rnd((M, K), 431).to(torch.bfloat16)
     w = rnd((N, K), 432, 1.0 / math.sqrt(K)).to(torch.bfloat16)
     bias = rnd((N,), 433, 0.1)
@@ -1011,6 +1026,78 @@ def test_gemm_4wave_variant(hip_ops, M, N, K, epi, kernel):
             assert_bf16_close(out, acc.reshape(M, 3, ns).permute(1, 0, 2), "gemm 4-wave split planes")
     finally:
         hip_ops.lib.icv_set_option(b"gemm256", 2)
+
+
+def _persist(hip_ops, on):
+    hip_ops.lib.icv_set_option(b"gemm256_persist", int(on))
+
+
+@pytest.mark.parametrize("M,N,K,epi,split", [(9360, 13824, 256, EPI_GELU_BF16, 0), (18000, 7680, 192, EPI_BF16, 0), (12345, 15360, 128, EPI_BF16, 5120),
+                                             (74880, 4608, 64, EPI_BF16, 1536)])
+def test_gemm_persistent_default_is_bit_identical_to_one_tile_per_block(hip_ops, M, N, K, epi, split):
+    """icv_gemm_bf16 runs the bf16 / GELU epilogues of launches with >= 2 tiles per CU on the persistent kernel (gemm256p.hip:
+    per-XCD work counters, next tile's prologue under the current epilogue).  Same MFMA order per accumulator, so the bytes must equal
+    the one-tile-per-block launch (gemm256_persist = 0) - for ragged M, the split-plane QKV layout and launch after launch on the same
+    stream (the counter block is found zeroed and left zeroed by every launch)."""
+    a = rnd((M, K), 441).to(torch.bfloat16).to(DEV)
+    w = rnd((N, K), 442, 1.0 / math.sqrt(K)).to(torch.bfloat16).to(DEV)
+    bias = rnd((N,), 443, 0.1).to(DEV)
+    shape = (N // split, M, split) if split else (M, N)
+    ref = torch.empty(shape, dtype=torch.bfloat16, device=DEV)
+    _persist(hip_ops, 0)
+    try:
+        hip_ops.gemm(a, w, bias, ref, epi, nsplit=split or None)
+    finally:
+        _persist(hip_ops, 1)
+    for rep in range(3):
+        out = torch.full(shape, 7.0, dtype=torch.bfloat16, device=DEV)
+        hip_ops.gemm(a, w, bias, out, epi, nsplit=split or None)
+        assert torch.equal(out, ref), f"persistent launch {rep} differs from the one-tile-per-block launch"
+    acc = a[:512].float() @ w.float().t() + bias
+    if epi == EPI_GELU_BF16:
+        acc = torch.nn.functional.gelu(acc, approximate="tanh")
+    got = (ref.permute(1, 0, 2).reshape(M, N) if split else ref)[:512]
+    assert_bf16_close(got, acc.cpu(), "persistent-default gemm vs fp32", abs_floor=2.0 ** -8)
+
+
+def test_gemm_persistent_under_graph_capture_and_on_two_streams(hip_ops):
+    """The persistent kernel's work counters are stateless between launches (zero at launch, zeroed by the last work-group to leave)
+    and come from a per-(device, stream) pool: (a) a hipGraph captured on a stream that never launched the kernel eagerly replays
+    correctly any number of times (a launch inside a capture that finds no pool falls back to the one-tile-per-block kernel);
+    (b) two streams launching at the same time do not share counters."""
+    M, N, K = 20000, 7680, 128
+    a = rnd((M, K), 451).to(torch.bfloat16).to(DEV)
+    w = rnd((N, K), 452, 1.0 / math.sqrt(K)).to(torch.bfloat16).to(DEV)
+    bias = rnd((N,), 453, 0.1).to(DEV)
+    ref = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    _persist(hip_ops, 0)
+    try:
+        hip_ops.gemm(a, w, bias, ref, EPI_BF16)
+    finally:
+        _persist(hip_ops, 1)
+    out = torch.zeros_like(ref)
+    hip_ops.gemm(a, w, bias, out, EPI_BF16)          # an eager launch first: the counter pool exists before the capture starts
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        hip_ops.gemm(a, w, bias, out, EPI_BF16)
+        hip_ops.gemm(a, w, bias, out, EPI_GELU_BF16)
+        hip_ops.gemm(a, w, bias, out, EPI_BF16)
+    for rep in range(3):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), f"graph replay {rep}"
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    o1, o2 = torch.zeros_like(ref), torch.zeros_like(ref)
+    for rep in range(4):
+        with torch.cuda.stream(s1):
+            hip_ops.gemm(a, w, bias, o1, EPI_BF16)
+        with torch.cuda.stream(s2):
+            hip_ops.gemm(a, w, bias, o2, EPI_BF16)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, ref) and torch.equal(o2, ref), "concurrent persistent launches on two streams"
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 4, 64), (3, 68, 64), (255, 252, 192), (257, 260, 128), (513, 256, 64)])

@@ -1,7 +1,8 @@
-"""A/B of the persistent-kernel experiment (csrc/experiments/gemm256p.hip, option gemm256 = 5) against the shipped gemm256 launch
-on the DiT's GEMM shapes at the rows the CFG-batched pair runs (2S): interleaved rounds in ONE process, median of the rounds, and a
-bit-for-bit check (same MFMA order per accumulator).  Needs the experiments build:
-    ICV_LIB_PATH=infinicube_amd/csrc/build/libicvideo_experiments.so python tools/gemm_persistent_ab.py"""
+"""A/B of the persistent GEMM kernel (csrc/gemm256p.hip; option gemm256 = 5 static stride / 6 per-XCD work counter, forced for EVERY
+epilogue) against the one-tile-per-block gemm256 launch (gemm256 = 1) on the DiT's GEMM shapes at the rows the CFG-batched pair runs
+(2S): interleaved rounds in ONE process, median of the rounds, and a bit-for-bit check (same MFMA order per accumulator).  The shipped
+default (gemm256 = 2) takes the work-counter kernel for the bf16 / GELU epilogues only.
+    python tools/gemm_persistent_ab.py"""
 import math, os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
