@@ -28,6 +28,15 @@ def label(name, grid, dur_us):
     """Human label of a dispatch group: self- vs cross-attention by duration, GEMM shapes by (epilogue, grid, duration)."""
     if "attn" in name:
         return "self-attention (K6)" if dur_us > 3000 else "cross-attention (K9)"
+    if "gemm256p" in name and DIMS:      # persistent launch (one work-group per CU): the grid says nothing about N; epilogue + duration do
+        d, f, _ = DIMS
+        epi = re.search(r"gemm256p_kernel<(\d)", name)
+        epi = int(epi.group(1)) if epi else -1
+        if epi == 1: return f"FFN1 GEMM + GELU [2S,{d}]x[{f},{d}] (K10), persistent"
+        if epi == 0:
+            qkv = dur_us > 2.0 * (2 * S) * d * (2 * d) / 1.3e15 * 1e6       # midway between N = d and N = 3d at ~1.3 PF/s
+            return f"QKV GEMM [2S,{d}]x[{3*d},{d}] (K4), persistent" if qkv else f"cross-q GEMM [2S,{d}]x[{d},{d}] (K9), persistent"
+        return f"gemm256p epi {epi}"
     if "gemm256" in name and DIMS:
         d, f, _ = DIMS
         epi = re.search(r"gemm256_kernel<(\d)", name)
