@@ -18,8 +18,8 @@ import torch
 
 # Default cap on RCCL's channel count for the K|V transports that run RCCL kernels (every channel = one resident work-group beside
 # an attention launch that runs one work-group per CU).  Measured on one MI355X (profiles/r05/kv_contention.md): the first
-# resident copy work-group already costs the shard-shape attention 10-21 %, the next seven add ~5 points, but 16+ jump to +22 % at
-# the sp8 shape; 8 channels move 150-190 GB/s, above what either layout needs to hide its exchange (sp8: 126 GB/s).
+# resident copy work-group that holds LDS already costs the shard-shape attention 6-18 %, the next seven add ~3 points; light ones are
+# nearly free up to 8 but cost +15-18 % from 16 on at the sp8 shape; 8 channels move 150-190 GB/s, above what either layout needs to hide its exchange (sp8: 126 GB/s).
 RCCL_MAX_CHANNELS_DEFAULT = 8
 
 

@@ -70,3 +70,26 @@ extern "C" int occ_masked_stream(const unsigned* mask, int words, void** stream)
   return 0;
 }
 extern "C" void occ_stream_destroy(void* s) { if (s) (void)hipStreamDestroy((hipStream_t)s); }
+
+// ---- probe: a stream wait WITHOUT a wave - hipLaunchHostFunc whose host function polls a host flag (tools/probe_hostfunc.py) ----
+#include <atomic>
+#include <chrono>
+#include <thread>
+namespace {
+struct HostWait { volatile uint32_t* flag; uint32_t value; std::atomic<int>* entered; };
+void host_wait_fn(void* arg) {
+  HostWait* w = (HostWait*)arg;
+  if (w->entered) w->entered->fetch_add(1);
+  const auto t0 = std::chrono::steady_clock::now();
+  while ((int32_t)(*w->flag - w->value) < 0) {
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) break;      // never hang the runtime's thread for good
+    std::this_thread::yield();
+  }
+  delete w;
+}
+}  // namespace
+// `stream` blocks (no wave) until *flag >= value: the host function runs on a runtime thread once the stream's earlier work is done
+extern "C" int occ_host_wait(void* stream, volatile uint32_t* flag, uint32_t value, void* entered_counter) {
+  HostWait* w = new HostWait{flag, value, (std::atomic<int>*)entered_counter};
+  return hipLaunchHostFunc((hipStream_t)stream, host_wait_fn, w) == hipSuccess ? 0 : 1;
+}
