@@ -10,8 +10,8 @@
 // tiles in flight per XCD (the L2 picture) is unchanged.  With a static stride instead (DYN = false, option gemm256 = 5) the XCD's
 // work-groups drift apart and lose their shared panels: -6 % on QKV / FFN1.
 // Measured, same box, interleaved (profiles/r05/gemm_persistent_ab.txt): bf16 / GELU epilogues +1.5...2.9 % on the 14B shapes,
-// +3...5 % on the 1.3B ones, +2.2 % at the sp4 shard; gated-residual epilogue -0.5...2.1 % (its residual loads compete with the
-// prologue).  So icv_gemm_bf16 uses this kernel for the bf16 / GELU epilogues when a launch has at least two tiles per CU, and
+// +3...5 % on the 1.3B ones, +1.3...2.4 % at the sp4 shard; gated-residual epilogue: a tie (+0.1...0.3 % once its register spills
+// were removed; -0.5...2.6 % before).  So icv_gemm_bf16 uses this kernel for the bf16 / GELU epilogues when a launch has at least two tiles per CU, and
 // gemm256.hip otherwise (option gemm256_persist = 0 switches it off; gemm256 = 5 / 6 force it for every epilogue).
 //
 // The work counters are STATELESS between launches: a 64-byte block (8 per-XCD counters + an exit counter) that every launch finds
@@ -222,12 +222,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(Params p) {
     // ---- the NEXT tile's first operands start moving now, under this tile's epilogue ----
     const int64_t cm0 = m0, cn0 = n0;
     const bool has_next = li_next < len;
-    if (has_next) {
+    // gated-residual epilogue: the next tile's offsets and prologue wait until the first half of the epilogue is done (its 16 residual
+    // loads + 64 accumulator registers + the offsets do not fit in 256 VGPRs together: computing the offsets here spilled 25 registers);
+    // the other epilogues only store, so their prologue starts right away
+    if (has_next && EPI != ICV_EPI_RESID_F32) {
       tile_of(start + li_next, m0, n0);
       offsets(m0, n0, offA, offB);
-      // gated-residual epilogue: its first half's 16 residual loads go out FIRST (they are consumed first and would otherwise queue
-      // behind 96 KB of prologue traffic); the other epilogues only store, so their prologue starts right away
-      if (EPI != ICV_EPI_RESID_F32) prologue(offA, offB);
+      prologue(offA, offB);
     }
 
     // ---- epilogue of the tile just computed (gemm256.hip's, for the four epilogues) ----
@@ -240,36 +241,46 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(Params p) {
     }
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
-      float4 rs[4][4];
-      if (EPI == ICV_EPI_RESID_F32) {
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-          const int64_t m = cm0 + wr * 128 + hf * 64 + ii * 16 + fr;
-          const int64_t mc = m < p.M ? m : p.M - 1;
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            rs[ii][j] = *reinterpret_cast<const float4*>(p.resid + mc * p.ldr + cn0 + wc * 64 + (j >> 1) * 32 + (j & 1) * 16 + kq * 4);
-        }
-        if (hf == 0 && has_next) prologue(offA, offB);
+      if (EPI == ICV_EPI_RESID_F32 && hf == 1 && has_next) {      // the first half's accumulators are dead: room for the offsets
+        tile_of(start + li_next, m0, n0);
+        offsets(m0, n0, offA, offB);
+        prologue(offA, offB);
       }
+      // gated residual: the residual rows are loaded in batches of 8 float4 (two 16-row fragments) ahead of their use - gemm256.hip batches
+      // 16, but this kernel carries the loop state of the persistent schedule on top and 16 spill 25 registers
 #pragma unroll
-      for (int ii = 0; ii < 4; ++ii) {
-        const int64_t m = cm0 + wr * 128 + hf * 64 + ii * 16 + fr;
-        if (m >= p.M) continue;
+      for (int qh = 0; qh < 2; ++qh) {
+        float4 rs[2][4];
+        if (EPI == ICV_EPI_RESID_F32) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int64_t n = cn0 + wc * 64 + (j >> 1) * 32 + (j & 1) * 16 + kq * 4;
-          const f32x4 a = acc[hf * 4 + ii][j];
-          float v0 = a[0] + bs[j].x, v1 = a[1] + bs[j].y, v2 = a[2] + bs[j].z, v3 = a[3] + bs[j].w;
-          const int64_t off = icv_out_offset(m, n, p.ldo, p.N, p.nsplit, p.split_stride);
-          if (EPI == ICV_EPI_BF16 || EPI == ICV_EPI_GELU_BF16) {
-            if (EPI == ICV_EPI_GELU_BF16) { v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3); }
-            *reinterpret_cast<uint2*>((bf16_t*)p.out + off) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-          } else if (EPI == ICV_EPI_RESID_F32) {
-            const float4 r = rs[ii][j];
-            *reinterpret_cast<float4*>((float*)p.out + off) = make_float4(r.x + gt[j].x * v0, r.y + gt[j].y * v1, r.z + gt[j].z * v2, r.w + gt[j].w * v3);
-          } else {
-            *reinterpret_cast<float4*>((float*)p.out + off) = make_float4(v0, v1, v2, v3);
+          for (int i2 = 0; i2 < 2; ++i2) {
+            const int64_t m = cm0 + wr * 128 + hf * 64 + (qh * 2 + i2) * 16 + fr;
+            const int64_t mc = m < p.M ? m : p.M - 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              rs[i2][j] = *reinterpret_cast<const float4*>(p.resid + mc * p.ldr + cn0 + wc * 64 + (j >> 1) * 32 + (j & 1) * 16 + kq * 4);
+          }
+        }
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+          const int ii = qh * 2 + i2;
+          const int64_t m = cm0 + wr * 128 + hf * 64 + ii * 16 + fr;
+          if (m >= p.M) continue;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int64_t n = cn0 + wc * 64 + (j >> 1) * 32 + (j & 1) * 16 + kq * 4;
+            const f32x4 a = acc[hf * 4 + ii][j];
+            float v0 = a[0] + bs[j].x, v1 = a[1] + bs[j].y, v2 = a[2] + bs[j].z, v3 = a[3] + bs[j].w;
+            const int64_t off = icv_out_offset(m, n, p.ldo, p.N, p.nsplit, p.split_stride);
+            if (EPI == ICV_EPI_BF16 || EPI == ICV_EPI_GELU_BF16) {
+              if (EPI == ICV_EPI_GELU_BF16) { v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3); }
+              *reinterpret_cast<uint2*>((bf16_t*)p.out + off) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+            } else if (EPI == ICV_EPI_RESID_F32) {
+              const float4 r = rs[i2][j];
+              *reinterpret_cast<float4*>((float*)p.out + off) = make_float4(r.x + gt[j].x * v0, r.y + gt[j].y * v1, r.z + gt[j].z * v2, r.w + gt[j].w * v3);
+            } else {
+              *reinterpret_cast<float4*>((float*)p.out + off) = make_float4(v0, v1, v2, v3);
+            }
           }
         }
       }
