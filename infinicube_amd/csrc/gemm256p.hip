@@ -300,7 +300,7 @@ int launch1(const Params& p, unsigned grid, hipStream_t st) {
 }
 
 // ---- counter blocks: one per (device, stream), from a per-device pool allocated outside stream capture ----
-constexpr int kBlockWords = 16, kPoolBlocks = 64;
+constexpr int kBlockWords = 16, kPoolBlocks = 256;      // 16 KiB per device; a stream handle keeps its block for the life of the process
 struct CounterPool {
   unsigned* base = nullptr;
   int used = 0;
