@@ -19,6 +19,8 @@
 //     command-processor packet: it is resident only for the skew between the two ranks (they run the same program), and it is
 //     the rows, not the flags, whose movement would otherwise occupy CUs for the whole transfer.  Sequence numbers only grow, so a
 //     late waiter can never miss a publish and no host handshake is needed;
+//   * a rank's OWN rows reach its gathered buffer by a local copy on a stream of its own (behind the same point of the launch
+//     stream as the pulls), so nothing of the exchange sits in the launch stream between two projections;
 //   * the reverse hazard (the producer's next layer overwriting rows a slow peer is still pulling) is closed the same way:
 //     each pull stream writes "pulled up to ticket k" into done[consumer][producer] behind its copy, and
 //     icv_ipc_acquire makes the producer's launch stream wait for every peer's counter before the K|V GEMM of the next layer.
@@ -74,7 +76,7 @@ struct icv_ipc {
   bool own_heap = false;               // hipMalloc'ed here (heap == NULL at create) or borrowed from the caller
   std::vector<char*> peer;             // address of every rank's heap as THIS process sees it ([rank] = own heap)
   std::vector<void*> peer_base;        // what hipIpcOpenMemHandle returned (the allocation the peer's heap lives in)
-  std::vector<hipStream_t> pull;       // one pull stream per peer
+  std::vector<hipStream_t> pull;       // one pull stream per peer; [rank] = the stream of this rank's own rows (a local copy)
   std::vector<hipEvent_t> landed;      // [peer * kSlots + slot]: that peer's chunk of the ticket in this slot has landed
   hipEvent_t started[kSlots] = {};     // launch-stream position at gather_start (the pulls' destination is free from there)
   uint32_t* flags_host = nullptr;      // mmap of the shared segment
@@ -134,8 +136,7 @@ extern "C" int icv_ipc_create(const char* shm_name, int rank, int world, void* h
   c->peer[rank] = c->heap;
   c->pull.assign(world, nullptr);
   c->landed.assign((size_t)world * kSlots, nullptr);
-  for (int p = 0; p < world; ++p) {
-    if (p == rank) continue;
+  for (int p = 0; p < world; ++p) {      // p == rank too: this rank's own rows travel on their own stream, off the launch stream
     ICV_IPC_TRY(hipStreamCreateWithFlags(&c->pull[p], hipStreamNonBlocking), "hipStreamCreateWithFlags");
     for (int s = 0; s < kSlots; ++s) ICV_IPC_TRY(hipEventCreateWithFlags(&c->landed[(size_t)p * kSlots + s], hipEventDisableTiming), "hipEventCreateWithFlags");
   }
@@ -235,8 +236,14 @@ extern "C" int icv_ipc_gather_start(icv_ipc* c, int64_t src_offset, int64_t byte
     ICV_IPC_RUN(hipStreamWriteValue32(ps, c->done(c->rank, p), (uint32_t)(k + 1), 0), "hipStreamWriteValue32(done)");
     ICV_IPC_RUN(hipEventRecord(c->landed[(size_t)p * kSlots + slot], ps), "hipEventRecord(landed)");
   }
-  // own rows: a local copy in launch-stream order
-  ICV_IPC_RUN(hipMemcpyAsync(dst + (int64_t)c->rank * bytes, c->heap + src_offset, (size_t)bytes, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync(own rows)");
+  // own rows: a local copy (a short blit kernel) behind the same `started` point, on its own stream - on the launch stream it sat
+  // between the K|V projection and the Q projection of every layer (2 % of a layer at the sp8 shard shapes)
+  {
+    hipStream_t ps = c->pull[c->rank];
+    ICV_IPC_RUN(hipStreamWaitEvent(ps, c->started[slot], 0), "hipStreamWaitEvent(started)");
+    ICV_IPC_RUN(hipMemcpyAsync(dst + (int64_t)c->rank * bytes, c->heap + src_offset, (size_t)bytes, hipMemcpyDeviceToDevice, ps), "hipMemcpyAsync(own rows)");
+    ICV_IPC_RUN(hipEventRecord(c->landed[(size_t)c->rank * kSlots + slot], ps), "hipEventRecord(landed)");
+  }
   c->waited[slot] = false;
   c->next_ticket = k + 1;
   *ticket = k;
@@ -249,17 +256,19 @@ extern "C" int icv_ipc_gather_wait(icv_ipc* c, int64_t ticket, void* stream) {
   ICV_REQUIRE(ticket >= 0 && ticket < c->next_ticket && ticket >= c->next_ticket - kSlots, "icv_ipc_gather_wait: ticket %lld is not in flight (next %lld)",
               (long long)ticket, (long long)c->next_ticket);
   const int slot = (int)(ticket % kSlots);
-  for (int p = 0; p < c->world; ++p) {
-    if (p == c->rank) continue;
+  for (int p = 0; p < c->world; ++p)      // every peer's chunk and this rank's own
     ICV_HIP_OK(hipStreamWaitEvent((hipStream_t)stream, c->landed[(size_t)p * kSlots + slot], 0), "hipStreamWaitEvent(landed)");
-  }
   c->waited[slot] = true;
   return 0;
 }
 
 extern "C" int icv_ipc_acquire(icv_ipc* c, void* stream) {
   ICV_REQUIRE(c, "icv_ipc_acquire: null argument");
-  if (c->next_ticket == 0 || c->world == 1) return 0;
+  if (c->next_ticket == 0) return 0;
+  // this rank's own copies read the heap rows too (their stream is in order: the latest one covers the earlier ones)
+  ICV_HIP_OK(hipStreamWaitEvent((hipStream_t)stream, c->landed[(size_t)c->rank * kSlots + (int)((c->next_ticket - 1) % kSlots)], 0),
+             "hipStreamWaitEvent(own rows read)");
+  if (c->world == 1) return 0;
   ICV_REQUIRE(c->world <= 64, "icv_ipc_acquire: at most 64 ranks");
   hipLaunchKernelGGL(wait_done_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint32_t*)c->done(0, c->rank), c->world, c->rank, (uint32_t)c->next_ticket);
   return icv_check_launch("icv_ipc_acquire");
