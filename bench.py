@@ -298,6 +298,14 @@ def main():
         raise SystemExit(rc)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        # read when HIP / HSA initialise, i.e. at this process's FIRST HIP call (torch.cuda.is_available() is one): set here, before
+        # anything touches the device, and in the supervised rank's environment before it exists (launch_guard._run_attempt).
+        # The copy-engine K|V transport keeps one pull stream per peer next to the launch stream, and a pull that waits for its
+        # peer's flag is a spinning kernel that blocks its HARDWARE queue (profiles/r05/kv_contention.md, "pending waits"): enough
+        # queues that neither the launch stream nor another peer's copy ever sits behind one (7 pulls + launch + torch / RCCL streams)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world > 1 and not guard.supervised() and os.environ.get("ICV_BENCH_GUARD", "1") == "1":
         raise SystemExit(supervise(args, world, rank))
     if world != args.gpus:
@@ -335,12 +343,6 @@ def run_rank(args, world, rank, phase, stdout_fd):
     # one process per GPU.  ICV_BENCH_SHARE_GPU=1 (+ ICV_DIST_BACKEND=gloo) lets several ranks share the only GPU of a
     # development box so the N>1 code path can be exercised there; it is never a measurement mode.
     share = os.environ.get("ICV_BENCH_SHARE_GPU", "0") == "1"
-    if world > 1:
-        # the copy-engine K|V transport keeps one pull stream per peer next to the launch stream, and a pull that waits for its peer's
-        # flag is a spinning kernel that blocks its HARDWARE queue (measured: profiles/r05/kv_contention.md, "pending waits"): enough
-        # queues that neither the launch stream nor another peer's copy ever sits behind one (7 pulls + launch + torch / RCCL streams;
-        # read when HIP initialises)
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     dev_index = local_rank % torch.cuda.device_count() if share else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)

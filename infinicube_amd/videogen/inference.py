@@ -11,6 +11,7 @@ tests/golden/boundary_trace.json, captured from the reference wrapper itself.
 from __future__ import annotations
 
 import os
+import sys
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -62,8 +63,8 @@ class WanVideoGenerator:
         self.torch_dtype = torch_dtype
         self.buffer_channels = buffer_channels
 
-        # N-GPU mode behind the unchanged caller: ICV_WORLD=N starts N-1 persistent per-GPU workers that build the same
-        # generator (multigpu.py); they load their weights while this process loads its own
+        # N-GPU mode behind the unchanged caller: ICV_WORLD=N starts N fresh per-GPU worker processes (rank 0 included) that
+        # build this same generator (multigpu.py); this process becomes their client and loads nothing itself
         from . import multigpu
         self._pool = None
         world = multigpu.requested_world()
@@ -71,6 +72,11 @@ class WanVideoGenerator:
             self._pool = multigpu.pool_for(world, dict(
                 checkpoint_path=checkpoint_path, device=device, torch_dtype=torch_dtype, buffer_channels=buffer_channels,
                 enable_vram_management=enable_vram_management, use_wan_1pt3b=use_wan_1pt3b))
+        if self._pool is not None:
+            # settings only (sent with every request); layout / K|V transport = the plan that passed the pool's start-up probe
+            self.pipe = self._pool.client_pipeline(device, torch_dtype)
+            sys.stdout.write(self._pool.construction_log)     # rank 0's constructor lines = what the code below prints
+            return
 
         model_id, shown = _BASE_MODELS[bool(use_wan_1pt3b)]
         print(f"Loading {shown} base model...")
@@ -88,10 +94,6 @@ class WanVideoGenerator:
             print("Enabling VRAM management...")
             self.pipe.enable_vram_management()
 
-        if self._pool is not None:
-            # layout / K|V transport that passed the pool's start-up probe (sent to the workers with every request)
-            self.pipe.parallelism, self.pipe.kv_exchange = self._pool.plan
-            self._pool.wait_ready()
         print("✓ WanVideoGenerator initialization complete")
 
     # A2 ---------------------------------------------------------------------------------------
@@ -144,14 +146,16 @@ class WanVideoGenerator:
         coordinate_frames = self._ndarray_to_pil_list(coordinate_buffer)
 
         print("Executing video generation...")
-        if self._pool is not None:     # the other ranks run the same request on their token shards / CFG branch
+        if self._pool is not None:     # the N ranks behind this generator run the request; rank 0's frames come back
             if seed is None:           # unseeded call: ONE drawn seed for every rank (each would otherwise draw its own noise)
                 seed = int.from_bytes(os.urandom(7), "little")
-            self._pool.generate(semantic_buffer, coordinate_buffer,
-                                dict(prompt=prompt, negative_prompt=negative_prompt, seed=seed, tiled=tiled), self.pipe)
-        video = self.pipe(prompt=prompt, negative_prompt=negative_prompt, semantic_buffer_video=semantic_frames,
-                          coordinate_buffer_video=coordinate_frames, height=height, width=width,
-                          num_frames=num_frames, seed=seed, tiled=tiled)
+            frames = self._pool.generate(semantic_buffer, coordinate_buffer,
+                                         dict(prompt=prompt, negative_prompt=negative_prompt, seed=seed, tiled=tiled), self.pipe)
+            video = [Image.fromarray(f, mode="RGB") for f in frames]
+        else:
+            video = self.pipe(prompt=prompt, negative_prompt=negative_prompt, semantic_buffer_video=semantic_frames,
+                              coordinate_buffer_video=coordinate_frames, height=height, width=width,
+                              num_frames=num_frames, seed=seed, tiled=tiled)
 
         if output_path is not None and _is_rank0():
             print(f"Saving video to: {output_path}")

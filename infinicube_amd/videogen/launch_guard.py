@@ -214,6 +214,10 @@ class Supervisor:
         env = dict(os.environ)
         env.pop("TORCHELASTIC_USE_AGENT_STORE", None)        # the workers' own rendezvous: rank 0's worker hosts its store
         env.update(att.env)
+        # the HIP runtime's own variables are read at the rank's first HIP call: they belong in its environment BEFORE it exists
+        # (hardware queues for the copy-engine K|V transport's pull streams; dmabuf IPC for RCCL / hipIpc handles)
+        env.setdefault("GPU_MAX_HW_QUEUES", "16")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.update(ICV_GUARD_ROLE="worker", ICV_GUARD_ATTEMPT=str(k), ICV_GUARD_LABEL=att.label, ICV_GUARD_PHASE_FILE=phase_file,
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(self.rank), WORLD_SIZE=str(self.world))
         if self.rank == 0:

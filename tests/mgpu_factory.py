@@ -21,7 +21,7 @@ def factory(torch_dtype, device, model_configs):
 
 
 def failing_factory(torch_dtype, device, model_configs):
-    """Workers (ICV_WORKER_RANK set) fail while building their pipeline; rank 0 builds normally."""
+    """Ranks of a worker pool (ICV_WORKER_RANK set) fail while building their pipeline; a plain process builds normally."""
     import os
     if os.environ.get("ICV_WORKER_RANK") is not None:
         raise RuntimeError("synthetic worker failure while loading the checkpoint")

@@ -388,8 +388,9 @@ def test_bench_line_for_n_gpus(launcher):
     assert d["scaling"] == "strong" and d["value"] > 0
 
 
-def _pool_frames(tmp_path, monkeypatch, n, backend, share, factory="gpu_factory", max_diff=2, max_frac=0.02, max_mean=None):
-    """Frames of the single-GPU generator and of the same generator behind an n-rank worker pool (ICV_WORLD=n)."""
+def _pool_frames(tmp_path, monkeypatch, n, backend, share, factory="gpu_factory", max_diff=2, max_frac=0.02, max_mean=None, check=None):
+    """Frames of the single-GPU generator and of the same generator behind an n-rank worker pool (ICV_WORLD=n).
+    ``check(generator, frames)`` runs while the pool is alive."""
     import contextlib
     import io
     import numpy as np
@@ -421,10 +422,14 @@ def _pool_frames(tmp_path, monkeypatch, n, backend, share, factory="gpu_factory"
     g = None
     try:
         g, got = run()
-        assert dist.is_initialized() and dist.get_world_size() == n and dist.get_backend() == backend and g._pool is not None
+        # the caller's process is the pool's client: no process group here, N fresh processes behind it
+        assert not dist.is_initialized() and g._pool is not None and g._pool.world == n and g._pool.backend == backend
+        assert all(r["GPU_MAX_HW_QUEUES"] == "16" and not r["hip_initialised_at_start"] for r in g._pool.plan_record()["ranks"])
         d = np.abs(ref.astype(np.int16) - got.astype(np.int16))
         assert d.max() <= max_diff and (d > 0).mean() < max_frac, f"{n}-rank frames differ from the single-GPU frames: max {d.max()}, {100 * (d > 0).mean():.2f} % pixels"
         assert max_mean is None or d.mean() <= max_mean, f"mean |diff| {d.mean():.3f} levels"
+        if check is not None:
+            check(g, got)
     finally:
         if g is not None and g._pool is not None:
             g._pool.close()
@@ -440,16 +445,50 @@ def test_worker_pool_two_processes_sharing_the_gpu(tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_worker_pool_client_with_hip_already_initialised_four_ranks_copy_engine_transport(tmp_path, monkeypatch):
+    """The reference's caller has long initialised the GPU when it builds the generator
+    [R infinicube/inference/guidance_buffer_generation.py:459-460,626 vs :755-766].  Here the parent allocates and launches on
+    cuda:0 FIRST, then builds the generator with ICV_WORLD=4 (four ranks sharing the GPU), `sp` layout and the copy-engine
+    K|V transport forced: every rank - 0 included - must be a fresh process whose runtime initialised under
+    GPU_MAX_HW_QUEUES=16 / HSA_ENABLE_IPC_MODE_LEGACY=0 (the pool's plan record says so), the parent must have joined no
+    process group and keep its environment, and the frames must be BIT-IDENTICAL to the same four ranks on the collective
+    transport (the exchange only moves bytes) and equal the single-GPU frames to rounding."""
+    import numpy as np
+    x = torch.randn(512, 512, device="cuda:0")
+    y = (x @ x).sum().item()                                     # the caller's own GPU work, before the generator exists
+    assert torch.cuda.is_initialized() and y == y
+    env_before = {k: os.environ.get(k) for k in ("GPU_MAX_HW_QUEUES", "NCCL_MAX_NCHANNELS", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    monkeypatch.setenv("ICV_PARALLELISM", "sp")
+    monkeypatch.setenv("ICV_WORLD_FALLBACK", "0")                # the forced plan or an error: no silent ladder in this test
+    frames = {}
+
+    def check_for(kv):
+        def check(g, got):
+            rec = g._pool.plan_record()
+            assert rec["plan"] == ["sp", kv] and rec["failed_plans"] == []
+            assert rec["client"]["hip_initialised"] is True and rec["client"]["joined_process_group"] is False
+            assert len(rec["ranks"]) == 4 and all(r["GPU_MAX_HW_QUEUES"] == "16" and r["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+                                                  and r["hip_initialised_at_start"] is False and r["device"] == "cuda:0" for r in rec["ranks"])
+            assert {k: os.environ.get(k) for k in env_before} == env_before
+            frames[kv] = got
+            print(f"pool plan record ({kv}): {json.dumps(rec)}")
+        return check
+
+    for kv in ("allgather", "ipc"):
+        monkeypatch.setenv("ICV_KV_EXCHANGE", kv)
+        _pool_frames(tmp_path, monkeypatch, 4, "gloo", share=True, check=check_for(kv))
+    assert np.array_equal(frames["ipc"], frames["allgather"]), "copy-engine transport behind the client differs from the collective transport"
+
+
+@pytest.mark.gpu
 def test_worker_pool_sharing_the_gpu_with_the_tiled_vae_dealt_to_the_ranks(tmp_path, monkeypatch):
-    """The same with the PRODUCT's tiled Wan-VAE (bf16, NDHWC, HIP norm kernel): both buffer encodes and the decode are shared out
-    over the two processes on the GPU (the worker joins the decode's broadcasts and returns nothing); frames against the
-    single-process generator.  The latents are identical (no K|V sharding at two ranks: one CFG branch per rank); the tiles the
-    OTHER process computed are not bit-identical to the ones this process would have computed (MIOpen's convolution kernels are
-    not reproducible across processes, search or no search - measured: up to 6 levels on 58 % of the bytes of a random-weight
-    VAE's frames), so the bar is a small mean difference and a bounded maximum, not equality (equality of the dealing itself
-    is proven on the CPU, tests/test_vae_shard.py)."""
-    monkeypatch.setenv("ICV_VAE_FIND", "0")
-    _pool_frames(tmp_path, monkeypatch, 2, "gloo", share=True, factory="gpu_real_vae_factory", max_diff=24, max_frac=1.01, max_mean=2.0)
+    """The same with the PRODUCT's tiled Wan-VAE (bf16, NDHWC volumes, every convolution on libicvideo's icv_conv3d_ndhwc): both
+    buffer encodes and the decode are shared out over the two processes on the GPU (the non-zero rank joins the decode's
+    broadcasts and returns nothing); frames against the single-process generator.  The latents are identical (no K|V sharding
+    at two ranks: one CFG branch per rank) and since round 5 no process picks its own convolution kernel (no MIOpen search:
+    the same HIP kernel in every process, tests/test_vae_shard.py asserts the dealt tiles bit-identical on the GPU), so the
+    bar is EQUALITY of the frames (rounds 2-4: max 24 levels, when MIOpen's per-process kernel choice moved the tiles)."""
+    _pool_frames(tmp_path, monkeypatch, 2, "gloo", share=True, factory="gpu_real_vae_factory", max_diff=0, max_frac=1e-9, max_mean=0.0)
 
 
 @pytest.mark.gpu

@@ -1,6 +1,7 @@
 """ICV_WORLD=N: the unchanged single-process caller [R infinicube/inference/guidance_buffer_generation.py:755-782]
-gets N ranks from inside the constructor (multigpu.WorkerPool).  Real processes over gloo on CPU; the whole path goes
-through WanVideoGenerator.generate -> WanVideoPipeline.__call__ on every rank."""
+gets N ranks from inside the constructor (multigpu.WorkerPool): N fresh worker processes, rank 0 included; the caller's
+process is their client (no process group, no environment writes).  Real processes over gloo on CPU; the whole path goes
+through WanVideoGenerator.generate -> WorkerPool.generate -> WanVideoPipeline.__call__ on every rank."""
 import contextlib
 import io
 import os
@@ -51,10 +52,22 @@ def test_generator_spawns_workers_and_matches_single_process(tmp_path, monkeypat
     monkeypatch.setenv("ICV_WORLD_TIMEOUT_S", "300")
     monkeypatch.setenv("PYTHONPATH", os.pathsep.join([os.path.dirname(HERE), HERE, os.environ.get("PYTHONPATH", "")]))
     g = None
+    env_before = dict(os.environ)
     try:
         g, got1, got2, out_multi, log_multi = _run(path, tmp_path, "multi.mp4")
         import torch.distributed as dist
-        assert dist.is_initialized() and dist.get_world_size() == world and g._pool is not None
+        # the caller's process is a CLIENT: it joined no process group, its environment was not written, and every rank - 0
+        # included - is a fresh process whose runtime initialised under the composed environment
+        assert not dist.is_initialized() and g._pool is not None and g._pool.world == world
+        assert dict(os.environ) == env_before, "the pool must not write the caller's environment"
+        rec = g._pool.plan_record()
+        assert rec["client"]["pid"] == os.getpid() and rec["client"]["joined_process_group"] is False
+        assert [r["rank"] for r in rec["ranks"]] == list(range(world)) and len({r["pid"] for r in rec["ranks"]} | {os.getpid()}) == world + 1
+        for r in rec["ranks"]:
+            assert r["GPU_MAX_HW_QUEUES"] == "16" and r["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and r["hip_initialised_at_start"] is False
+            assert r["NCCL_MAX_NCHANNELS"] == "8"          # the RCCL channel cap lives in the ranks' environments only
+        assert rec["plan"] == [g.pipe.parallelism, g.pipe.kv_exchange]
+        assert not hasattr(g.pipe, "dit") or g.pipe.dit is None, "the client loads no weights"
         assert log_multi == log_single.replace("single.mp4", "multi.mp4"), "the caller-visible progress lines must not change"
         assert os.path.getsize(out_multi) > 0
         # sharded attention reorders fp32 sums (and bf16 storage roundings can flip): frames agree to rounding
@@ -112,7 +125,7 @@ def test_device_literal_maps_to_local_rank(monkeypatch):
 
 def test_worker_that_dies_while_loading_is_reported(tmp_path, monkeypatch):
     """A worker that fails after joining the process group (missing checkpoint, out of memory, ...) must surface as an error
-    with ITS log in the caller within seconds, not as a collective timeout."""
+    with ITS traceback in the caller within seconds, not as a collective timeout."""
     import time
     import mgpu_factory as F
     from infinicube.videogen import WanVideoGenerator
@@ -138,7 +151,7 @@ def test_worker_that_dies_while_loading_is_reported(tmp_path, monkeypatch):
 
 @pytest.mark.parametrize("inject,want_plan,n_failed", [
     ("0:1:raise", ("sp", "allgather"), 1),               # world 3 + p2p requested: plan 0 = (sp, p2p) fails on a worker -> (sp, allgather)
-    ("0:0:hang,1:2:raise", None, 2),                     # rank 0 itself hangs in plan 0, a worker raises in plan 1 -> ONE GPU
+    ("0:0:hang,1:2:raise", None, 2),                     # rank 0 hangs in plan 0, rank 2 raises in plan 1 -> ONE GPU, in the caller's process
 ])
 def test_pool_start_falls_back_plan_by_plan(tmp_path, monkeypatch, capfd, inject, want_plan, n_failed):
     """The staged start of the worker pool (the mirror of bench.py's launch guard): every plan is probed on all ranks before any
@@ -168,7 +181,7 @@ def test_pool_start_falls_back_plan_by_plan(tmp_path, monkeypatch, capfd, inject
             assert np.array_equal(got1, ref1)
         else:
             assert g._pool is not None and g._pool.plan == want_plan and len(g._pool.failed_plans) == n_failed
-            assert dist.is_initialized() and dist.get_world_size() == 3
+            assert not dist.is_initialized() and g._pool.world == 3 and len(g._pool.plan_record()["ranks"]) == 3
             assert (g.pipe.parallelism, g.pipe.kv_exchange) == want_plan
             d = np.abs(ref1.astype(np.int16) - got1.astype(np.int16))
             assert d.max() <= 2
