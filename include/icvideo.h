@@ -29,8 +29,12 @@ extern "C" {
 /* 2: icv_unpatchify_cfg_euler gained `round_bf16` (a signature change a host built against 1 cannot detect otherwise);
  *    icv_dit_set_fp8 / icv_dit_set_seqpar and the e4m3 / sequence-parallel bind names were added. */
 /* 3: icv_ipc_* (the copy-engine K|V transport), icv_conv3d_ndhwc and the padded-volume VAE helpers were added; no existing
- *    signature changed. */
-#define ICV_ABI_VERSION 3
+ *    signature changed.
+ * 4: icv_attention_fwd_pieces (ONE arrival-gated attention launch per layer over K|V pieces), icv_ipc_arrival / _configure / _check /
+ *    _drain / _probe_copy (arrival flags, bounded device-side waits, teardown that does not depend on live peers, copy-engine-or-blit
+ *    probe), icv_flag_write; no existing
+ *    signature changed (icv_ipc_gather_wait accepts stream == NULL: bookkeeping only). */
+#define ICV_ABI_VERSION 4
 
 /* ---- library / device ------------------------------------------------------------------ */
 int icv_abi_version(void);
@@ -193,6 +197,38 @@ int icv_attention_fwd_chunk(const void* q, int64_t ldq, const void* k, int64_t l
                             int64_t ldv, void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml,
                             int64_t Sq, int64_t Skv, int64_t heads, float scale, int first, int last,
                             void* stream);
+
+/* ---- K6 for the sequence-parallel schedule, ARRIVAL-DRIVEN (SURVEY §8e "process K/V chunks in arrival order (own shard first)
+ * with online-softmax merging"): ONE launch per layer over a list of K|V pieces instead of one icv_attention_fwd_chunk launch per
+ * row chunk.  Replaces: the fork's / xDiT-USP's "all-gather K and V, then flash_attention" of a sequence-parallel DiT layer [EXT]
+ * (the reference runs one dense sequence on one GPU, [R infinicube/inference/guidance_buffer_generation.py:759-766]).
+ *   o bf16 [Sq, H*128] = softmax(q [k_0; k_1; ...]^T * scale) [v_0; v_1; ...]     (key order = piece order; irrelevant to the result
+ *   up to fp32 summation order)
+ * pieces: HOST array of n_pieces {k, v bf16 [rows, H*128] with row strides ldk / ldv, rows, flag, value}.  flag < 0: the rows are in
+ * place when the launch starts (this rank's own rows: listed FIRST, read where the K|V projection wrote them).  flag >= 0: the rows are
+ * there once (int32)(flags[flag] - value) >= 0, where `flags` is DEVICE-visible memory written behind the transfer (icv_ipc_arrival's
+ * words, or icv_flag_write on the stream that waited for a collective); the rows must not be read by anybody between the launch and that
+ * moment (they are not: nothing else consumes a gathered buffer).  A work-group that reaches a piece before its rows waits inside the
+ * kernel (one lane polls, s_sleep between polls); after timeout_us (0 = for ever) it stores 0x80000000 | piece index into *err
+ * (device-visible uint32, may be NULL; first time-out wins) and goes on with whatever bytes are there - a dead peer is an error the host
+ * finds in *err, never a hung queue.  Empty pieces (rows == 0) are skipped; at most ICV_ATTN_MAX_PIECES non-empty ones.
+ * trace (diagnostics, may be NULL): device u64 [heads * ceil(Sq/256)][n_pieces] <- s_memrealtime tick (100 MHz) at which that
+ * work-group started that piece. */
+#define ICV_ATTN_MAX_PIECES 64
+typedef struct icv_kv_piece {
+  const void* k;
+  const void* v;
+  int64_t rows;
+  int32_t flag;
+  uint32_t value;
+} icv_kv_piece;
+int icv_attention_fwd_pieces(const void* q, int64_t ldq, const icv_kv_piece* pieces, int64_t n_pieces, int64_t ldk, int64_t ldv,
+                             void* o, int64_t ldo, int64_t Sq, int64_t heads, float scale, const uint32_t* flags, uint32_t* err,
+                             int64_t timeout_us, void* trace, void* stream);
+/* flags[index] <- value with a system-scope release, enqueued on `stream` (one thread): the arrival flag of a piece whose rows were
+ * delivered by something `stream` has waited for (an RCCL collective, a copy); delay_us > 0 first holds the stream for that long
+ * (tests: a late peer). */
+int icv_flag_write(uint32_t* flags, int64_t index, uint32_t value, int64_t delay_us, void* stream);
 
 /* ---- K1: im2col for Conv3d(k = s = (1,2,2)) on a [C,T,H8,W8] f32 latent -------------------
  * out bf16 [n_tok, C*4] (ldo), row = token tok0 + r (f, hp, wp; wp fastest),
@@ -378,8 +414,9 @@ int icv_allgather_kv(icv_comm* comm, const void* rows, void* out, int64_t m, int
  * HEAP (same size everywhere) that holds its K|V rows; peers open it through hipIpc and PULL row chunks with
  * hipMemcpyAsync on one stream per peer (SDMA over the pair's xGMI link); readiness and reuse are flag words in a POSIX
  * shared-memory segment `shm_name` (mapped and hipHostRegister'ed by every rank) written with hipStreamWriteValue32 and
- * waited for with hipStreamWaitValue32 — no host round trip anywhere in the per-layer path (on current ROCm both stream
- * operations are small runtime kernels: the wait spins on one wave for the skew between two ranks; the ROWS move by SDMA).
+ * waited for by one-wave kernels with a deadline — no host round trip anywhere in the per-layer path (on current ROCm the
+ * runtime's own hipStreamWaitValue32 is such a spinning kernel too, without a deadline; the wait is resident for the skew
+ * between two ranks; the ROWS move by SDMA).
  *   every rank:  icv_ipc_create(name, rank, world, heap, heap_bytes, &ipc) — `heap` = a BORROWED device buffer of heap_bytes
  *                (it must stay alive until icv_ipc_destroy; the allocation containing it is what gets exported), or NULL
  *                to let the library hipMalloc one (icv_ipc_heap returns it); icv_ipc_export(ipc, handle) -> host ships the
@@ -406,6 +443,28 @@ int icv_ipc_gather_start(icv_ipc* ipc, int64_t src_offset, int64_t bytes, void* 
 int icv_ipc_gather_wait(icv_ipc* ipc, int64_t ticket, void* stream);
 int icv_ipc_acquire(icv_ipc* ipc, void* stream);
 int64_t icv_ipc_tickets(const icv_ipc* ipc);
+/* Arrival flags for icv_attention_fwd_pieces: *flags = DEVICE memory uint32 [world]; flags[p] >= t + 1 once the rows rank p
+ * contributed to ticket t have landed in that ticket's `out` (monotonic; entry [own rank] is never written: own rows are read in place).
+ * A consumer that gates on these calls icv_ipc_gather_wait(ipc, ticket, NULL) (bookkeeping only: no stream waits are enqueued).
+ * icv_ipc_configure(ipc, copy_own_rows): 0 = gather_start no longer copies this rank's own rows into `out` (the arrival-driven
+ * attention reads them from the heap). */
+int icv_ipc_arrival(icv_ipc* ipc, const uint32_t** flags);
+int icv_ipc_configure(icv_ipc* ipc, int copy_own_rows);
+/* Liveness (round 6).  Every device-side wait of the transport is a one-wave kernel with a deadline (ICV_IPC_WAIT_TIMEOUT_MS, default
+ * 30000, 0 = none): a wait that expires records whom it was waiting for and lets its queue go on with stale rows.
+ * icv_ipc_check: 0 = no wait of this rank has expired; otherwise non-zero and icv_last_error names the peer - the run is invalid from
+ * that exchange on (call it once per denoising step; it reads one host word).
+ * icv_ipc_drain(ipc, timeout_ms): give this rank's queues that long to finish on their own, then satisfy every wait word of the segment
+ * so that they do (0 = drained by themselves, 1 = released): teardown never depends on a live peer.  icv_ipc_destroy calls it
+ * (ICV_IPC_DRAIN_TIMEOUT_MS, default 5000). */
+int icv_ipc_check(icv_ipc* ipc);
+int icv_ipc_drain(icv_ipc* ipc, int timeout_ms);
+/* First-contact probe: is a pull of `bytes` from rank `peer`'s heap executed WITHOUT compute units?  An occupier kernel takes every
+ * wave slot of this device for ~8 ms; meanwhile a control kernel and the copy are enqueued on other streams.  *kind: 1 = the copy
+ * finished while no wave slot was free (a copy engine moved it), 2 = it did not (the runtime used a blit kernel: the transport then
+ * costs the overlapped attention CUs like an RCCL channel does), 0 = inconclusive (the control kernel got a slot).  *copy_ms
+ * (may be NULL): the copy's duration from events.  A diagnostic: ~20 ms, synchronises the device, not for the per-layer path. */
+int icv_ipc_probe_copy(icv_ipc* ipc, int peer, int64_t bytes, int* kind, double* copy_ms);
 /* a rank that cannot go on releases every peer wait that depends on it (its flag words jump past every sequence number: the
  * peers pull undefined bytes instead of spinning forever) and refuses further exchanges; the error itself travels by the host's
  * own channel.  Turns "one rank failed" from a hang on the others into an error on all. */

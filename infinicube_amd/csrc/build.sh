@@ -12,7 +12,7 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$root/include" -I"$here" -W
 objs=()
 pids=()
 mkdir -p "$here/build"
-srcs=(api elementwise gemm gemm256 gemm256p gemm_fp8 fp8 attention attn2 attn7 attn8 buffers voxels vae_ops dit_forward comm ipc conv)
+srcs=(api elementwise gemm gemm256 gemm256p gemm_fp8 fp8 attention attn2 attn7 attn7p attn8 buffers voxels vae_ops dit_forward comm ipc conv)
 tag=""
 if [[ "${ICV_EXPERIMENTS:-0}" == "1" ]]; then
   srcs+=(experiments/attn1 experiments/attn3 experiments/attn4 experiments/attn5 experiments/attn6 experiments/attn9 experiments/gemm256w experiments/gemm256x)

@@ -94,14 +94,27 @@ SIGNATURES.update({
     "icv_ipc_acquire": (c_int, [c_void_p, _P]),
     "icv_ipc_tickets": (c_int64, [c_void_p]),
     "icv_ipc_abort": (c_int, [c_void_p]),
+    "icv_ipc_arrival": (c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
+    "icv_ipc_configure": (c_int, [c_void_p, c_int]),
+    "icv_ipc_check": (c_int, [c_void_p]),
+    "icv_ipc_drain": (c_int, [c_void_p, c_int]),
+    "icv_ipc_probe_copy": (c_int, [c_void_p, c_int, _I, ctypes.POINTER(c_int), ctypes.POINTER(c_double)]),
+    "icv_attention_fwd_pieces": (c_int, [_P, _I, _P, _I, _I, _I, _P, _I, _I, _I, c_float, _P, _P, _I, _P, _P]),
+    "icv_flag_write": (c_int, [_P, _I, ctypes.c_uint32, _I, _P]),
     "icv_dit_profile": (c_int, [c_void_p, c_int]),
     "icv_dit_profile_read": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
 })
 
+class KVPiece(ctypes.Structure):
+    """icv_kv_piece of include/icvideo.h (icv_attention_fwd_pieces)."""
+    _fields_ = [("k", c_void_p), ("v", c_void_p), ("rows", c_int64), ("flag", ctypes.c_int32), ("value", ctypes.c_uint32)]
+
+
+ATTN_MAX_PIECES = 64   # ICV_ATTN_MAX_PIECES
 COMM_ID_BYTES = 128   # ICV_COMM_ID_BYTES
 IPC_HANDLE_BYTES = 72  # ICV_IPC_HANDLE_BYTES
 IPC_SLOTS = 32         # ICV_IPC_SLOTS
-ABI_VERSION = 3       # ICV_ABI_VERSION of include/icvideo.h
+ABI_VERSION = 4       # ICV_ABI_VERSION of include/icvideo.h
 
 _lib: Optional[ctypes.CDLL] = None
 

@@ -44,6 +44,23 @@ from .ops import BF16, EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_F32, F32, FP8
 from .scheduler import FlowMatchScheduler
 from .seqpar import BranchExchange, KVGather, ShardPlan, chunk_bounds  # noqa: F401
 
+ARRIVAL_SUFFIX = "+arrival"      # K|V exchange mode "<transport>+arrival": ONE arrival-gated attention launch per layer (csrc/attn7p.hip)
+
+
+def split_kv_mode(mode: Optional[str]):
+    """("ipc+arrival") -> ("ipc", True).  ICV_ATTN_ARRIVAL=1 / 0 forces the arrival-driven attention on / off for every mode."""
+    arrival = bool(mode) and mode.endswith(ARRIVAL_SUFFIX)
+    base = mode[: -len(ARRIVAL_SUFFIX)] if arrival else mode
+    env = os.environ.get("ICV_ATTN_ARRIVAL")
+    if env in ("0", "1"):
+        arrival = env == "1"
+    return (base or None), arrival
+
+
+class _ChunkBufs(list):
+    """The gathered row-chunks of one exchange + the local rows they were cut from (the arrival-driven attention reads its own rows in place)."""
+    own = None
+
 ACT_SILU = 1
 
 
@@ -307,8 +324,10 @@ class WanDiT:
             old = getattr(self, "kv_gather", None)
             if old is not None and old is not kv_gather and hasattr(old, "close"):
                 old.close()                                        # a copy-engine transport owns a heap and streams
-            self.kv_gather = kv_gather or KVGather(self.plan, group, kv_exchange)
-            self.sp_bounds = chunk_bounds(n, sp_chunks)
+            base_mode, arrival = split_kv_mode(kv_exchange)
+            self.kv_gather = kv_gather or KVGather(self.plan, group, base_mode)
+            self._sp_set_arrival(arrival)
+            self.sp_bounds = chunk_bounds(n, sp_chunks, self.sp_align)
             # e4m3 attention under sequence parallelism: ship e4m3 K|V (each rank quantises its own rows once) instead of bf16
             # rows that every rank re-quantises (ICV_FP8_WIRE=bf16 restores that order of operations)
             self.fp8_wire = (self.attn_fp8 and os.environ.get("ICV_FP8_WIRE", "e4m3") == "e4m3" and hasattr(ops, "attention_fp8_quantize_kv")
@@ -337,6 +356,8 @@ class WanDiT:
                 tot8 += rows8
         if hasattr(kg, "reserve"):
             kg.reserve(3 * n * 2 * d * 2 + 3 * tot8 * d + 4096, self.ops.device)
+        if getattr(self, "attn_arrival", False):
+            kg.enable_arrival(self.ops)      # after reserve(): the copy-engine transport's flags belong to its heap
         if hasattr(kg, "local_rows"):
             rows = lambda r, cols=2 * d, dt=BF16: kg.local_rows(r, cols, dt, self.ops.alloc)      # noqa: E731
         else:
@@ -353,6 +374,32 @@ class WanDiT:
         d = self.cfg.dim
         return (rows(tot8, d, torch.uint8), self.ops.alloc((self.plan.world * tot8, d), torch.uint8), self.ops.alloc((3, self.cfg.num_heads), F32))
 
+    def _sp_set_arrival(self, want: bool):
+        """Arrival-driven self-attention (csrc/attn7p.hip): bf16 attention on an operator set that has the kernel.  The
+        e4m3 mode keeps the chunked launches (its pieces kernel has no arrival gate)."""
+        ops = self.ops
+        self.attn_arrival = bool(want) and not self.attn_fp8 and hasattr(ops, "attention_pieces") and hasattr(self.kv_gather, "enable_arrival")
+        self.sp_align = 64 if self.attn_arrival else 1
+        self.sp_err = None
+        if self.attn_arrival:
+            if self._is_gpu():
+                self.sp_err = ops.alloc((1,), torch.int32)
+                self.sp_err.zero_()
+            self.sp_timeout_us = int(float(os.environ.get("ICV_ATTN_ARRIVAL_TIMEOUT_MS", "30000")) * 1000)
+
+    def check_exchange(self):
+        """Raise if the K|V exchange lost a peer: a device-side wait of the copy-engine transport or of the arrival-driven attention
+        gave up (both are bounded; what they computed since is garbage).  One host word + one 4-byte read-back: call per step at most."""
+        kg = getattr(self, "kv_gather", None)
+        if kg is not None and hasattr(kg, "check"):
+            kg.check()
+        err = getattr(self, "sp_err", None)
+        if err is not None:
+            e = int(err.item()) & 0xffffffff
+            if e:
+                raise RuntimeError(f"sequence-parallel attention gave up waiting for K|V piece {e & 0xffff} of a layer after "
+                                   f"{self.sp_timeout_us / 1e6:.0f} s (a peer is dead or stalled); the result is invalid")
+
     def _sp_acquire(self):
         """Before the K|V GEMM overwrites the local rows: wait for the peers' pulls of the previous layer (mode "ipc" only)."""
         kg = self.kv_gather
@@ -365,11 +412,13 @@ class WanDiT:
         if not self.sp_on:
             return self
         n = self.plan.n_tok
-        self.sp_bounds = chunk_bounds(n, sp_chunks)
         old = self.kv_gather
         if hasattr(old, "close"):
             old.close()
-        self.kv_gather = KVGather(self.plan, getattr(old, "group", None), mode)
+        base_mode, arrival = split_kv_mode(mode)
+        self.kv_gather = KVGather(self.plan, getattr(old, "group", None), base_mode)
+        self._sp_set_arrival(arrival)
+        self.sp_bounds = chunk_bounds(n, sp_chunks, self.sp_align)
         self._sp_local_rows()
         if self.attn_fp8:      # the e4m3 K/V side of the workspace is sized for the largest gathered chunk
             kv_rows = self.plan.world * max(b1 - b0 for b0, b1 in zip(self.sp_bounds[:-1], self.sp_bounds[1:]))
@@ -504,6 +553,8 @@ class WanDiT:
                 handles.append(self.kv_gather.start(blob, full))
             return handles, bufs
         kv_full = self.kv_full if kv_full is None else kv_full
+        bufs = _ChunkBufs()
+        bufs.own = kv_loc
         for c in range(len(b) - 1):
             r0, r1 = b[c], b[c + 1]
             full = kv_full[world * r0: world * r1]
@@ -517,6 +568,23 @@ class WanDiT:
         ops = self.ops
         att = self.att if att is None else att
         C = len(bufs)
+        if getattr(self, "attn_arrival", False):
+            # ONE launch over the pieces: this rank's own rows (in place, no flag) first, then every (row chunk, peer) in the order the
+            # exchange delivers them - chunk-major, peers starting with the right-hand neighbour (the order the pulls are issued in)
+            d, kg, world, rank = self.cfg.dim, self.kv_gather, self.plan.world, self.plan.rank
+            own = bufs.own
+            pieces, flags = [(own[:, :d], own[:, d:], -1, 0)], None
+            for c in range(C):
+                kf, vf = bufs[c]
+                m = kf.shape[0] // world
+                fl, entries = kg.arrival(handles[c])
+                flags = fl if fl is not None else flags
+                for j, idx, val in sorted(entries, key=lambda e: (e[0] - rank) % world):
+                    pieces.append((kf[j * m:(j + 1) * m], vf[j * m:(j + 1) * m], idx if fl is not None else -1, val))
+            ops.attention_pieces(q, pieces, att, H, scale, flags=flags, err=self.sp_err, timeout_us=self.sp_timeout_us)
+            for c in range(C):
+                kg.consumed(handles[c])
+            return
         wire = getattr(self, "fp8_wire", False)
         ws = self.attn8_ws
         if ws is not None:
@@ -912,6 +980,8 @@ class WanDiT:
                                          scheduler.dsigma(i), plan.tok0, plan.n_tok, round_bf16=round_bf16)
                 if on_step is not None:
                     on_step(i, latent)
+            if self.sp_on:
+                self.check_exchange()
             return latent
         use_cfg = ctx_uncond is not None and cfg_scale != 1.0
         twin, side = self._cfg_twin() if (use_cfg and self.dual_stream) else (None, None)
@@ -938,4 +1008,6 @@ class WanDiT:
                                      cfg_scale, scheduler.dsigma(i), plan.tok0, plan.n_tok, round_bf16=round_bf16)
             if on_step is not None:
                 on_step(i, latent)
+        if self.sp_on:
+            self.check_exchange()
         return latent

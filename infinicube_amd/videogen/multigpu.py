@@ -467,7 +467,7 @@ def probe_plan(plan, plan_index: int, rank: int, world: int, backend: str, layou
                     raise RuntimeError(f"group smoke test returned {dst.view(m, 4)[:, 0].tolist()}, expected {want}")
             if lay.sp_world > 1:       # the K|V transport of the plan, on 8 rows per rank
                 plan_s = lay.shard_plan(8 * lay.sp_world)
-                kg = KVGather(plan_s, lay.sp_group, "allgather" if kv == "auto" else kv)
+                kg = KVGather(plan_s, lay.sp_group, "allgather" if kv == "auto" else kv.split("+")[0])   # "+arrival" is the consumer's business
                 kg.reserve(1 << 16, dev)                 # the copy-engine transport keeps the rows in its symmetric heap
                 rows = kg.local_rows(8, 16, torch.bfloat16, lambda shape, dt: torch.empty(shape, dtype=dt, device=dev))
                 rows.fill_(float(lay.sp_rank + 1))

@@ -15,6 +15,8 @@ from typing import Optional
 
 import os
 
+import ctypes
+
 import torch
 
 from .. import native
@@ -308,6 +310,32 @@ class HipOps:
             native.ptr(o), o.stride(0) if o is not None else 0, native.ptr(acc),
             acc.stride(0) if acc is not None else 0, native.ptr(ml), q.shape[0], k.shape[0], heads, scale,
             int(first), int(last), self._stream()), "icv_attention_fwd_chunk")
+
+    def attention_pieces(self, q, pieces, o, heads: int, scale: float, flags=None, err=None, timeout_us: int = 0, trace=None):
+        """K6, arrival-driven (csrc/attn7p.hip): ONE launch over the K|V ``pieces`` = [(k, v, flag, value), ...] - k, v bf16 row views
+        with one common row stride each; flag < 0: the rows are in place now (this rank's own rows: list them FIRST); otherwise the rows
+        are there once (int32)(flags[flag] - value) >= 0 (``flags`` int32 / uint32 device tensor written behind the transfer).  A piece
+        that is late costs a bounded in-kernel wait; after ``timeout_us`` the kernel stores 0x80000000 | piece into ``err`` and goes on."""
+        _chk(q, BF16, "attention_pieces.q"); _chk(o, BF16, "attention_pieces.o")
+        arr = (native.KVPiece * len(pieces))()
+        ldk = ldv = None
+        for i, (k, v, flag, value) in enumerate(pieces):
+            if k.shape[0] == 0:
+                arr[i] = native.KVPiece(None, None, 0, -1, 0)
+                continue
+            _chk(k, BF16, "attention_pieces.k"); _chk(v, BF16, "attention_pieces.v")
+            assert ldk in (None, k.stride(0)) and ldv in (None, v.stride(0)), "attention_pieces: the pieces must share their row strides"
+            ldk, ldv = k.stride(0), v.stride(0)
+            arr[i] = native.KVPiece(k.data_ptr(), v.data_ptr(), k.shape[0], int(flag), int(value) & 0xffffffff)
+        native.check(self.lib.icv_attention_fwd_pieces(
+            q.data_ptr(), q.stride(0), ctypes.cast(arr, ctypes.c_void_p), len(pieces), ldk or 0, ldv or 0, o.data_ptr(), o.stride(0), q.shape[0], heads, scale,
+            native.ptr(flags), native.ptr(err), int(timeout_us), native.ptr(trace), self._stream()), "icv_attention_fwd_pieces")
+
+    def flag_write(self, flags, index: int, value: int, delay_us: int = 0, stream: Optional[int] = None):
+        """flags[index] <- value (system-scope release) on ``stream`` (default: the current one), optionally after holding it delay_us."""
+        assert flags.dtype in (torch.int32, torch.uint32) and flags.is_contiguous()
+        native.check(self.lib.icv_flag_write(flags.data_ptr(), index, int(value) & 0xffffffff, int(delay_us),
+                                             self._stream() if stream is None else stream), "icv_flag_write")
 
     def patchify(self, latent, out, tok0: int, n_tok: int):
         _chk(latent, F32, "patchify.latent"); _chk(out, BF16, "patchify.out")

@@ -373,7 +373,10 @@ class WanVideoPipeline:
             engine.forward_tokens(latent, ctx, 500.0, buf_tokens, engine.head_own, num_layers=min(2, engine.cfg.num_layers))
 
         modes = ("allgather", "p2p", "native", "ipc") if on_dev else ("allgather", "p2p")
-        cands = [(m, c) for m in modes for c in sorted({self.sp_chunks, 2}, reverse=True)]
+        # per transport: ONE arrival-gated attention launch per layer (dit.ARRIVAL_SUFFIX; bf16 attention only) and the chunked
+        # carried-state launches with sp_chunks and with 2 chunks
+        arrival = [] if (engine.attn_fp8 or os.environ.get("ICV_ATTN_ARRIVAL") == "0") else ["+arrival"]
+        cands = [(m + sfx, c) for m in modes for sfx, c in [(a, self.sp_chunks) for a in arrival] + [("", c) for c in sorted({self.sp_chunks, 2}, reverse=True)]]
         t0 = time.perf_counter()
         best, table = autotune_kv_exchange(engine, two_layers, sync, cands, reps=2, reduce_max=reduce_max)
         self.kv_autotune = dict(chosen=best, table=table, seconds=time.perf_counter() - t0)

@@ -174,6 +174,8 @@ class KVGather:
         if self.mode == "native":
             self._native = _NativeComm.for_group(self.dist, group, self.peers, plan.rank, plan.world)
         self._heap = None           # mode "ipc": the symmetric heap (made by reserve())
+        self._arrival_ops = None    # enable_arrival(): the consumer gates on arrival flags inside ONE attention launch per layer
+        self._flags, self._flag_seq, self._flag_stream = None, 0, None
 
     # ---- where the local K|V rows live ---------------------------------------------------------------------------------
     def reserve(self, nbytes: int, device) -> None:
@@ -213,18 +215,75 @@ class KVGather:
             self._heap.close()
             self._heap = None
 
+    def check(self) -> None:
+        """Raise if a device-side wait of the transport gave up (mode "ipc": a dead or stalled peer)."""
+        if self._heap is not None:
+            self._heap.check()
+
+    # ---- arrival-driven consumption (dit.WanDiT._sp_attention, csrc/attn7p.hip) ----------------------------------------------
+    ARRIVAL_SLOTS = 64
+
+    def enable_arrival(self, ops) -> None:
+        """From now on the consumer does not ``wait(handle)``: it asks ``arrival(handle)`` for the flag each peer's rows of that
+        row-chunk raise when they have landed and gates on them inside its own kernel (``ops.attention_pieces``), then calls
+        ``consumed(handle)``.  Mode "ipc": the transport's own per-peer device words (and this rank's rows are no longer copied into
+        the gathered buffer: the consumer reads them where they are).  The collective modes: ONE flag per row-chunk, written with
+        ``ops.flag_write`` by a side stream that waited for the chunk's work handles."""
+        self._arrival_ops = ops
+        if self._heap is not None:
+            self._heap.configure(copy_own_rows=False)
+            self._flags = self._heap.arrival_flags()
+        elif self.plan.world > 1 and torch.device(ops.device).type == "cuda":
+            self._flags = ops.alloc((self.ARRIVAL_SLOTS,), torch.int32)
+            self._flags.zero_()
+            self._flag_stream = torch.cuda.Stream(device=ops.device)
+
+    def arrival(self, handle):
+        """(flags, [(peer index j, flag index, value), ...]) for the peers' rows of this row-chunk (own rows excluded: in place);
+        flags None = the rows are there already (CPU twins: the handles were waited for on the host)."""
+        peers = [j for j in range(self.plan.world) if j != self.plan.rank]
+        if not handle or not peers:
+            return None, [(j, -1, 0) for j in peers]
+        w = handle[0]
+        if isinstance(w, _IpcWork):
+            return self._flags, [(j, j, w.ticket + 1) for j in peers]
+        if isinstance(w, _FlaggedWork):
+            return self._flags, [(j, w.slot, w.value) for j in peers]
+        for x in handle:           # no flag machinery (CPU): the host waits, the rows are simply there
+            x.wait()
+        return None, [(j, -1, 0) for j in peers]
+
+    def consumed(self, handle) -> None:
+        for w in handle:
+            if isinstance(w, _IpcWork):
+                w.consumed()
+
+    def _flagged(self, works):
+        """Collective modes under enable_arrival(): a side stream waits for the chunk and raises its flag."""
+        if self._flag_stream is None:
+            return tuple(works)
+        slot = self._flag_seq % self.ARRIVAL_SLOTS
+        self._flag_seq += 1
+        value = self._flag_seq
+        with torch.cuda.stream(self._flag_stream):
+            for w in works:
+                w.wait()
+            self._arrival_ops.flag_write(self._flags, slot, value)
+        return (_FlaggedWork(tuple(works), slot, value),)
+
     def start(self, rows: torch.Tensor, out: torch.Tensor):
         assert rows.is_contiguous() and out.is_contiguous() and out.shape[0] == self.plan.world * rows.shape[0]
         self.n_collectives += 1
         if self.mode == "native":
-            return (self._native.allgather(rows, out),)
+            return self._flagged((self._native.allgather(rows, out),))
         if self.mode == "ipc":
             return (self._heap.gather(rows, out),)
         if self.plan.world == 1:          # the one-rank rehearsal of the schedule (WanDiT.prepare(force_sp=True)): a local copy
-            out.copy_(rows)
+            if self._arrival_ops is None:
+                out.copy_(rows)
             return ()
         if self.mode == "allgather":
-            return (self.dist.all_gather_into_tensor(out, rows, group=self.group, async_op=True),)
+            return self._flagged((self.dist.all_gather_into_tensor(out, rows, group=self.group, async_op=True),))
         m, dist = rows.shape[0], self.dist
         if rows.is_cuda and dist.get_backend(self.group) != "nccl":
             # development set-ups only (gloo ranks sharing a GPU): gloo's send reads the device buffer from the host with no
@@ -233,11 +292,12 @@ class KVGather:
         p2p = []
         for j, peer in enumerate(self.peers):
             if j == self.plan.rank:
-                out[j * m:(j + 1) * m].copy_(rows)          # own rows: a local copy on the compute stream
+                if self._arrival_ops is None:
+                    out[j * m:(j + 1) * m].copy_(rows)      # own rows: a local copy on the compute stream
                 continue
             p2p.append(dist.P2POp(dist.isend, rows, peer, self.group))
             p2p.append(dist.P2POp(dist.irecv, out[j * m:(j + 1) * m], peer, self.group))
-        return tuple(dist.batch_isend_irecv(p2p))
+        return self._flagged(dist.batch_isend_irecv(p2p))
 
     def wait(self, handle) -> None:
         if self.timing is not None and torch.cuda.is_available():
@@ -370,6 +430,7 @@ class _IpcHeap:
             box = [name]
             dist.broadcast_object_list(box, src=peers[0], group=group)
             name = box[0]
+        self._shm_name = name
         err, blob = "", b""
         try:
             # torch owns the memory (borrowed by the library); a dedicated allocation, so the exported range is this heap
@@ -392,8 +453,7 @@ class _IpcHeap:
         except Exception as e:      # noqa: BLE001
             err = f"rank {rank}: {type(e).__name__}: {e}"[:300]
         self._raise_if_any(self._agree((err, b"")), "opening the peers' heaps")
-        if rank == 0:
-            self.lib.icv_ipc_shm_unlink(name.encode())      # everyone has it mapped: leave nothing behind in /dev/shm
+        self._unlink()                                      # everyone has it mapped: leave nothing behind in /dev/shm
         self._live.append(self)
         self._raise_if_any(self._agree((self._self_test(), b"")), "self-test")
 
@@ -404,11 +464,45 @@ class _IpcHeap:
         self.dist.all_gather_object(got, item, group=self.group)
         return got
 
+    def _unlink(self):
+        """The flag segment's NAME goes as soon as it is no longer needed - also on every failure path (a set-up that
+        failed between shm_open and the all-mapped point left /dev/shm/icv_kv_* behind).  Idempotent; every rank may call it."""
+        name, self._shm_name = getattr(self, "_shm_name", None), None
+        if name:
+            self.lib.icv_ipc_shm_unlink(name.encode())
+
     def _raise_if_any(self, got, what):
         errs = [g[0] for g in got if g[0]]
         if errs:
+            self._unlink()
             self.close()
             raise RuntimeError(f"copy-engine K|V transport unusable ({what}): " + "; ".join(errs))
+
+    def configure(self, copy_own_rows: bool) -> None:
+        self.native.check(self.lib.icv_ipc_configure(self.handle, int(bool(copy_own_rows))), "icv_ipc_configure")
+
+    def arrival_flags(self):
+        """Device words flags[p] = ticket + 1 once rank p's rows of that ticket have landed (icv_ipc_arrival)."""
+        import ctypes
+        p = ctypes.c_void_p()
+        self.native.check(self.lib.icv_ipc_arrival(self.handle, ctypes.byref(p)), "icv_ipc_arrival")
+        return _DevicePointer(p.value)
+
+    COPY_KINDS = {0: "inconclusive (the device could not be filled)", 1: "copy engine (no wave needed)", 2: "blit kernel (needs CUs)"}
+
+    def probe_copy(self, peer: int, nbytes: int = 8 << 20):
+        """(kind text, milliseconds) of one pull of ``nbytes`` from ``peer`` while every wave slot of this device is held
+        (icv_ipc_probe_copy): does the transport's data movement need compute units on THIS node?"""
+        import ctypes
+        kind, ms = ctypes.c_int(0), ctypes.c_double(-1.0)
+        nbytes = min(int(nbytes), self.mem.numel())
+        self.native.check(self.lib.icv_ipc_probe_copy(self.handle, int(peer), nbytes, ctypes.byref(kind), ctypes.byref(ms)), "icv_ipc_probe_copy")
+        return self.COPY_KINDS.get(kind.value, str(kind.value)), ms.value
+
+    def check(self) -> None:
+        """Raises when one of this rank's device-side waits timed out (a dead or stalled peer): reads one host word."""
+        if self.handle is not None:
+            self.native.check(self.lib.icv_ipc_check(self.handle), "icv_ipc_check")
 
     def _self_test(self) -> str:
         try:
@@ -464,6 +558,10 @@ class _IpcHeap:
         h, self.handle = getattr(self, "handle", None), None
         if h is not None:
             try:
+                self._unlink()
+                # teardown must not depend on live peers: the library gives this rank's queues a bounded time to finish and then
+                # satisfies every wait word itself (icv_ipc_drain); only then is a device-wide synchronize guaranteed to return
+                self.lib.icv_ipc_drain(h, int(os.environ.get("ICV_IPC_DRAIN_TIMEOUT_MS", "5000")))
                 torch.cuda.synchronize(self.device)
                 self.lib.icv_ipc_destroy(h)
             except Exception:  # pragma: no cover - interpreter shutdown
@@ -482,12 +580,37 @@ class _IpcHeap:
         self.close()
 
 
+class _DevicePointer:
+    """A raw device address with the one method the operator set asks of a tensor argument."""
+
+    def __init__(self, address: int):
+        self.address = int(address)
+
+    def data_ptr(self) -> int:
+        return self.address
+
+
 class _IpcWork:
     def __init__(self, heap, ticket):
         self.heap, self.ticket = heap, ticket
 
     def wait(self):
         self.heap.native.check(self.heap.lib.icv_ipc_gather_wait(self.heap.handle, self.ticket, self.heap._stream()), "icv_ipc_gather_wait")
+
+    def consumed(self):
+        """The consumer gated on the arrival flags itself: bookkeeping only (no stream waits are enqueued)."""
+        self.heap.native.check(self.heap.lib.icv_ipc_gather_wait(self.heap.handle, self.ticket, None), "icv_ipc_gather_wait")
+
+
+class _FlaggedWork:
+    """Work handles of one collective row-chunk whose completion a side stream turns into an arrival flag (KVGather.enable_arrival)."""
+
+    def __init__(self, works, slot: int, value: int):
+        self.works, self.slot, self.value = works, slot, value
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
 
 
 class _EventWork:
@@ -500,17 +623,28 @@ class _EventWork:
         torch.cuda.current_stream().wait_event(self.event)
 
 
-def chunk_bounds(n_rows: int, chunks: int):
+def chunk_bounds(n_rows: int, chunks: int, align: int = 1):
     """Row boundaries of the K/V gather chunks of one shard (identical on every rank).  The sizes RAMP
     (weights 1, 3, 6, 6, ...): only the first chunk's transfer is exposed before attention can start,
     so it is small; later chunks are large so launches stay efficient and each transfer hides under the
-    previous chunk's attention."""
-    chunks = max(1, min(chunks, n_rows))
+    previous chunk's attention.  ``align``: interior boundaries are multiples of it (the arrival-driven attention walks
+    (peer, chunk) pieces tile by tile: a boundary off the 64-key tile grid costs every peer's piece a masked partial tile)."""
+    chunks = max(1, min(chunks, max(1, n_rows // max(1, align)) if align > 1 else n_rows))
     w = [1.0, 3.0][:chunks] + [6.0] * max(0, chunks - 2)
     tot, acc, out = sum(w), 0.0, [0]
     for c in range(chunks):
         acc += w[c]
-        out.append(n_rows if c == chunks - 1 else max(out[-1] + 1, int(round(n_rows * acc / tot))))
+        if c == chunks - 1:
+            out.append(n_rows)
+            continue
+        b = int(round(n_rows * acc / tot))
+        if align > 1:
+            b = max(align, int(round(b / align)) * align)
+        out.append(min(n_rows - 1, max(out[-1] + max(1, align), b)) if align > 1 else max(out[-1] + 1, b))
+    if align > 1:          # the clamps above may have produced a non-increasing tail on tiny shards: fall back to fewer chunks
+        out = sorted(set(out))
+        if out[-1] != n_rows:
+            out.append(n_rows)
     return out
 
 

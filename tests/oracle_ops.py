@@ -218,6 +218,12 @@ class OracleOps:
             ml[:, :, 0] = m_new.t()
             ml[:, :, 1] = l_new.t()
 
+    def attention_pieces(self, q, pieces, o, heads, scale, flags=None, err=None, timeout_us=0, trace=None):
+        """The arrival-driven launch on CPU: the pieces are simply there (flags were waited for by the caller's work handles)."""
+        ks = [k for k, v, _, _ in pieces if k.shape[0]]
+        vs = [v for k, v, _, _ in pieces if k.shape[0]]
+        o.copy_(R.attention(q.float(), torch.cat(ks).float(), torch.cat(vs).float(), heads, scale=scale).to(BF16))
+
     def patchify(self, latent, out, tok0, n_tok):
         C, T, H8, W8 = latent.shape
         Hp, Wp = H8 // 2, W8 // 2

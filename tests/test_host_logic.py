@@ -248,7 +248,8 @@ def _sp_worker(rank, world, port, q, kv_exchange="allgather"):
         sd, bsd, noise, c1, c2, bl = _inputs()
         plan = ShardPlan.make(GRID.S, world, rank)
         m = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID, plan, kv_exchange=kv_exchange)
-        assert isinstance(m.kv_gather, KVGather) and m.kv_gather.mode == kv_exchange
+        assert isinstance(m.kv_gather, KVGather) and m.kv_gather.mode == kv_exchange.split("+")[0]
+        assert m.attn_arrival == kv_exchange.endswith("+arrival")
         lat = noise.clone()
         m.denoise(lat, m.encode_context(c1), m.encode_context(c2), m.embed_buffers(bl), FlowMatchScheduler(3), 5.0)
         lat = gather_latent(lat, plan, GRID)
@@ -257,7 +258,7 @@ def _sp_worker(rank, world, port, q, kv_exchange="allgather"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kv_exchange", ["allgather", "p2p"])
+@pytest.mark.parametrize("kv_exchange", ["allgather", "p2p", "allgather+arrival", "p2p+arrival"])
 def test_gloo_world2_sequence_parallel_equals_single(kv_exchange):
     """Token-sequence parallel denoise loop over two real processes; the K|V rows travel by all-gather or by the
     direct send/recv-to-every-peer schedule (seqpar.KVGather mode "p2p")."""

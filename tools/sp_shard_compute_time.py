@@ -56,6 +56,18 @@ class ServedGather:
         self.world = world
         self.side = torch.cuda.Stream()
         self.filled = set()
+        self.arrival_on = False
+
+    # the arrival-driven attention (ONE launch per layer over the pieces, csrc/attn7p.hip): every piece is there, no flag to wait for;
+    # own rows are read in place, so nothing is copied at all
+    def enable_arrival(self, ops):
+        self.arrival_on = True
+
+    def arrival(self, handle):
+        return None, [(j, -1, 0) for j in range(1, self.world)]
+
+    def consumed(self, handle):
+        pass
 
     def allreduce_max(self, t):           # e4m3 wire format: the abs-max exchange (2 x heads floats) - nothing to time on one rank
         pass
@@ -69,6 +81,8 @@ class ServedGather:
             else:
                 out.copy_(peers[: out.shape[0]])
             self.filled.add(out.data_ptr())
+        if self.arrival_on:
+            return ()
         ready = torch.cuda.Event()
         ready.record()
         self.side.wait_event(ready)
@@ -83,12 +97,14 @@ class ServedGather:
             torch.cuda.current_stream().wait_event(ev)
 
 
-def time_forward(world, chunks, iters=3, pair=False):
+def time_forward(world, chunks, iters=3, pair=False, arrival=False):
     """ms per layer of ONE forward on the shard (pair=False), or of BOTH CFG forwards issued as WanDiT.forward_pair (pair=True:
     what a rank of the `sp` layout runs per step - projections over 2n rows, exchange + attention per branch)."""
     plan = ShardPlan.make(grid.S, world, 0)
     m = WanDiT(cfg, sd, ops, bsd, gemm_dtype=GEMM, attn_dtype=ATTN).prepare(grid, plan, kv_gather=ServedGather(world) if world > 1 else None,
-                                                                           sp_chunks=chunks, graphs=False)
+                                                                           sp_chunks=chunks, graphs=False,
+                                                                           kv_exchange="allgather+arrival" if arrival and world > 1 else None)
+    assert m.attn_arrival == bool(arrival and world > 1 and ATTN == "bf16")
     clip = syn.make_clip_features(cfg) if cfg.has_image_input else None
     ck, bt = m.encode_context(ctx, clip), m.embed_buffers(bl)
     if cfg.has_image_input:
@@ -118,7 +134,7 @@ rows = []
 ONLY = os.environ.get("ONLY")          # "world:chunks[:pair]" -> time just that shard shape (for a rocprofv3 kernel trace of it)
 if ONLY:
     w, c, *rest = ONLY.split(":")
-    t = time_forward(int(w), int(c), iters=int(os.environ.get("ITERS", "3")), pair=bool(rest))
+    t = time_forward(int(w), int(c), iters=int(os.environ.get("ITERS", "3")), pair="pair" in rest, arrival="arrival" in rest)
     print(f"{MODEL} S={grid.S} gemm {GEMM} attn {ATTN} wire {os.environ.get('ICV_FP8_WIRE', 'e4m3') if ATTN == 'fp8' else 'bf16'}: shard 1/{w} chunks {c}{' pair' if rest else ''}: {t:.3f} ms per layer")
     sys.exit(0)
 L = cfg_full.num_layers
@@ -129,15 +145,16 @@ one_gpu_step = L * base
 print(f"1 GPU: {base:.2f} ms per layer for both forwards of a step (pair-batched; two separate forwards: {2 * base1:.2f}) -> {one_gpu_step:.0f} ms per step x {L} layers")
 for n_gpus, layout, world, pair in ((2, "cfg+sp", 1, False), (4, "cfg+sp", 2, False), (8, "cfg+sp (auto)", 4, False), (8, "sp", 8, True), (8, "sp unpaired", 8, False),
                                     (4, "sp", 4, True), (2, "sp", 2, True)):
-    for chunks in ((1,) if world == 1 else (4, 2)):
+    for chunks, arrival in (((1, False),) if world == 1 else ((4, True), (4, False), (2, False)) if ATTN == "bf16" else ((4, False), (2, False))):
         if pair:
-            t = time_forward(world, chunks, pair=True)          # both forwards of the step
+            t = time_forward(world, chunks, pair=True, arrival=arrival)          # both forwards of the step
         else:
-            t = (base1 if world == 1 else time_forward(world, chunks)) * (2 if layout.startswith("sp") else 1)
+            t = (base1 if world == 1 else time_forward(world, chunks, arrival=arrival)) * (2 if layout.startswith("sp") else 1)
         step = L * t
-        rows.append(dict(n_gpus=n_gpus, layout=layout, sp_world=world, sp_chunks=chunks, ms_per_layer_per_step=t, compute_only_ms_per_step=step,
+        rows.append(dict(n_gpus=n_gpus, layout=layout, sp_world=world, sp_chunks=chunks, attention="one arrival-gated launch" if arrival else "chunk launches",
+                         ms_per_layer_per_step=t, compute_only_ms_per_step=step,
                          compute_only_steps_per_s=1e3 / step, compute_only_scaling=one_gpu_step / step))
-        print(f"N = {n_gpus} {layout:14s} shard 1/{world} chunks {chunks}: {t:6.2f} ms per layer per step -> {step:7.1f} ms per step, "
+        print(f"N = {n_gpus} {layout:14s} shard 1/{world} chunks {chunks}{' ARRIVAL' if arrival else '        '}: {t:6.2f} ms per layer per step -> {step:7.1f} ms per step, "
               f"{1e3 / step:.3f} steps/s, x{one_gpu_step / step:.2f} of one GPU (compute only, exchange fully hidden)")
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(dict(model=cfg_full.name, gemm=GEMM, attn=ATTN, S=grid.S, layers_timed=LAYERS, one_gpu_ms_per_step=one_gpu_step, rows=rows), open("gpurun_out/sp_compute_only_projection.json", "w"), indent=1)
