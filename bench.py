@@ -47,6 +47,7 @@ from infinicube_amd.videogen.scheduler import FlowMatchScheduler  # noqa: E402
 from infinicube_amd.videogen.seqpar import BranchExchange, ParallelLayout, autotune_kv_exchange  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+XGMI_LINKS, XGMI_LINK_GBS = 7, 153.0     # per GPU, point to point (task statement / MI355X guide)
 PEAK_FP8_TFLOPS = 5000.0    # dense fp8 (K=64/128 scaled) MFMA peak, same guide
 CFG_SCALE = 5.0
 
@@ -172,11 +173,14 @@ def parse_args(argv=None):
     ap.add_argument("--parallelism", default=os.environ.get("ICV_PARALLELISM", "auto"), choices=["auto", "sp", "cfg+sp"],
                     help="N>1: 'sp' = token shards over all N ranks, both CFG forwards on every rank; 'cfg+sp' = cond / "
                          "uncond forwards on two groups of N/2 ranks, token shards inside a group (auto when N is even)")
-    ap.add_argument("--kv-exchange", default=os.environ.get("ICV_KV_EXCHANGE", "auto"), choices=["auto", "allgather", "p2p", "native", "ipc"],
+    ap.add_argument("--kv-exchange", default=os.environ.get("ICV_KV_EXCHANGE", "auto"),
+                    choices=["auto"] + [m + sfx for m in ("allgather", "p2p", "native", "ipc") for sfx in ("", "+arrival")],
                     help="N>1: K|V rows travel by all_gather_into_tensor (RCCL's schedule) or by grouped send/recv to every "
                          "peer (the direct, fully-connected schedule), or by libicvideo's own RCCL communicator (icv_allgather_kv; "
                          "seqpar.KVGather); 'auto' (default) = a start-up autotune times two real layers with each transport x "
-                         "{4, 2} chunks on the ranks of the run and keeps the fastest (the table goes into multi_gpu.autotune)")
+                         "{4, 2} chunks on the ranks of the run and keeps the fastest (the table goes into multi_gpu.autotune); "
+                         "'<transport>+arrival' = ONE arrival-gated attention launch per layer over the K|V pieces (csrc/attn7p.hip) "
+                         "instead of one carried-state launch per row chunk")
     ap.add_argument("--rccl-max-channels", type=int, default=-1,
                     help="N>1: cap RCCL's channel count (NCCL_MAX_NCHANNELS; one channel = one resident workgroup beside the attention "
                          "kernel while a transfer runs): -1 (default) = 8 unless NCCL_MAX_NCHANNELS is already set - derived from the "
@@ -454,6 +458,20 @@ def run_rank(args, world, rank, phase, stdout_fd):
             raw_chunk(q, k, v, o, acc, ml, heads, scale, first, last)
 
     ops.attention_chunk = timed_chunk
+    raw_pieces = ops.attention_pieces
+    piece_events = []
+
+    def timed_pieces(q, pieces, o, heads, scale, **kw):     # arrival-driven: ONE launch per layer over all S keys
+        if record["on"]:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            raw_pieces(q, pieces, o, heads, scale, **kw)
+            e1.record()
+            piece_events.append((e0, e1, sum(int(p[0].shape[0]) for p in pieces)))
+        else:
+            raw_pieces(q, pieces, o, heads, scale, **kw)
+
+    ops.attention_pieces = timed_pieces
 
     def sync():
         torch.cuda.synchronize(device)
@@ -479,23 +497,78 @@ def run_rank(args, world, rank, phase, stdout_fd):
                 return t.tolist()
 
             t_tune = time.perf_counter()
-            cands = [(m, c) for m in ("allgather", "p2p", "native", "ipc") for c in sorted({args.sp_chunks, 2}, reverse=True)]
+            # per transport: the arrival-driven attention (one launch per layer; bf16 attention only) and the chunked launches
+            arrival = [("+arrival", args.sp_chunks)] if (args.attn_dtype == "bf16" and os.environ.get("ICV_ATTN_ARRIVAL") != "0") else []
+            cands = [(m + sfx, c) for m in ("allgather", "p2p", "native", "ipc")
+                     for sfx, c in arrival + [("", c) for c in sorted({args.sp_chunks, 2}, reverse=True)]]
             if share:      # several ranks on ONE GPU (development boxes): RCCL refuses duplicate devices in a communicator
-                cands = [mc for mc in cands if mc[0] != "native"]
+                cands = [mc for mc in cands if not mc[0].startswith("native")]
+            peers = layout.sp_world - 1
+            link_peak = XGMI_LINK_GBS * min(peers, XGMI_LINKS)          # what the links of THIS rank can deliver to it (one per peer)
+
+            def attn_probe(mode, chunks):
+                """First contact made self-explaining, per candidate on the ranks of the run:
+                  attn_under_exchange_ms / attn_from_memory_ms - one layer's self-attention (all its launches) with the REAL exchange in
+                    flight in front of it (issued right before: the transfer hides under nothing else) vs the same launches over rows that
+                    are already there: the difference is what the transfer exposes PLUS what its data movement costs the kernel beside it;
+                  ipc_peer_copy - does a pull from the right-hand neighbour need compute units (icv_ipc_probe_copy: blit kernel) or not
+                    (copy engine)?  Nothing in a timing table would tell."""
+                if model.attn_fp8:
+                    return {}
+                H, q = cfg.num_heads, model.qkv[0]
+                out = {}
+                for key, under in (("attn_under_exchange_ms", True), ("attn_from_memory_ms", False)):
+                    ms = []
+                    for rep in range(3):
+                        sync()
+                        if under:
+                            model._sp_acquire()
+                            handles, bufs = model._sp_start_gather()
+                        else:
+                            handles, bufs = model._sp_start_gather(start=False)
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        model._sp_attention(q, handles, bufs, H, model.attn_scale, from_memory=not under)
+                        e1.record()
+                        torch.cuda.synchronize(device)
+                        if rep:
+                            ms.append(e0.elapsed_time(e1))
+                    out[key] = sum(ms) / len(ms)
+                out["attn_under_exchange_ms"], out["attn_from_memory_ms"] = reduce_max([out["attn_under_exchange_ms"], out["attn_from_memory_ms"]])
+                heap = getattr(model.kv_gather, "_heap", None)
+                if heap is not None and peers > 0:
+                    sync()
+                    kind, ms_copy = heap.probe_copy((layout.sp_rank + 1) % layout.sp_world)
+                    out["ipc_peer_copy"] = kind
+                    out["ipc_peer_copy_8mib_ms"] = ms_copy
+                    sync()
+                return out
+
             def exchange_only():          # one layer's K|V exchange with nothing to hide under: the raw transfer
                 handles, _ = model._sp_start_gather()
                 for h in handles:
                     model.kv_gather.wait(h)
+                    if hasattr(model.kv_gather, "consumed"):
+                        model.kv_gather.consumed(h)
 
             (args.kv_exchange, args.sp_chunks), table = autotune_kv_exchange(
-                model, two_layers, sync, cands, reps=2, reduce_max=reduce_max, exchange_only=exchange_only,
+                model, two_layers, sync, cands, reps=2, reduce_max=reduce_max, exchange_only=exchange_only, probe=attn_probe,
                 log=(lambda m: print(f"[bench] {m}", file=sys.stderr, flush=True)) if rank == 0 else None)
             recv = 2 * 2 * plan.n_tok * cfg.dim * (layout.sp_world - 1)         # bytes each rank RECEIVES per layer exchange (k | v rows, bf16)
             for row in table:
                 if row.get("exchange_ms"):
                     row["recv_gb_per_s_per_rank"] = recv / (row["exchange_ms"] * 1e-3) / 1e9
+                    row["frac_of_xgmi_links"] = row["recv_gb_per_s_per_rank"] / link_peak if (link_peak and not share) else None
+                if row.get("attn_under_exchange_ms") and row.get("attn_from_memory_ms"):
+                    row["attn_slowdown_under_exchange"] = row["attn_under_exchange_ms"] / row["attn_from_memory_ms"]
             autotune = {"seconds": time.perf_counter() - t_tune, "layers_timed": min(2, cfg.num_layers), "table": table,
                         "bytes_received_per_rank_per_layer_exchange": recv,
+                        "xgmi_peak_gb_per_s_into_one_rank": link_peak, "xgmi_note": f"{XGMI_LINKS} links x {XGMI_LINK_GBS:.0f} GB/s per GPU, point to point: one link per peer"
+                        + (" (ranks SHARE one GPU here: no link is involved)" if share else ""),
+                        "columns": {"ms": "two real layers, max over ranks (the choice is made on this)", "exchange_ms": "one layer's exchange with nothing to hide under",
+                                    "attn_under_exchange_ms": "one layer's self-attention launches with the real exchange issued right in front of them",
+                                    "attn_from_memory_ms": "the same launches over rows that are already there",
+                                    "ipc_peer_copy": "icv_ipc_probe_copy: does a pull need compute units (blit kernel) or not (copy engine)"},
                         "chosen": {"kv_exchange": args.kv_exchange, "sp_chunks": args.sp_chunks}}
         else:
             args.kv_exchange = "allgather"          # cfg+sp at N = 2: no K|V exchange at all
@@ -550,9 +623,17 @@ def run_rank(args, world, rank, phase, stdout_fd):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         comm = {"rccl_ranks": world, "backend": dist.get_backend(), "kv_exchange": args.kv_exchange, "sp_chunks": args.sp_chunks,
                 "kv_group_ranks": layout.sp_world, "rccl_max_channels": os.environ.get("NCCL_MAX_NCHANNELS") or "rccl default",
+                "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES") or "runtime default (4)",
+                "attention": "ONE arrival-gated launch per layer over the K|V pieces (csrc/attn7p.hip)" if getattr(model, "attn_arrival", False)
+                else "one carried-state launch per row chunk",
                 "kv_exchanges_per_step_per_rank": tt[2].item() / args.steps,
-                "kv_bytes_sent_per_exchange_layer": 2 * 2 * plan.n_tok * cfg.dim if layout.sp_world > 1 else 0,
-                "exposed_kv_wait_ms_per_step": tt[0].item() / args.steps,      # max over ranks of the compute-stream stalls
+                # what one rank SENDS per layer exchange: its k | v rows in bf16, or (e4m3 on the wire) its e4m3 blobs
+                "kv_bytes_sent_per_exchange_layer": 0 if layout.sp_world <= 1 else
+                (sum(r8 for _, r8, _, _ in model._kv8_chunks) * cfg.dim if getattr(model, "fp8_wire", False) else 2 * 2 * plan.n_tok * cfg.dim),
+                "kv_wire_format": "e4m3 blobs (quantised once per rank)" if getattr(model, "fp8_wire", False) else "bf16 rows",
+                # max over ranks of the compute-stream stalls in front of the chunk launches; the arrival-driven attention has no such
+                # stall to time (it waits INSIDE its one launch): multi_gpu.autotune's attn_under_exchange_ms - attn_from_memory_ms is its exposure
+                "exposed_kv_wait_ms_per_step": None if getattr(model, "attn_arrival", False) else tt[0].item() / args.steps,
                 "kv_chunk_waits_per_step": tt[1].item() / args.steps}
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -560,7 +641,11 @@ def run_rank(args, world, rank, phase, stdout_fd):
         elapsed = float(tt.item())
     assert torch.isfinite(latent).all(), "latent went non-finite"
 
-    if chunk_events:   # N>1: one self-attention = sp_chunks launches over S/sp_chunks keys each
+    if piece_events:   # N>1, arrival-driven: one launch per layer over all keys of the sequence
+        attn_ms = sum(a.elapsed_time(b) for a, b, _ in piece_events) / len(piece_events)
+        attn_flops = 4.0 * plan.n_tok * (sum(kk for _, _, kk in piece_events) / len(piece_events)) * cfg.dim
+        attn_events = piece_events
+    elif chunk_events:   # N>1: one self-attention = sp_chunks launches over S/sp_chunks keys each
         attn_ms = sum(a.elapsed_time(b) for a, b, _ in chunk_events) / len(chunk_events)
         attn_flops = 4.0 * plan.n_tok * (sum(kk for _, _, kk in chunk_events) / len(chunk_events)) * cfg.dim
         attn_events = chunk_events

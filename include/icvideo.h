@@ -30,10 +30,10 @@ extern "C" {
  *    icv_dit_set_fp8 / icv_dit_set_seqpar and the e4m3 / sequence-parallel bind names were added. */
 /* 3: icv_ipc_* (the copy-engine K|V transport), icv_conv3d_ndhwc and the padded-volume VAE helpers were added; no existing
  *    signature changed.
- * 4: icv_attention_fwd_pieces (ONE arrival-gated attention launch per layer over K|V pieces), icv_ipc_arrival / _configure / _check /
+ * 4: icv_attention_fwd_pieces (ONE arrival-gated attention launch per layer over K|V pieces), icv_ipc_arrival / _gather_consumed / _configure / _check /
  *    _drain / _probe_copy (arrival flags, bounded device-side waits, teardown that does not depend on live peers, copy-engine-or-blit
  *    probe), icv_flag_write; no existing
- *    signature changed (icv_ipc_gather_wait accepts stream == NULL: bookkeeping only). */
+ *    signature changed. */
 #define ICV_ABI_VERSION 4
 
 /* ---- library / device ------------------------------------------------------------------ */
@@ -346,6 +346,10 @@ int icv_voxel_raycast(const int* vol, const unsigned char* bricks, const int* di
  *   of every rank are exchanged with icv_allgather_kv on `comm`, enqueued on `side_stream` (a hipStream_t the caller owns)
  *   and fenced against the launch stream with events the context owns, and attention consumes the chunks in order with
  *   carried softmax state (icv_attention_fwd_chunk).  comm == NULL returns to the single-rank schedule.
+ *   SCOPE: the one-call driver knows THIS sequence-parallel form only - an RCCL communicator (icv_comm_*), bf16 rows on the wire,
+ *   one carried-state launch per row chunk.  The copy-engine transport (icv_ipc_*), e4m3 K|V on the wire
+ *   (icv_attention_fp8_quantize_kv / _fwd_pieces) and the arrival-driven attention (icv_attention_fwd_pieces) are driven through
+ *   the per-op entry points by the host (infinicube_amd/videogen/dit.py, which refuses the one-call driver in those modes).
  * icv_dit_forward: latent f32 [C,T,H8,W8]; mod f32 [layers,6d] and hmod f32 [2,d] = this step's modulation tables;
  *   ctx_k / ctx_v bf16 [ctx_len, d] of layer 0, layer i at + i * ctx_layer_stride elements (text K/V cache); img_k / img_v
  *   likewise with img_len / img_layer_stride, or NULL; buf_tokens f32
@@ -445,10 +449,12 @@ int icv_ipc_acquire(icv_ipc* ipc, void* stream);
 int64_t icv_ipc_tickets(const icv_ipc* ipc);
 /* Arrival flags for icv_attention_fwd_pieces: *flags = DEVICE memory uint32 [world]; flags[p] >= t + 1 once the rows rank p
  * contributed to ticket t have landed in that ticket's `out` (monotonic; entry [own rank] is never written: own rows are read in place).
- * A consumer that gates on these calls icv_ipc_gather_wait(ipc, ticket, NULL) (bookkeeping only: no stream waits are enqueued).
+ * A consumer that gates on these calls icv_ipc_gather_consumed(ipc, ticket) instead of icv_ipc_gather_wait (bookkeeping only: no
+ * stream waits are enqueued).
  * icv_ipc_configure(ipc, copy_own_rows): 0 = gather_start no longer copies this rank's own rows into `out` (the arrival-driven
  * attention reads them from the heap). */
 int icv_ipc_arrival(icv_ipc* ipc, const uint32_t** flags);
+int icv_ipc_gather_consumed(icv_ipc* ipc, int64_t ticket);
 int icv_ipc_configure(icv_ipc* ipc, int copy_own_rows);
 /* Liveness (round 6).  Every device-side wait of the transport is a one-wave kernel with a deadline (ICV_IPC_WAIT_TIMEOUT_MS, default
  * 30000, 0 = none): a wait that expires records whom it was waiting for and lets its queue go on with stale rows.

@@ -306,17 +306,37 @@ extern "C" int icv_conv3d_ndhwc(const void* x, int64_t ldx, int64_t x_rows_befor
                 i, (long long)off, (long long)m0, (long long)m1, (long long)x_rows_before, (long long)x_rows_after, (long long)(m1 - 1));
     p.tap_bytes[i] = off * ldx * 2;
   }
-  // per-lane row offsets are 32-bit byte offsets from the operand base
-  ICV_REQUIRE((double)m1 * (double)ldx * 2.0 < 4294967296.0 && (double)cout * (double)K * 2.0 < 4294967296.0, "icv_conv3d_ndhwc: operand spans >= 4 GiB: split the rows");
+  ICV_REQUIRE((double)cout * (double)K * 2.0 < 4294967296.0, "icv_conv3d_ndhwc: the weight matrix spans >= 4 GiB");
   const int nb = cout <= 32 ? 1 : cout <= 96 ? 3 : (cout % 192 != 0 && cout % 96 == 0) ? 3 : 6;
   const int bn = 32 * nb;
-  p.tiles_m = (int)((m1 - m0 + cv::BM - 1) / cv::BM);
   p.tiles_n = (int)((cout + bn - 1) / bn);
-  ICV_REQUIRE((int64_t)p.tiles_m * p.tiles_n <= 0x7fffffffLL, "icv_conv3d_ndhwc: too many tiles");
   hipStream_t st = (hipStream_t)stream;
-  switch (nb) {
-    case 1: return cv::launch<1>(p, st);
-    case 3: return cv::launch<3>(p, st);
-    default: return cv::launch<6>(p, st);
+  // The kernel keeps a lane's A-row position as a 32-bit byte offset from the operand base (the tap shifts are 64-bit), so ONE launch
+  // covers rows whose offsets from ITS base stay below 4 GiB.  A longer volume (a full-resolution 192-channel decoder volume of a
+  // 240 x 416 tile reaches 4 GiB at 109 frames; an untiled 480p volume exceeds it outright - ADVICE r5) is cut into row ranges, each
+  // launched with the bases of x / out / resid moved to its first row: the arithmetic per output row is unchanged (same taps, same K
+  // order), so the result is bit-identical to a hypothetical single launch.
+  const int64_t max_rows = (int64_t)((4294967296.0 - 1.0) / ((double)ldx * 2.0)) / cv::BM * cv::BM;
+  ICV_REQUIRE(max_rows >= cv::BM, "icv_conv3d_ndhwc: a row of %lld elements is too long", (long long)ldx);
+  // [m0, m1) from base row 0 fits one launch when m1 <= max_rows (the common case); otherwise ranges of max_rows rows from m0 on
+  for (int64_t a = (m1 <= max_rows ? 0 : m0); a < m1;) {
+    const int64_t b = (m1 - a <= max_rows) ? m1 : a + max_rows;
+    cv::Params q = p;
+    q.X = p.X + a * ldx * 2;
+    q.out = p.out + a * ldo;
+    q.resid = p.resid ? p.resid + a * ldr : nullptr;
+    q.m0 = (a == 0 ? m0 : 0);
+    q.m1 = b - a;
+    q.tiles_m = (int)((q.m1 - q.m0 + cv::BM - 1) / cv::BM);
+    ICV_REQUIRE((int64_t)q.tiles_m * q.tiles_n <= 0x7fffffffLL, "icv_conv3d_ndhwc: too many tiles");
+    int rc = 0;
+    switch (nb) {
+      case 1: rc = cv::launch<1>(q, st); break;
+      case 3: rc = cv::launch<3>(q, st); break;
+      default: rc = cv::launch<6>(q, st); break;
+    }
+    if (rc) return rc;
+    a = b;
   }
+  return 0;
 }

@@ -14,6 +14,9 @@
 // were removed; -0.5...2.6 % before).  So icv_gemm_bf16 uses this kernel for the bf16 / GELU epilogues when a launch has at least two tiles per CU, and
 // gemm256.hip otherwise (option gemm256_persist = 0 switches it off; gemm256 = 5 / 6 force it for every epilogue).
 //
+// (A hipGraph captured on stream S keeps S's counter block: replay it on S, as the loop does.  Replaying it on ANOTHER stream
+// concurrently with eager GEMMs on S would make two launches share one block - serialise such a replay against S, or capture it on the
+// stream it will run on.)
 // The work counters are STATELESS between launches: a 64-byte block (8 per-XCD counters + an exit counter) that every launch finds
 // zeroed and whose last-exiting work-group zeroes again - safe under hipGraph replay; one block per (device, stream) from a pool that
 // is allocated outside stream capture, so launches on different streams never share counters.
@@ -344,6 +347,10 @@ template <int EPI>
 int launch(Params& p, int n_cu, bool dyn, hipStream_t st) {
   const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
   const unsigned grid = (unsigned)(nwg < n_cu ? nwg : n_cu);
+  // the tile space is cut into 8 ranges keyed by blockIdx.x & 7 (one per XCD): a launch with fewer than 8 work-groups but more tiles
+  // than work-groups (gemm256p_cus < 8, a device reporting < 8 CUs) would leave whole ranges without a work-group and their tiles
+  // unwritten - such a launch is not this kernel's business: the one-tile-per-block kernel takes it
+  if (grid < 8 && nwg > (int64_t)grid) return -1;
   if (!dyn) return launch1<EPI, false>(p, grid, st);
   p.ctr = counters_for(st);
   if (!p.ctr) return -1;                                     // caller falls back to gemm256.hip
@@ -352,15 +359,15 @@ int launch(Params& p, int n_cu, bool dyn, hipStream_t st) {
 
 }  // namespace g256p
 
-int icv_gemm256p_cus() {
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
+int icv_gemm256p_cus() {      // CUs of the CURRENT device (cached per device: a process may drive several)
+  static int n_cu[ICV_MAX_DEVICES] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ICV_MAX_DEVICES) return 256;
+  if (!n_cu[dev]) {
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
+    n_cu[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
   }
-  return n_cu;
+  return n_cu[dev];
 }
 
 // mode: 5 = static stride, 6 = per-XCD work counter.  Returns -1 (no error text) when mode 6 has no counter block for `st` right

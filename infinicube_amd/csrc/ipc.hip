@@ -310,11 +310,19 @@ extern "C" int icv_ipc_gather_wait(icv_ipc* c, int64_t ticket, void* stream) {
   ICV_REQUIRE(ticket >= 0 && ticket < c->next_ticket && ticket >= c->next_ticket - kSlots, "icv_ipc_gather_wait: ticket %lld is not in flight (next %lld)",
               (long long)ticket, (long long)c->next_ticket);
   const int slot = (int)(ticket % kSlots);
-  // stream == NULL: the consumer gates on the arrival flags itself (icv_ipc_arrival + icv_attention_fwd_pieces); bookkeeping only
-  if (stream)
-    for (int p = 0; p < c->world; ++p)      // every peer's chunk and this rank's own
-      ICV_HIP_OK(hipStreamWaitEvent((hipStream_t)stream, c->landed[(size_t)p * kSlots + slot], 0), "hipStreamWaitEvent(landed)");
+  for (int p = 0; p < c->world; ++p)      // every peer's chunk and this rank's own
+    ICV_HIP_OK(hipStreamWaitEvent((hipStream_t)stream, c->landed[(size_t)p * kSlots + slot], 0), "hipStreamWaitEvent(landed)");
   c->waited[slot] = true;
+  return 0;
+}
+
+// The consumer gated on the arrival flags itself (icv_ipc_arrival + icv_attention_fwd_pieces): bookkeeping only, nothing is enqueued.
+// (Not "icv_ipc_gather_wait with a NULL stream": NULL IS a stream - the default one.)
+extern "C" int icv_ipc_gather_consumed(icv_ipc* c, int64_t ticket) {
+  ICV_REQUIRE(c, "icv_ipc_gather_consumed: null argument");
+  ICV_REQUIRE(ticket >= 0 && ticket < c->next_ticket && ticket >= c->next_ticket - kSlots, "icv_ipc_gather_consumed: ticket %lld is not in flight (next %lld)",
+              (long long)ticket, (long long)c->next_ticket);
+  c->waited[(int)(ticket % kSlots)] = true;
   return 0;
 }
 

@@ -95,6 +95,7 @@ SIGNATURES.update({
     "icv_ipc_tickets": (c_int64, [c_void_p]),
     "icv_ipc_abort": (c_int, [c_void_p]),
     "icv_ipc_arrival": (c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
+    "icv_ipc_gather_consumed": (c_int, [c_void_p, _I]),
     "icv_ipc_configure": (c_int, [c_void_p, c_int]),
     "icv_ipc_check": (c_int, [c_void_p]),
     "icv_ipc_drain": (c_int, [c_void_p, c_int]),

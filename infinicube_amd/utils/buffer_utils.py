@@ -7,16 +7,17 @@ sky fill) runs in libicvideo's HIP kernels (csrc/buffers.hip) on the depth map r
 PyTorch only handles a handful of numbers: K^-1, pose_0^-1 pose_n and the two quantile vectors.
 
 The <= 100000-point sample the quantiles are taken on [R infinicube/utils/buffer_utils.py:236-241] is drawn
-  * ``sampling="reference"`` (default): the reference's call for call — host `torch.randperm(n_valid)[:100000]` on
-    the global RNG and host `torch.quantile`, so a run seeded like the reference's reproduces its bytes (the golden
-    test) and consumes the CPU global RNG exactly as the reference does.  At 93 x 480 x 832 that host permutation
-    of 29 M indices costs ~1 s.
-  * ``sampling="device"`` (opt-in: the argument, or ``ICV_COORD_SAMPLING=device`` in the environment): drawn on the
-    GPU — one jittered pick per stratum of the valid points (flattened order), quantiles on the device: the whole
-    function in 39 ms instead of 1.1 s.  The reference's own draw is UNSEEDED in its caller
-    [R infinicube/utils/buffer_utils.py:239-241], so what this mode reproduces is the estimator (5 % / 95 %
-    quantiles of <= 100000 of the finite points), held by test to the reference's own run-to-run spread.  With
-    <= 100000 finite points the sample is all of them and the result equals the reference's bit for bit.
+  * ``sampling="device"`` (DEFAULT since round 6): on the GPU — one jittered pick per stratum of the valid points
+    (flattened order), quantiles on the device: the whole function in ~39 ms instead of 1.1 s at 93 x 480 x 832.  The
+    reference's own draw is UNSEEDED in its caller [R infinicube/utils/buffer_utils.py:239-241], so there are no
+    reference bytes to reproduce: what this mode reproduces is the estimator (5 % / 95 % quantiles of <= 100000 of the
+    finite points), held by test to the reference's own run-to-run spread (tests/test_buffers.py: at most 1 level,
+    on no more bytes than two reference runs with different seeds differ by).  With <= 100000 finite points the sample
+    is all of them and the result equals the reference's bit for bit.
+  * ``sampling="reference"`` (the argument, or ``ICV_COORD_SAMPLING=reference``): the reference's call for call — host
+    `torch.randperm(n_valid)[:100000]` on the global RNG and host `torch.quantile`, so a run SEEDED like a reference run
+    reproduces its bytes (what the golden test does) and consumes the CPU global RNG exactly as the reference does.  At
+    93 x 480 x 832 that host permutation of 29 M indices is 996 of the call's 1005 ms.
 """
 from __future__ import annotations
 
@@ -40,10 +41,10 @@ def generate_coordinate_buffer_from_memory_global_norm(depth_buffer: torch.Tenso
     """depth_buffer [N,H,W] metres (0 = infinitely far), camera_model with ``get_intrinsics_matrix()`` -> [3,3],
     camera_poses [N,4,4] camera-to-world  ->  [N,H,W,3] float32 in [0,1] (on ``device``), or with
     ``return_uint8=True`` the uint8 buffer ``(coord * 255).astype(uint8)`` the video generator consumes.
-    ``sampling``: "reference" | "device" (module docstring; None = ``ICV_COORD_SAMPLING`` or "reference");
+    ``sampling``: "device" | "reference" (module docstring; None = ``ICV_COORD_SAMPLING`` or "device");
     ``generator``: optional device torch.Generator for the device draw (default: the device's global generator)."""
     if sampling is None:
-        sampling = os.environ.get("ICV_COORD_SAMPLING", "reference")
+        sampling = os.environ.get("ICV_COORD_SAMPLING", "device")
     if sampling not in ("device", "reference"):
         raise ValueError(f"sampling must be 'device' or 'reference', got {sampling!r}")
     lib = native.lib()

@@ -306,9 +306,10 @@ class WanDiT:
         # XCD-local K/V and weight reuse of each other more than they fill each other's tail waves.
         self.dual_stream = os.environ.get("ICV_DUAL_STREAM", "0") == "1" and not self.sp_on and self._is_gpu()
         # ICV_NATIVE_FORWARD=1 / self.native_forward = True: one C call (icv_dit_forward) enqueues the whole forward instead of
-        # ~13 C-ABI calls per layer from Python — the same launchers in the same order, so bit-identical, in every mode (bf16 /
-        # e4m3, one rank / sequence-parallel with libicvideo's own RCCL communicator).  Off by default: host issue time is
-        # 0.3 % of a 14B step either way (profiles/r03).
+        # ~13 C-ABI calls per layer from Python — the same launchers in the same order, so bit-identical, in every mode it covers
+        # (bf16 / e4m3 projections and attention on one rank; sequence-parallel over an RCCL transport with bf16 rows on the wire and the
+        # chunked launches - _native_eligible() says no to the e4m3 wire format, the copy-engine transport and the arrival-driven
+        # attention, and the per-op driver runs).  Off by default: host issue time is 0.3 % of a 14B step either way.
         self.native_forward = os.environ.get("ICV_NATIVE_FORWARD", "0") == "1"
         if getattr(self, "_native", None) is not None:      # a new workspace: the old context points at freed buffers
             self.ops.lib.icv_dit_destroy(self._native)
@@ -338,6 +339,7 @@ class WanDiT:
             self.sp_ml = a((n, cfg.num_heads, 2), F32)             # carried (running max, row sum)
         else:
             self.kv_loc, self.kv_full, self.kv_gather = None, None, None
+            self.attn_arrival, self.sp_err, self.sp_align = False, None, 1
         return self
 
     def _sp_local_rows(self):
@@ -503,7 +505,12 @@ class WanDiT:
                 pass
 
     def _native_eligible(self) -> bool:
-        return self.native_forward and self._is_gpu() and hasattr(self.ops, "lib") and (not self.sp_on or isinstance(self.kv_gather, KVGather))
+        # the C driver knows the RCCL transport, bf16 rows on the wire and the chunked carried-state launches - nothing newer: with e4m3
+        # on the wire, the copy-engine transport or the arrival-driven attention the per-op driver runs (it used to take
+        # the C path and silently re-quantise gathered bf16 rows per chunk)
+        sp_ok = not self.sp_on or (isinstance(self.kv_gather, KVGather) and self.kv_gather.mode != "ipc"
+                                   and not getattr(self, "fp8_wire", False) and not getattr(self, "attn_arrival", False))
+        return self.native_forward and self._is_gpu() and hasattr(self.ops, "lib") and sp_ok
 
     def native_profile(self, enable: bool):
         """Time every self-attention launch of the native forward with HIP events on the launch stream (bench.py)."""
@@ -530,27 +537,30 @@ class WanDiT:
         dev = getattr(self.ops, "device", None)
         return dev is not None and torch.device(dev).type == "cuda"
 
-    def _sp_start_gather(self, kv_loc=None, kv_full=None, kv8=None):
+    def _sp_start_gather(self, kv_loc=None, kv_full=None, kv8=None, start: bool = True):
         """K13: enqueue the exchange of every K|V row-chunk (RCCL runs them back to back on its own
         stream; chunk c = rows [r0, r1) of EVERY rank's shard, rank-major).
         e4m3 on the wire (``fp8_wire``; ``kv8`` = this branch's wire set): the per-head abs-max of the local K and V rows is
         max-reduced over the group first (2 x H floats, one tiny collective per layer), every rank quantises its own rows of
         each chunk ONCE with those scales - the scales of the unsharded launch, so the e4m3 values are the single-GPU ones -
-        and the exchange moves the e4m3 blobs: half the bytes of bf16 rows, 1/world of the quantise work."""
+        and the exchange moves the e4m3 blobs: half the bytes of bf16 rows, 1/world of the quantise work.
+        ``start=False`` (bench.py's attention-from-memory probe): only describe the buffers of the LAST exchange, move nothing."""
         world, b, d = self.plan.world, self.sp_bounds, self.cfg.dim
         kv_loc = self.kv_loc if kv_loc is None else kv_loc
         handles, bufs = [], []
         if getattr(self, "fp8_wire", False):
             loc8, full8, amax = self.kv8 if kv8 is None else kv8
             H = self.cfg.num_heads
-            self.ops.attention_fp8_kv_amax(kv_loc[:, :d], kv_loc[:, d:], H, amax)
-            self.kv_gather.allreduce_max(amax[1:3])
+            if start:
+                self.ops.attention_fp8_kv_amax(kv_loc[:, :d], kv_loc[:, d:], H, amax)
+                self.kv_gather.allreduce_max(amax[1:3])
             for off8, rows8, r0, r1 in self._kv8_chunks:
                 blob = loc8[off8: off8 + rows8]
-                self.ops.attention_fp8_quantize_kv(kv_loc[r0:r1, :d], kv_loc[r0:r1, d:], H, amax, blob.view(-1))
+                if start:
+                    self.ops.attention_fp8_quantize_kv(kv_loc[r0:r1, :d], kv_loc[r0:r1, d:], H, amax, blob.view(-1))
                 full = full8[world * off8: world * (off8 + rows8)]
                 bufs.append((full, r1 - r0, amax))
-                handles.append(self.kv_gather.start(blob, full))
+                handles.append(self.kv_gather.start(blob, full) if start else ())
             return handles, bufs
         kv_full = self.kv_full if kv_full is None else kv_full
         bufs = _ChunkBufs()
@@ -559,12 +569,13 @@ class WanDiT:
             r0, r1 = b[c], b[c + 1]
             full = kv_full[world * r0: world * r1]
             bufs.append((full[:, :d], full[:, d:]))            # strided views: the kernels take a row stride
-            handles.append(self.kv_gather.start(kv_loc[r0:r1], full))
+            handles.append(self.kv_gather.start(kv_loc[r0:r1], full) if start else ())
         return handles, bufs
 
-    def _sp_attention(self, q, handles, bufs, H, scale, att=None):
+    def _sp_attention(self, q, handles, bufs, H, scale, att=None, from_memory: bool = False):
         """K6 pipelined with K13: attention consumes chunk c as soon as it has landed, carrying the
-        online-softmax state in fp32 between launches, while later chunks are still in flight."""
+        online-softmax state in fp32 between launches, while later chunks are still in flight.
+        ``from_memory`` (bench.py's probe): the same launches over rows that are already there - no wait, no flag."""
         ops = self.ops
         att = self.att if att is None else att
         C = len(bufs)
@@ -577,12 +588,12 @@ class WanDiT:
             for c in range(C):
                 kf, vf = bufs[c]
                 m = kf.shape[0] // world
-                fl, entries = kg.arrival(handles[c])
+                fl, entries = (None, [(j, -1, 0) for j in range(world) if j != rank]) if from_memory else kg.arrival(handles[c])
                 flags = fl if fl is not None else flags
                 for j, idx, val in sorted(entries, key=lambda e: (e[0] - rank) % world):
                     pieces.append((kf[j * m:(j + 1) * m], vf[j * m:(j + 1) * m], idx if fl is not None else -1, val))
             ops.attention_pieces(q, pieces, att, H, scale, flags=flags, err=self.sp_err, timeout_us=self.sp_timeout_us)
-            for c in range(C):
+            for c in range(C if not from_memory else 0):
                 kg.consumed(handles[c])
             return
         wire = getattr(self, "fp8_wire", False)
@@ -592,7 +603,8 @@ class WanDiT:
                 ws = ops.attention_fp8_with_amax(ws, bufs[0][2])     # this branch's abs-max table (queries' row written here)
             ops.attention_fp8_prepare(ws, H, q=q)                       # queries once per layer, under the first transfer
         for c in range(C):
-            self.kv_gather.wait(handles[c])
+            if not from_memory:
+                self.kv_gather.wait(handles[c])
             if wire:
                 full, m, amax = bufs[c]
                 ops.attention_fp8_pieces(ws, amax, full.view(-1), m, self.plan.world, q.shape[0], att, self.sp_acc, self.sp_ml, H,

@@ -599,7 +599,7 @@ class _IpcWork:
 
     def consumed(self):
         """The consumer gated on the arrival flags itself: bookkeeping only (no stream waits are enqueued)."""
-        self.heap.native.check(self.heap.lib.icv_ipc_gather_wait(self.heap.handle, self.ticket, None), "icv_ipc_gather_wait")
+        self.heap.native.check(self.heap.lib.icv_ipc_gather_consumed(self.heap.handle, self.ticket), "icv_ipc_gather_consumed")
 
 
 class _FlaggedWork:
@@ -664,7 +664,7 @@ def gather_latent(latent: torch.Tensor, plan: ShardPlan, grid, group=None) -> to
     return full.reshape(T, Hp, Wp, C, 2, 2).permute(3, 0, 1, 4, 2, 5).reshape(C, T, H8, W8).contiguous()
 
 
-def autotune_kv_exchange(model, run_layers, sync, candidates=None, reps: int = 2, reduce_max=None, log=None, exchange_only=None):
+def autotune_kv_exchange(model, run_layers, sync, candidates=None, reps: int = 2, reduce_max=None, log=None, exchange_only=None, probe=None):
     """Start-up choice of the K|V exchange (transport x chunk count) by MEASUREMENT on the ranks that will run it.
 
     xGMI is point-to-point and what RCCL schedules over it is not known before the first contact: ``allgather`` may ring
@@ -683,9 +683,12 @@ def autotune_kv_exchange(model, run_layers, sync, candidates=None, reps: int = 2
     propagates (the launch ladder above, multigpu / launch_guard, abandons the process group and falls back to its next plan).
     ``exchange_only()`` (optional): one layer's exchange with nothing to hide under; its time is recorded next to the layer time
     (``exchange_ms``: the raw transfer, for the bandwidth it implies), never used for the choice.
+    ``probe(mode, chunks) -> dict`` (optional): further per-candidate measurements merged into the candidate's row (bench.py: the
+    self-attention under the real exchange next to the same launches served from memory; for "ipc" whether a pull needs CUs); it
+    runs on every rank at the same point, after the timed layers, and may use collectives symmetrically; never used for the choice.
     Returns (best (mode, chunks), table of dict rows)."""
     import time
-    cands = list(candidates or [(m, c) for m in ("allgather", "p2p", "native", "ipc") for c in (4, 2)])
+    cands = list(candidates or [(m + sfx, c) for m in ("allgather", "p2p", "native", "ipc") for sfx, c in (("+arrival", 4), ("", 4), ("", 2))])
     table = []
     for mode, chunks in cands:
         err = ""
@@ -718,9 +721,14 @@ def autotune_kv_exchange(model, run_layers, sync, candidates=None, reps: int = 2
             xms = 1e3 * (time.perf_counter() - t0) / 3
         if reduce_max is not None:
             ms, xms = reduce_max([ms, xms])
-        table.append(dict(kv_exchange=mode, sp_chunks=chunks, ms=ms, error=None, exchange_ms=xms or None))
+        row = dict(kv_exchange=mode, sp_chunks=chunks, ms=ms, error=None, exchange_ms=xms or None)
+        if probe is not None:
+            row.update(probe(mode, chunks) or {})
+        table.append(row)
         if log:
-            log(f"autotune {mode:9s} chunks {chunks}: {ms:.2f} ms" + (f" (exchange alone {xms:.2f} ms)" if xms else ""))
+            log(f"autotune {mode:17s} chunks {chunks}: {ms:.2f} ms" + (f" (exchange alone {xms:.2f} ms)" if xms else "")
+                + "".join(f"; {k} {v:.3f}" if isinstance(v, float) else f"; {k} {v}" for k, v in row.items()
+                          if k not in ("kv_exchange", "sp_chunks", "ms", "error", "exchange_ms")))
     usable = [(r["ms"], i) for i, r in enumerate(table) if r["ms"] is not None]
     if not usable:
         raise RuntimeError(f"K|V exchange autotune: no transport worked: {table}")

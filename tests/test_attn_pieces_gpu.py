@@ -100,17 +100,22 @@ def test_rows_that_land_after_the_launch_started(hip_ops, Sq, H, late_ms):
     trace = torch.zeros((nwg, 4), dtype=torch.int64, device=DEV)
     mark = torch.zeros((2,), dtype=torch.int64, device=DEV)
     side = torch.cuda.Stream(device=DEV)
-    torch.cuda.synchronize()
     o = torch.zeros_like(want)
-    pieces = [(views[0][0], views[0][1], -1, 0), (views[1][0], views[1][1], 1, 7), (views[2][0], views[2][1], 2, 7), (views[3][0], views[3][1], -1, 0)]
-    hip_ops.attention_pieces(q, pieces, o, H, SCALE, flags=flags, err=err, timeout_us=5_000_000, trace=trace)
-    with torch.cuda.stream(side):
-        kv[bounds[1]:bounds[2]].copy_(staged[bounds[1]:bounds[2]])            # the early peer: rows, then its flag
-        hip_ops.flag_write(flags, 1, 7)
-        hip_ops.flag_write(mark.view(torch.int32), 0, 1, delay_us=late_ms * 1000)   # hold the stream: the late peer
-        kv[bounds[2]:bounds[3]].copy_(staged[bounds[2]:bounds[3]])
-        hip_ops.flag_write(flags, 2, 7)
-    torch.cuda.synchronize()
+    for value in (7, 8):          # twice: the first pass pays the side stream's first-use costs (its queue, the copy kernels' module load)
+        kv[bounds[1]:bounds[3]] = float("nan")
+        trace.zero_()
+        o.zero_()
+        torch.cuda.synchronize()
+        pieces = [(views[0][0], views[0][1], -1, 0), (views[1][0], views[1][1], 1, value), (views[2][0], views[2][1], 2, value),
+                  (views[3][0], views[3][1], -1, 0)]
+        hip_ops.attention_pieces(q, pieces, o, H, SCALE, flags=flags, err=err, timeout_us=5_000_000, trace=trace)
+        with torch.cuda.stream(side):
+            kv[bounds[1]:bounds[2]].copy_(staged[bounds[1]:bounds[2]])            # the early peer: rows, then its flag
+            hip_ops.flag_write(flags, 1, value)
+            hip_ops.flag_write(mark.view(torch.int32), 0, 1, delay_us=late_ms * 1000)   # hold the stream: the late peer
+            kv[bounds[2]:bounds[3]].copy_(staged[bounds[2]:bounds[3]])
+            hip_ops.flag_write(flags, 2, value)
+        torch.cuda.synchronize()
     assert int(err.item()) == 0, f"a work-group gave up waiting: err word {int(err.item()) & 0xffffffff:#x}"
     assert torch.isfinite(o.float()).all(), "rows were read before they landed"
     assert torch.equal(o, want), "late rows: result differs from the all-present launch"

@@ -99,7 +99,7 @@ def test_hip_matches_reference_golden(name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", CASES)
 def test_hip_device_sampling_vs_reference_golden(name):
-    """The opt-in ``sampling="device"`` path draws the <= 100000-point quantile sample on the device (stratified, unseeded like the
+    """The default ``sampling="device"`` path (round 6; opt-in before) draws the <= 100000-point quantile sample on the device (stratified, unseeded like the
     reference's own draw): with <= 100000 finite points ("small", "allsky") the sample is every finite point and the bytes
     equal the reference's; with more ("big": 118 640) the two 100000-point samples differ by design and the quantile
     estimates with them — bar: every uint8 within +-1 of the reference's output, at most 2 % of the bytes off by one."""
@@ -108,7 +108,7 @@ def test_hip_device_sampling_vs_reference_golden(name):
     k = cam.get_intrinsics_matrix()
     same_host_math = (np.array_equal(torch.inverse(k).numpy(), G[f"{name}_kinv"]) and np.array_equal(
         torch.einsum("ij,bjk->bik", torch.inverse(poses[0]), poses).numpy(), G[f"{name}_to_cam0"]))
-    u8 = gen(depth, cam, poses, percentile=0.05, return_uint8=True, sampling="device").cpu().numpy()   # the opt-in device-side draw
+    u8 = gen(depth, cam, poses, percentile=0.05, return_uint8=True, sampling="device").cpu().numpy()   # the device-side draw (the default)
     diff = np.abs(u8.astype(np.int16) - want_u8.astype(np.int16))
     frac = float((diff > 0).mean())
     print(f"[{name}] device-sampled coordinate buffer vs the reference's bytes: max |diff| {diff.max()}, {100 * frac:.3f} % of bytes differ")

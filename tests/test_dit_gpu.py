@@ -310,6 +310,35 @@ def test_copy_engine_transport_one_rank_rehearsal(hip_ops):
     assert torch.isfinite(lats["ipc"]).all() and torch.equal(lats["ipc"], lats["allgather"])
 
 
+@pytest.mark.parametrize("mode", ["allgather+arrival", "ipc+arrival"])
+def test_arrival_driven_attention_one_rank_rehearsal(hip_ops, mode):
+    """The arrival-driven self-attention (csrc/attn7p.hip: ONE launch per layer over the K|V pieces) on the one rank a one-GPU
+    process has: the sequence-parallel schedule with the engine's own rows as the only piece.  One piece of whole tiles in memory
+    order is the plain kernel's tile sequence, so an 8-step CFG loop must be BIT-IDENTICAL to the same schedule on the chunked
+    carried-state launches with ONE chunk (a single launch over the same rows; 3 chunks re-associate the fp32 sums).  With
+    "ipc": the transport runs without its own-rows copy (icv_ipc_configure), tickets are released by icv_ipc_gather_consumed
+    (the 32-slot ring wraps), and no device-side wait may have given up.  The peers' half: tests/test_multigpu_rccl.py."""
+    grid = TokenGrid(9, 64, 96)
+    cfg, sd, bsd, _, _ = _setup("tiny", grid)
+    noise, c1, c2, bl = syn.make_latent_noise(grid), syn.make_text_context(cfg, 1), syn.make_text_context(cfg, 2), syn.make_buffer_latents(cfg, grid)
+    lats = {}
+    for kv, chunks in ((mode.split("+")[0], 1), (mode, 3)):
+        m = WanDiT(cfg, sd, hip_ops, bsd).prepare(grid, force_sp=True, kv_exchange=kv, sp_chunks=chunks)
+        assert m.sp_on and m.attn_arrival == kv.endswith("+arrival") and m.kv_gather.mode == kv.split("+")[0]
+        lat = noise.clone().to("cuda:0")
+        m.denoise(lat, m.encode_context(c1), m.encode_context(c2), m.embed_buffers(bl), FlowMatchScheduler(8), 5.0)
+        torch.cuda.synchronize()
+        lats[kv] = lat.clone()
+        if m.attn_arrival:
+            assert int(m.sp_err.item()) == 0
+            m.check_exchange()
+            if kv.startswith("ipc"):
+                assert hip_ops.lib.icv_ipc_tickets(m.kv_gather._heap.handle) > 32, "the loop must wrap the flag-slot ring"
+        m.kv_gather.close()
+    a, b = lats[mode.split("+")[0]], lats[mode]
+    assert torch.isfinite(b).all() and torch.equal(a, b), f"arrival-driven vs one chunked launch: max |d| {float((a - b).abs().max())}"
+
+
 def test_copy_engine_transport_refuses_misuse(hip_ops):
     """icv_ipc_* error paths on one rank: rows outside the symmetric heap, a heap that is too small for what is carved from it,
     more than ICV_IPC_SLOTS exchanges without a wait, a wait for a ticket that is not in flight - each a clean error, not a hang."""
@@ -567,7 +596,7 @@ def test_pipeline_i2v_with_the_real_vae_and_clip_modules_on_gpu(monkeypatch):
 
 @pytest.mark.parametrize("name,mode", [("tiny", "bf16"), ("tiny-i2v", "bf16"), ("tiny", "fp8"), ("tiny-i2v", "fp8"),
                                        ("tiny", "sp"), ("tiny", "sp-torch"), ("tiny-i2v", "sp+fp8")])
-def test_native_forward_matches_python_driver(hip_ops, name, mode):
+def test_native_forward_matches_python_driver(hip_ops, name, mode, monkeypatch):
     """icv_dit_create / icv_dit_bind / icv_dit_forward (the whole forward enqueued by ONE C call) against the per-op
     driver in dit.py: the same launchers in the same order, so the velocity tokens and a whole CFG denoise loop are
     bit-identical, with and without the shared stem; binding errors are reported through the ABI.
@@ -586,6 +615,14 @@ def test_native_forward_matches_python_driver(hip_ops, name, mode):
     y = syn.make_cond_latents(cfg, grid) if cfg.has_image_input else None
     fp8, sp = "fp8" in mode, mode.startswith("sp")
     kw = dict(gemm_dtype="fp8", attn_dtype="fp8") if fp8 else {}
+    if fp8 and sp:
+        # like with like: the C driver gathers bf16 rows and quantises each gathered chunk; the per-op driver's default since
+        # round 5 is e4m3 ON THE WIRE (quantised once with group-wide scales), which the C driver does not implement - and refuses
+        eng = WanDiT(cfg, sd, hip_ops, bsd, **kw).prepare(grid, graphs=False, force_sp=True, sp_chunks=3, kv_exchange="native")
+        eng.native_forward = True
+        assert eng.fp8_wire and not eng._native_eligible(), "the C driver must stand down for the e4m3 wire format"
+        eng.kv_gather.close()
+        monkeypatch.setenv("ICV_FP8_WIRE", "bf16")
     outs = {}
     for native_on in (False, True):
         m = WanDiT(cfg, sd, hip_ops, bsd, **kw).prepare(grid, graphs=False, force_sp=sp, sp_chunks=3,

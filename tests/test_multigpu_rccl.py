@@ -165,6 +165,25 @@ def test_shared_gpu_copy_engine_transport_is_bit_identical_to_allgather(tmp_path
     assert torch.equal(got["result"], ref["result"]), "the copy-engine transport moved different bytes than the collective one"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,kv_exchange", [(2, "ipc+arrival"), (4, "ipc+arrival"), (4, "allgather+arrival"), (4, "p2p+arrival")])
+def test_shared_gpu_arrival_driven_attention(tmp_path, gpu_single, world, kv_exchange):
+    """SURVEY §8e "process K/V chunks in arrival order (own shard first) with online-softmax merging" between REAL processes: N ranks
+    sharing the one GPU run the `sp` loop with ONE arrival-gated attention launch per layer and branch (csrc/attn7p.hip): this
+    rank's own rows are read in place, every (row chunk, peer) piece is gated inside the kernel on the flag its transfer raises - the
+    copy-engine transport's per-peer device word (icv_ipc_arrival), or one flag per chunk written by a side stream that waited for the
+    collective (icv_flag_write).  Against the single-GPU loop at the N-rank bar (only the softmax merge order and the bf16
+    roundings it moves change), and against the SAME ranks on the chunked launches (also not bit-identical: pieces re-associate the
+    fp32 sums differently from chunks).  No rank may report a wait that gave up (WanDiT.check_exchange runs at the end of the loop)."""
+    args = ["--backend", "gloo", "--share-gpu"] + GPU_TINY[2:] + ["--scenario", "loop", "--parallelism", "sp"]
+    got = run_ranks(world, str(tmp_path / "arrival.pt"), args + ["--kv-exchange", kv_exchange], extra_env={"GPU_MAX_HW_QUEUES": "16"})
+    ref = run_ranks(world, str(tmp_path / "chunked.pt"), args + ["--kv-exchange", kv_exchange.split("+")[0]], extra_env={"GPU_MAX_HW_QUEUES": "16"})
+    # (the arrival-driven schedule cuts its row chunks on the 64-key tile grid: these small shards give it fewer chunks than the chunked arm)
+    assert got["info"]["world"] == world and got["info"]["kv_exchange"] == kv_exchange and 0 < got["info"]["kv_collectives"] <= ref["info"]["kv_collectives"]
+    _close(got, gpu_single["loop"], f"gloo x{world} on one GPU, sp / {kv_exchange}", rel_bound=1e-2, psnr_bound=50.0)
+    _close(got, ref, f"arrival-driven vs chunked launches, x{world} {kv_exchange}", rel_bound=1e-2, psnr_bound=50.0)
+
+
 IPC_ABORT_WORKER = r"""
 import os, sys, time, torch, torch.distributed as dist
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])

@@ -138,6 +138,49 @@ def test_conv_full_tile_size_sampled_rows_and_linearity():
     assert float(a.float().abs().mean()) > 0.1
 
 
+def test_conv_volume_beyond_4_gib_is_cut_into_row_ranges():
+    """a lane's A-row position is a 32-bit byte offset from the operand base, so one launch covers < 4 GiB of rows - a
+    192-channel (384 with the time-upsample's doubled channels) full-resolution decoder volume of a 240 x 416 tile reaches that at
+    109 frames, an untiled 480p volume exceeds it outright.  icv_conv3d_ndhwc now cuts the rows into ranges with shifted bases.
+    Here: 60 frames of [242, 418] positions x 384 channels = 4.66 GB of input rows, causal (3,1,1) taps (the time-upsample's
+    geometry; its taps reach two FRAMES back across every range boundary) 384 -> 32.  (a) the rows of the last 3 frames - all of
+    them beyond the 4 GiB mark - must be BIT-IDENTICAL to the same frames computed as their own short volume (same taps, same K
+    order); (b) sampled positions across the whole volume, also next to the cut, against a direct fp32 evaluation."""
+    dev = _dev()
+    torch.manual_seed(9)
+    T, H, W, C, CO = 60, 240, 416, 384, 32
+    mod = V.CausalConv3d(C, CO, (3, 1, 1), padding=(1, 0, 0))
+    with torch.no_grad():
+        mod.weight.copy_((mod.weight * 4).to(torch.bfloat16).float())
+    hip = VH.VaeHip(nn.Identity(), dev)
+    xv = VH.Vol(T, H, W, C, dev)
+    assert xv.rows * C * 2 > (1 << 32)
+    for t0 in range(0, T, 10):                                               # filled in slabs: randn of the whole volume would need 9 GB of fp32
+        xv.interior()[t0:t0 + 10].copy_((torch.randn((min(10, T - t0), H, W, C), device=dev) * 0.5).to(torch.bfloat16))
+    xv.zero_halo()
+    out = hip.conv(xv, mod, VH.TAPS_311)
+    torch.cuda.synchronize()
+    # (a) the last 3 frames as their own volume whose two causal padding frames hold frames T-5, T-4
+    sv = VH.Vol(3, H, W, C, dev)
+    sv.vol().copy_(xv.vol()[T - 3:])                                         # padded frame index = frame + 2: frames T-5 .. T-1
+    so = hip.conv(sv, mod, VH.TAPS_311)
+    torch.cuda.synchronize()
+    assert torch.equal(out.interior()[T - 3:], so.interior()), "rows beyond the 4 GiB mark differ from the same rows computed on a short volume"
+    # (b) sampled positions, fp32
+    g = torch.Generator().manual_seed(5)
+    cut_frame = int((((1 << 32) - 1) // (C * 2)) // 256 * 256 // xv.frame_rows)      # the real frame the first cut falls into (ranges start at the first real row)
+    assert 2 < cut_frame < T - 2
+    pos = [(0, 0, 0), (T - 1, H - 1, W - 1), (cut_frame, 0, 0), (cut_frame, H - 1, W - 1), (cut_frame + 1, 5, 7), (cut_frame - 1, 100, 200)]
+    pos += [(int(torch.randint(0, T, (1,), generator=g)), int(torch.randint(0, H, (1,), generator=g)), int(torch.randint(0, W, (1,), generator=g))) for _ in range(250)]
+    t_i, h_i, w_i = (torch.tensor(v, device=dev) for v in zip(*pos))
+    xp = xv.vol()
+    w = mod.weight.detach().to(dev).float()                                  # [co, ci, 3, 1, 1]
+    ref = mod.bias.detach().to(dev).float()[None].repeat(len(pos), 1)
+    for dt in range(3):
+        ref += xp[t_i + dt, h_i + 1, w_i + 1].float() @ w[:, :, dt, 0, 0].t()
+    _per_op_ok(out.interior()[t_i, h_i, w_i, :CO].float(), ref, "(3,1,1) 384->32 over a 4.66 GB volume, sampled positions")
+
+
 def test_stride2_forms_match_torch():
     """The encoder's two strided convolutions through their stride-1 evaluation + subsampling (VaeHip.downsample)."""
     dev = _dev()

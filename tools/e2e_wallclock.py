@@ -30,6 +30,55 @@ class HashTokenizer:
         return {"input_ids": ids, "attention_mask": mask}
 
 
+def synthetic_factory(torch_dtype, device, model_configs):
+    """The random-init pipeline of this tool as a module-level factory: what every rank of a worker pool builds
+    (ICV_WORLD=N ICV_WORKER_FACTORY=e2e_wallclock:synthetic_factory PYTHONPATH=tools; MODEL=14b|1.3b picks the DiT)."""
+    dev = WanVideoPipeline.resolve_device(device)
+    cfg = preset(os.environ.get("MODEL", "14b"))
+    sd = syn.make_dit_state_dict(cfg, seed=0, device=dev, dtype=torch.bfloat16)
+    with torch.device(dev):
+        t5 = UMT5Encoder().to(torch.bfloat16).eval()
+    return WanVideoPipeline(dev, torch_dtype, DiTHolder(sd, cfg), UMT5TextEncoder(t5, HashTokenizer(), dev), WanVAE(WanVAENet(), dev, torch.bfloat16))
+
+
+def run_e2e_pool(model="14b", steps=50, gemm="bf16", log=print):
+    """The same two generate() calls with ICV_WORLD=N ranks behind the UNCHANGED caller (multigpu.WorkerPool: N fresh worker
+    processes, this process is their client): wall-clock as the caller sees it, the pool's plan record (layout, K|V transport,
+    per-rank runtime environment) and the ranks' K|V autotune table.  No stage table: the stages run in the workers."""
+    os.environ["MODEL"] = model
+    os.environ.setdefault("ICV_WORKER_FACTORY", "e2e_wallclock:synthetic_factory")
+    os.environ["PYTHONPATH"] = os.pathsep.join([os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                os.environ.get("PYTHONPATH", "")])
+    dtype = torch.float8_e4m3fn if gemm == "fp8" else torch.bfloat16
+    cfg, grid = preset(model), GRID_480P
+    ck = os.path.join(tempfile.mkdtemp(), "step-1.safetensors")
+    save_file({"buffer_embedder." + k: v for k, v in syn.make_buffer_embedder_state_dict(cfg).items()}, ck)
+    t0 = time.perf_counter()
+    gen = WanVideoGenerator(ck, device="cuda:0", torch_dtype=dtype, use_wan_1pt3b=(model == "1.3b"))
+    if gen._pool is None:
+        raise SystemExit("ICV_WORLD is set but no multi-GPU plan could be started (see stderr)")
+    log(f"pool of {gen._pool.world} ranks ready after {time.perf_counter() - t0:.1f} s (random weights on every rank; not part of the metric)")
+    sem, co = syn.make_dummy_buffers(grid)
+    out_mp4 = os.path.join(tempfile.mkdtemp(), "out.mp4")
+    gen.pipe.num_inference_steps = steps
+    marks, tuned = {}, None
+    try:
+        for label in ("first", "run"):
+            t = time.perf_counter()
+            frames = gen.generate(semantic_buffer=sem, coordinate_buffer=co, seed=0, tiled=True, output_path=out_mp4)
+            marks[label] = time.perf_counter() - t
+            assert len(frames) == grid.num_frames and frames[0].size == (grid.width, grid.height)
+            tuned = (gen._pool.last_reply or {}).get("kv_autotune") or tuned
+            log(f"{label}: {marks[label]:.1f} s")
+        rec = gen._pool.plan_record()
+    finally:
+        gen._pool.close()
+    return {"model": cfg.name, "gemm_dtype": gemm, "frames": grid.num_frames, "height": grid.height, "width": grid.width, "steps": steps,
+            "n_ranks": rec["world"], "generate_wallclock_s": marks["run"], "first_call_s": marks["first"], "pool": rec, "kv_autotune": tuned,
+            "note": "first call includes the ranks' K|V autotune (seconds in kv_autotune)", "mp4_bytes": os.path.getsize(out_mp4),
+            "weights": "random-init DiT / UMT5-XXL / Wan-VAE architectures on every rank (no checkpoint offline), hash tokenizer"}
+
+
 def run_e2e(model="14b", steps=50, gemm="bf16", dev="cuda:0", log=print, first_steps=None):
     """Two whole WanVideoGenerator.generate() calls (93 frames 480p, tiled VAE, mp4 written) with random-init weights of the real
     architectures in ONE fresh process: the FIRST call of the process (``first_steps`` steps, default = ``steps``: what a user of
@@ -128,5 +177,9 @@ def run_e2e(model="14b", steps=50, gemm="bf16", dev="cuda:0", log=print, first_s
 
 if __name__ == "__main__":
     fs = os.environ.get("FIRST_STEPS")
+    if os.environ.get("ICV_WORLD"):
+        print(json.dumps(run_e2e_pool(os.environ.get("MODEL", "14b"), int(os.environ.get("STEPS", 50)), os.environ.get("GEMM", "bf16"),
+                                      log=lambda m: print(m, flush=True))))
+        sys.exit(0)
     print(json.dumps(run_e2e(os.environ.get("MODEL", "14b"), int(os.environ.get("STEPS", 50)), os.environ.get("GEMM", "bf16"),
                              log=lambda m: print(m, flush=True), first_steps=int(fs) if fs else None)))
