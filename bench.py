@@ -537,10 +537,14 @@ def run_rank(args, world, rank, phase, stdout_fd):
                 out["attn_under_exchange_ms"], out["attn_from_memory_ms"] = reduce_max([out["attn_under_exchange_ms"], out["attn_from_memory_ms"]])
                 heap = getattr(model.kv_gather, "_heap", None)
                 if heap is not None and peers > 0:
-                    sync()
-                    kind, ms_copy = heap.probe_copy((layout.sp_rank + 1) % layout.sp_world)
-                    out["ipc_peer_copy"] = kind
-                    out["ipc_peer_copy_8mib_ms"] = ms_copy
+                    # the ranks take turns: the probe fills its device with an occupier kernel, which ranks that SHARE a GPU (the 1-GPU
+                    # rehearsal) would do to each other, and on a real node a neighbour's concurrent pull would muddy the copy's timing
+                    for turn in range(world):
+                        sync()
+                        if turn == rank:
+                            kind, ms_copy = heap.probe_copy((layout.sp_rank + 1) % layout.sp_world)
+                            out["ipc_peer_copy"] = kind
+                            out["ipc_peer_copy_8mib_ms"] = ms_copy
                     sync()
                 return out
 
@@ -553,6 +557,7 @@ def run_rank(args, world, rank, phase, stdout_fd):
 
             (args.kv_exchange, args.sp_chunks), table = autotune_kv_exchange(
                 model, two_layers, sync, cands, reps=2, reduce_max=reduce_max, exchange_only=exchange_only, probe=attn_probe,
+                on_candidate=lambda m, c: phase(f"autotune:{m}/{c}"),          # one supervisor phase (its own budget) per candidate
                 log=(lambda m: print(f"[bench] {m}", file=sys.stderr, flush=True)) if rank == 0 else None)
             recv = 2 * 2 * plan.n_tok * cfg.dim * (layout.sp_world - 1)         # bytes each rank RECEIVES per layer exchange (k | v rows, bf16)
             for row in table:

@@ -269,7 +269,9 @@ class KVGather:
             for w in works:
                 w.wait()
             self._arrival_ops.flag_write(self._flags, slot, value)
-        return (_FlaggedWork(tuple(works), slot, value),)
+            flagged = torch.cuda.Event()
+            flagged.record()
+        return (_FlaggedWork(tuple(works), slot, value, flagged),)
 
     def start(self, rows: torch.Tensor, out: torch.Tensor):
         assert rows.is_contiguous() and out.is_contiguous() and out.shape[0] == self.plan.world * rows.shape[0]
@@ -603,14 +605,15 @@ class _IpcWork:
 
 
 class _FlaggedWork:
-    """Work handles of one collective row-chunk whose completion a side stream turns into an arrival flag (KVGather.enable_arrival)."""
+    """Work handles of one collective row-chunk whose completion a side stream turns into an arrival flag (KVGather.enable_arrival).
+    The side stream has ALREADY waited for the works (a gloo send / recv work must not be waited for twice: the second wait blocks
+    until its time-out): ``wait()`` makes the current stream wait for the side stream's flag write instead."""
 
-    def __init__(self, works, slot: int, value: int):
-        self.works, self.slot, self.value = works, slot, value
+    def __init__(self, works, slot: int, value: int, flagged: "torch.cuda.Event"):
+        self.works, self.slot, self.value, self.flagged = works, slot, value, flagged
 
     def wait(self):
-        for w in self.works:
-            w.wait()
+        torch.cuda.current_stream().wait_event(self.flagged)
 
 
 class _EventWork:
@@ -664,7 +667,8 @@ def gather_latent(latent: torch.Tensor, plan: ShardPlan, grid, group=None) -> to
     return full.reshape(T, Hp, Wp, C, 2, 2).permute(3, 0, 1, 4, 2, 5).reshape(C, T, H8, W8).contiguous()
 
 
-def autotune_kv_exchange(model, run_layers, sync, candidates=None, reps: int = 2, reduce_max=None, log=None, exchange_only=None, probe=None):
+def autotune_kv_exchange(model, run_layers, sync, candidates=None, reps: int = 2, reduce_max=None, log=None, exchange_only=None, probe=None,
+                         on_candidate=None):
     """Start-up choice of the K|V exchange (transport x chunk count) by MEASUREMENT on the ranks that will run it.
 
     xGMI is point-to-point and what RCCL schedules over it is not known before the first contact: ``allgather`` may ring
@@ -686,11 +690,15 @@ def autotune_kv_exchange(model, run_layers, sync, candidates=None, reps: int = 2
     ``probe(mode, chunks) -> dict`` (optional): further per-candidate measurements merged into the candidate's row (bench.py: the
     self-attention under the real exchange next to the same launches served from memory; for "ipc" whether a pull needs CUs); it
     runs on every rank at the same point, after the timed layers, and may use collectives symmetrically; never used for the choice.
+    ``on_candidate(mode, chunks)`` (optional) is called before each candidate (bench.py reports a supervisor phase per candidate: each
+    gets its own time budget, and a hang is blamed on the candidate that caused it).
     Returns (best (mode, chunks), table of dict rows)."""
     import time
     cands = list(candidates or [(m + sfx, c) for m in ("allgather", "p2p", "native", "ipc") for sfx, c in (("+arrival", 4), ("", 4), ("", 2))])
     table = []
     for mode, chunks in cands:
+        if on_candidate is not None:
+            on_candidate(mode, chunks)
         err = ""
         try:
             model.set_kv_exchange(mode, chunks)

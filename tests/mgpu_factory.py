@@ -67,3 +67,22 @@ def gpu_real_vae_factory(torch_dtype, device, model_configs):
     pipe = WanVideoPipeline(dev, torch_dtype, DiTHolder(syn.make_dit_state_dict(CFG), CFG), HashTextEncoder(CFG), vae, ops=HipOps(dev))
     pipe.num_inference_steps = 2
     return pipe
+
+
+class _FlakyPipeline(WanVideoPipeline):
+    """Rank 1's SECOND request fails in the middle of the pipeline call (after the ranks have entered their collectives)."""
+    calls = 0
+
+    def __call__(self, *a, **k):
+        import os
+        type(self).calls += 1
+        if os.environ.get("ICV_WORKER_RANK") == "1" and type(self).calls == 2:
+            raise RuntimeError("synthetic failure in the middle of request 2 on rank 1")
+        return super().__call__(*a, **k)
+
+
+def flaky_factory(torch_dtype, device, model_configs):
+    torch.set_num_threads(2)
+    pipe = _FlakyPipeline(device, torch_dtype, DiTHolder(syn.make_dit_state_dict(CFG), CFG), HashTextEncoder(CFG), PoolVAE(), ops=OracleOps())
+    pipe.num_inference_steps = 2
+    return pipe

@@ -314,7 +314,7 @@ def test_copy_engine_transport_one_rank_rehearsal(hip_ops):
 def test_arrival_driven_attention_one_rank_rehearsal(hip_ops, mode):
     """The arrival-driven self-attention (csrc/attn7p.hip: ONE launch per layer over the K|V pieces) on the one rank a one-GPU
     process has: the sequence-parallel schedule with the engine's own rows as the only piece.  One piece of whole tiles in memory
-    order is the plain kernel's tile sequence, so an 8-step CFG loop must be BIT-IDENTICAL to the same schedule on the chunked
+    order is the plain kernel's tile sequence, so a 12-step CFG loop must be BIT-IDENTICAL to the same schedule on the chunked
     carried-state launches with ONE chunk (a single launch over the same rows; 3 chunks re-associate the fp32 sums).  With
     "ipc": the transport runs without its own-rows copy (icv_ipc_configure), tickets are released by icv_ipc_gather_consumed
     (the 32-slot ring wraps), and no device-side wait may have given up.  The peers' half: tests/test_multigpu_rccl.py."""
@@ -326,7 +326,7 @@ def test_arrival_driven_attention_one_rank_rehearsal(hip_ops, mode):
         m = WanDiT(cfg, sd, hip_ops, bsd).prepare(grid, force_sp=True, kv_exchange=kv, sp_chunks=chunks)
         assert m.sp_on and m.attn_arrival == kv.endswith("+arrival") and m.kv_gather.mode == kv.split("+")[0]
         lat = noise.clone().to("cuda:0")
-        m.denoise(lat, m.encode_context(c1), m.encode_context(c2), m.embed_buffers(bl), FlowMatchScheduler(8), 5.0)
+        m.denoise(lat, m.encode_context(c1), m.encode_context(c2), m.embed_buffers(bl), FlowMatchScheduler(12), 5.0)
         torch.cuda.synchronize()
         lats[kv] = lat.clone()
         if m.attn_arrival:

@@ -188,7 +188,7 @@ def test_layer_14b_i2v_720p(hip_ops, mode):
         assert cos >= 0.998 and rel <= 6e-2, f"14B i2v fp8 block at S=86400: rel-L2 {rel}, cosine {cos}"
 
 
-@pytest.mark.parametrize("world,attn_dtype", [(4, "bf16"), (8, "bf16"), (8, "fp8")])
+@pytest.mark.parametrize("world,attn_dtype", [(4, "bf16"), (8, "bf16"), (8, "fp8"), (4, "bf16+arrival"), (8, "bf16+arrival")])
 def test_layer_14b_sequence_parallel_shards_full_S(hip_ops, world, attn_dtype):
     """Config #4's per-rank work at its real size on ONE GPU: a Wan2.1-14B block at S = 37 440 computed as the token shards
     of a `world`-rank sequence-parallel run (4 = the shards of the cfg2 x sp4 layout `bench.py --gpus 8` builds, 8 = plain
@@ -197,8 +197,12 @@ def test_layer_14b_sequence_parallel_shards_full_S(hip_ops, world, attn_dtype):
     1-GPU box cannot do; real ranks: tests/test_multigpu_rccl.py).  First, middle and last shard against the rows of the
     unsharded HIP block (a self-comparison: only the softmax merge order differs; e4m3 attention: per-chunk K / V scales), and the
     middle shard ALSO against oracle/wan_ref.py's rows for 1024 of its tokens - oracle parity at the exact per-rank shapes
-    (n = 9 360 and n = 4 680 query rows against 37 440 keys in 4 ramped chunks)."""
+    (n = 9 360 and n = 4 680 query rows against 37 440 keys in 4 ramped chunks).
+    "+arrival" (round 6): the same shards through ONE arrival-gated attention launch over the pieces (csrc/attn7p.hip: own rows in
+    place, then 4 chunks x (world - 1) peers = up to 29 pieces, chunk bounds on the 64-key tile grid) instead of the 4 chunk launches."""
     from infinicube_amd.videogen.seqpar import ShardPlan
+    arrival = attn_dtype.endswith("+arrival")
+    attn_dtype = attn_dtype.split("+")[0]
     cfg, grid, chunks = dataclasses.replace(preset("14b"), num_layers=1), GRID_480P, 4
     sd = syn.make_dit_state_dict(cfg, seed=0, device=DEV, dtype=torch.bfloat16)
     bsd = syn.make_buffer_embedder_state_dict(cfg, device=DEV, dtype=torch.bfloat16)
@@ -254,8 +258,20 @@ def test_layer_14b_sequence_parallel_shards_full_S(hip_ops, world, attn_dtype):
             def wait(self, handle):
                 pass
 
+            # arrival-driven consumer: every piece is there (no flag); own rows are read in place
+            def enable_arrival(self, ops):
+                pass
+
+            def arrival(self, handle):
+                return None, [(j, -1, 0) for j in range(world) if j != plan.rank]
+
+            def consumed(self, handle):
+                pass
+
         g = ServedGather()
-        m = WanDiT(cfg, sd, hip_ops, bsd, **kw).prepare(grid, plan, kv_gather=g, sp_chunks=chunks, graphs=False)
+        m = WanDiT(cfg, sd, hip_ops, bsd, **kw).prepare(grid, plan, kv_gather=g, sp_chunks=chunks, graphs=False,
+                                                        kv_exchange="allgather+arrival" if arrival else None)
+        assert m.attn_arrival == arrival and (not arrival or all(b % 64 == 0 for b in m.sp_bounds[1:-1]))
         m.forward_tokens(lat, m.encode_context(ctx), 731.0, m.embed_buffers(bl), m.head_out[0], num_layers=1)
         torch.cuda.synchronize()
         assert g.n_collectives == chunks and g.r0 == n

@@ -191,3 +191,41 @@ def test_pool_start_falls_back_plan_by_plan(tmp_path, monkeypatch, capfd, inject
         from infinicube_amd.videogen import multigpu
         multigpu._DEGRADED = None
     assert not dist.is_initialized()
+
+
+def test_a_rank_that_fails_in_the_middle_of_a_request_ends_the_pool_with_its_traceback(tmp_path, monkeypatch):
+    """One rank raises inside a request while its peers sit in that request's collectives: the client must get THAT rank's traceback
+    within seconds (not a collective timeout), tear the whole pool down (the survivors can never complete), refuse further requests
+    cleanly, and leave no worker process and no tmpfs blob behind."""
+    import glob
+    import time
+    import mgpu_factory as F
+    from infinicube.videogen import WanVideoGenerator
+    from infinicube_amd.videogen import synthetic as syn
+    path = _checkpoint(tmp_path)
+    monkeypatch.setenv("ICV_WORLD", "2")
+    monkeypatch.setenv("ICV_DIST_BACKEND", "gloo")
+    monkeypatch.setenv("ICV_WORKER_FACTORY", "mgpu_factory:flaky_factory")
+    monkeypatch.setenv("ICV_WORLD_TIMEOUT_S", "300")
+    monkeypatch.setenv("PYTHONPATH", os.pathsep.join([os.path.dirname(HERE), HERE, os.environ.get("PYTHONPATH", "")]))
+    sem, co = syn.make_dummy_buffers(F.GRID)
+    blobs_before = set(glob.glob("/dev/shm/icv_pool_*"))
+    g = None
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            g = WanVideoGenerator(path, device="cpu", use_wan_1pt3b=True, pipeline_factory=F.factory)
+            assert len(g.generate(sem, co, seed=3)) == F.GRID.num_frames
+            pids = [r["pid"] for r in g._pool.plan_record()["ranks"]]
+            t0 = time.time()
+            with pytest.raises(RuntimeError, match="synthetic failure in the middle of request 2 on rank 1"):
+                g.generate(sem, co, seed=4)
+            assert time.time() - t0 < 60
+            assert g._pool._closed and not g._pool.procs
+            with pytest.raises(RuntimeError, match="pool is closed"):
+                g.generate(sem, co, seed=5)
+        for pid in pids:
+            assert not os.path.exists(f"/proc/{pid}") or open(f"/proc/{pid}/stat").read().split()[2] == "Z", f"rank process {pid} survived the pool"
+        assert set(glob.glob("/dev/shm/icv_pool_*")) == blobs_before, "the request / frames blobs must go with the pool"
+    finally:
+        if g is not None and g._pool is not None:
+            g._pool.close()

@@ -107,7 +107,7 @@ def test_worker_pool_frames_with_the_tiled_vae_sharded_over_the_ranks(tmp_path, 
     g = None
     try:
         g, got = run()
-        assert dist.is_initialized() and dist.get_world_size() == 3 and g._pool is not None
+        assert not dist.is_initialized() and g._pool is not None and g._pool.world == 3      # the caller is the pool's client: N fresh rank processes behind it
         d = np.abs(ref.astype(np.int16) - got.astype(np.int16))
         # the latents of a sharded loop differ from the single-process ones at rounding level; the VAE stage adds nothing to that
         assert d.max() <= 3 and (d > 0).mean() < 0.05, f"max {d.max()}, {100 * (d > 0).mean():.2f} % of bytes differ"
