@@ -471,6 +471,10 @@ int icv_ipc_drain(icv_ipc* ipc, int timeout_ms);
  * costs the overlapped attention CUs like an RCCL channel does), 0 = inconclusive (the control kernel got a slot).  *copy_ms
  * (may be NULL): the copy's duration from events.  A diagnostic: ~20 ms, synchronises the device, not for the per-layer path. */
 int icv_ipc_probe_copy(icv_ipc* ipc, int peer, int64_t bytes, int* kind, double* copy_ms);
+/* The same probe for any copy hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault) can make (device, peer-device, pinned host pointers;
+ * dst == NULL = a scratch device buffer): the instrument's own controls - a same-device copy must answer 2, a pinned-host-to-device
+ * copy 1 (tests/test_kernels_gpu.py). */
+int icv_probe_copy_path(const void* src, void* dst, int64_t bytes, int* kind, double* copy_ms);
 /* a rank that cannot go on releases every peer wait that depends on it (its flag words jump past every sequence number: the
  * peers pull undefined bytes instead of spinning forever) and refuses further exchanges; the error itself travels by the host's
  * own channel.  Turns "one rank failed" from a hang on the others into an error on all. */

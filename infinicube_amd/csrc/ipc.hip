@@ -414,19 +414,20 @@ __global__ __launch_bounds__(1024) void occupy_kernel(unsigned long long ticks, 
 __global__ void touch_kernel(int* flag) { *flag = 1; }
 }  // namespace
 
-extern "C" int icv_ipc_probe_copy(icv_ipc* c, int peer, int64_t bytes, int* kind, double* copy_ms) {
-  ICV_REQUIRE(c && kind, "icv_ipc_probe_copy: null argument");
-  ICV_REQUIRE(peer >= 0 && peer < c->world && c->peer[peer], "icv_ipc_probe_copy: peer %d is not open", peer);
-  ICV_REQUIRE(bytes > 0 && bytes <= c->heap_bytes, "icv_ipc_probe_copy: %lld bytes do not fit the %lld-byte heap", (long long)bytes, (long long)c->heap_bytes);
+// the probe for any (src, dst): device, peer-device or pinned host pointers; dst == NULL = a scratch device buffer
+extern "C" int icv_probe_copy_path(const void* src, void* dst_arg, int64_t bytes, int* kind, double* copy_ms) {
+  ICV_REQUIRE(src && kind && bytes > 0, "icv_probe_copy_path: bad argument");
   *kind = 0;
   if (copy_ms) *copy_ms = -1.0;
+  int device = 0;
+  ICV_HIP_OK(hipGetDevice(&device), "hipGetDevice");
   hipDeviceProp_t prop;
-  ICV_HIP_OK(hipGetDeviceProperties(&prop, c->device), "hipGetDeviceProperties");
+  ICV_HIP_OK(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
   int per_cu = 0;
   ICV_HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, occupy_kernel, 1024, 0), "hipOccupancyMaxActiveBlocksPerMultiprocessor");
-  ICV_REQUIRE(per_cu > 0, "icv_ipc_probe_copy: the occupier does not fit a CU");
+  ICV_REQUIRE(per_cu > 0, "icv_probe_copy_path: the occupier does not fit a CU");
   const int nwg = per_cu * prop.multiProcessorCount;
-  void* dst = nullptr;
+  void* dst = dst_arg;
   int* words = nullptr;                 // [0] census, [1] control flag
   hipStream_t s_occ = nullptr, s_ctl = nullptr, s_cpy = nullptr;
   hipEvent_t e_occ = nullptr, e_ctl = nullptr, e_c0 = nullptr, e_c1 = nullptr;
@@ -435,11 +436,11 @@ extern "C" int icv_ipc_probe_copy(icv_ipc* c, int peer, int64_t bytes, int* kind
   do {                                                                                        \
     const hipError_t e_ = (call);                                                             \
     if (e_ != hipSuccess && rc == 0) {                                                        \
-      icv_set_error("icv_ipc_probe_copy: %s: %s (%s)", what, hipGetErrorName(e_), hipGetErrorString(e_)); \
+      icv_set_error("icv_probe_copy_path: %s: %s (%s)", what, hipGetErrorName(e_), hipGetErrorString(e_)); \
       rc = 2;                                                                                 \
     }                                                                                         \
   } while (0)
-  PROBE_TRY(hipMalloc(&dst, (size_t)bytes), "hipMalloc(scratch)");
+  if (!dst) PROBE_TRY(hipMalloc(&dst, (size_t)bytes), "hipMalloc(scratch)");
   PROBE_TRY(hipMalloc((void**)&words, 2 * sizeof(int)), "hipMalloc(words)");
   if (rc == 0) PROBE_TRY(hipMemset(words, 0, 2 * sizeof(int)), "hipMemset");
   PROBE_TRY(hipStreamCreateWithFlags(&s_occ, hipStreamNonBlocking), "hipStreamCreate");
@@ -452,7 +453,7 @@ extern "C" int icv_ipc_probe_copy(icv_ipc* c, int peer, int64_t bytes, int* kind
   if (rc == 0) {
     PROBE_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
     // warm both paths once (first-use set-up of a peer mapping / a blit kernel must not be mistaken for "waiting for a wave")
-    PROBE_TRY(hipMemcpyAsync(dst, c->peer[peer], (size_t)bytes, hipMemcpyDeviceToDevice, s_cpy), "hipMemcpyAsync(warm-up)");
+    PROBE_TRY(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDefault, s_cpy), "hipMemcpyAsync(warm-up)");
     hipLaunchKernelGGL(touch_kernel, dim3(1), dim3(1), 0, s_ctl, words + 1);
     PROBE_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
     PROBE_TRY(hipMemset(words, 0, 2 * sizeof(int)), "hipMemset");
@@ -465,7 +466,7 @@ extern "C" int icv_ipc_probe_copy(icv_ipc* c, int peer, int64_t bytes, int* kind
     hipLaunchKernelGGL(touch_kernel, dim3(1), dim3(1), 0, s_ctl, words + 1);
     PROBE_TRY(hipEventRecord(e_ctl, s_ctl), "hipEventRecord");
     PROBE_TRY(hipEventRecord(e_c0, s_cpy), "hipEventRecord");
-    PROBE_TRY(hipMemcpyAsync(dst, c->peer[peer], (size_t)bytes, hipMemcpyDeviceToDevice, s_cpy), "hipMemcpyAsync(probe)");
+    PROBE_TRY(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDefault, s_cpy), "hipMemcpyAsync(probe)");
     PROBE_TRY(hipEventRecord(e_c1, s_cpy), "hipEventRecord");
     bool copy_done = false, ctl_done = false, occ_done = false;
     for (int i = 0; i < 60 && rc == 0; ++i) {       // <= 6 ms, inside the occupier's 8 ms
@@ -494,9 +495,16 @@ extern "C" int icv_ipc_probe_copy(icv_ipc* c, int peer, int64_t bytes, int* kind
   if (s_occ) (void)hipStreamDestroy(s_occ);
   if (s_ctl) (void)hipStreamDestroy(s_ctl);
   if (s_cpy) (void)hipStreamDestroy(s_cpy);
-  if (dst) (void)hipFree(dst);
+  if (dst && !dst_arg) (void)hipFree(dst);
   if (words) (void)hipFree(words);
   return rc;
+}
+
+extern "C" int icv_ipc_probe_copy(icv_ipc* c, int peer, int64_t bytes, int* kind, double* copy_ms) {
+  ICV_REQUIRE(c && kind, "icv_ipc_probe_copy: null argument");
+  ICV_REQUIRE(peer >= 0 && peer < c->world && c->peer[peer], "icv_ipc_probe_copy: peer %d is not open", peer);
+  ICV_REQUIRE(bytes > 0 && bytes <= c->heap_bytes, "icv_ipc_probe_copy: %lld bytes do not fit the %lld-byte heap", (long long)bytes, (long long)c->heap_bytes);
+  return icv_probe_copy_path(c->peer[peer], nullptr, bytes, kind, copy_ms);
 }
 
 // Teardown must not depend on the peers being alive: give this rank's queues `timeout_ms` to finish on their own, then satisfy EVERY wait

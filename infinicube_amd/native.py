@@ -100,6 +100,7 @@ SIGNATURES.update({
     "icv_ipc_check": (c_int, [c_void_p]),
     "icv_ipc_drain": (c_int, [c_void_p, c_int]),
     "icv_ipc_probe_copy": (c_int, [c_void_p, c_int, _I, ctypes.POINTER(c_int), ctypes.POINTER(c_double)]),
+    "icv_probe_copy_path": (c_int, [_P, _P, _I, ctypes.POINTER(c_int), ctypes.POINTER(c_double)]),
     "icv_attention_fwd_pieces": (c_int, [_P, _I, _P, _I, _I, _I, _P, _I, _I, _I, c_float, _P, _P, _I, _P, _P]),
     "icv_flag_write": (c_int, [_P, _I, ctypes.c_uint32, _I, _P]),
     "icv_dit_profile": (c_int, [c_void_p, c_int]),

@@ -1214,3 +1214,29 @@ def test_randomised_token_local_kernels(hip_ops):
         hip_ops.attention_add(q.to(DEV), k.to(DEV), v.to(DEV), o, H, 1.0 / math.sqrt(128))
         assert_bf16_close(o, prev.float() + R.attention(q.float(), k.float(), v.float(), H), f"attention_add Sq={Sq} Skv={Skv} H={H}",
                           abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
+
+
+def test_copy_path_probe_controls(hip_ops):
+    """icv_probe_copy_path - the first-contact instrument that says whether a copy needs compute units (an occupier kernel holds every wave
+    slot of the device; a copy that completes meanwhile was moved by a copy engine) - against its two controls in ONE process:
+    a same-device device-to-device copy is a blit KERNEL on this runtime (profiles/r05/stream_ops_probe.txt: __amd_rocclr_copyBuffer) and
+    must answer 2; a pinned-host-to-device copy is executed by an SDMA engine and must answer 1.  (Between ranks that SHARE a GPU the
+    hardware scheduler time-slices the processes' queues and the probe may answer 0 = inconclusive: it is built for one rank per device.)"""
+    import ctypes
+    from infinicube_amd import native
+    n = 8 << 20
+    src_dev = torch.randint(0, 255, (n,), dtype=torch.uint8, device=DEV)
+    src_pin = torch.randint(0, 255, (n,), dtype=torch.uint8).pin_memory()
+    dst = torch.zeros((n,), dtype=torch.uint8, device=DEV)
+    got = {}
+    for name, src in (("device->device", src_dev), ("pinned host->device", src_pin)):
+        kinds = []
+        for _ in range(3):
+            kind, ms = ctypes.c_int(-1), ctypes.c_double(0.0)
+            native.check(hip_ops.lib.icv_probe_copy_path(src.data_ptr(), dst.data_ptr(), n, ctypes.byref(kind), ctypes.byref(ms)), "icv_probe_copy_path")
+            kinds.append(kind.value)
+            assert torch.equal(dst.cpu(), src.cpu())
+        got[name] = kinds
+    print(f"copy-path probe: {got} (1 = copy engine, 2 = blit kernel, 0 = inconclusive)")
+    assert all(k == 2 for k in got["device->device"]), got
+    assert all(k == 1 for k in got["pinned host->device"]), got

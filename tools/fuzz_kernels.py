@@ -307,12 +307,80 @@ def fuzz_attention_fp8_pieces():
         fails.append(f"{what}: rms err {err:.3g} vs rms {rms:.3g}")
 
 
-t0, n = time.time(), {"gemm": 0, "attention": 0, "gemm_fp8": 0, "attention_fp8": 0, "conv": 0, "fp8_pieces": 0}
+def fuzz_attention_pieces():
+    """round 6's arrival-driven launch (icv_attention_fwd_pieces): random piece lists (ragged, one-row, empty, out of memory order) over K|V
+    rows held as ONE [S, 2d] matrix; some pieces gated on flags that a side stream raises AFTER the launch (rows copied in late).  Tile-aligned
+    pieces in memory order must equal the plain launch bit for bit; everything else must meet the attention bar against exact attention
+    and be deterministic; nobody may time out."""
+    H = rng.choice([1, 2, 3, 5])
+    Sq = rng.choice([1, 33, 256, 257, 300, 513]) if rng.random() < 0.7 else rng.randint(1, 1200)
+    P = rng.randint(1, 9)
+    aligned = rng.random() < 0.4
+    rows = [64 * rng.randint(1, 9) if aligned else rng.choice([0, 1, 63, 64, 65, 130, 300, 777]) if rng.random() < 0.6 else rng.randint(1, 900) for _ in range(P)]
+    if sum(rows) == 0:
+        rows[0] = 65
+    d, Skv = H * 128, sum(rows)
+    unit = rng.random() < 0.5
+    g = torch.Generator(device=DEV).manual_seed(rng.randint(0, 2 ** 31))
+    q = (torch.randn((Sq, d), device=DEV, generator=g) * rng.choice([1.0, 1.0, 3.0])).to(torch.bfloat16)
+    kv = torch.randn((Skv, 2 * d), device=DEV, generator=g).to(torch.bfloat16)
+    scale = 128 ** -0.5
+    if unit:
+        kv[:, :d] = (kv[:, :d].float() * (scale * math.log2(math.e))).to(torch.bfloat16)
+    call_scale = math.log(2.0) if unit else scale
+    b = [0]
+    for r in rows:
+        b.append(b[-1] + r)
+    order = list(range(P))
+    if not aligned:
+        rng.shuffle(order)
+    ref = ref_attention(q, kv[:, :d], kv[:, d:], H, call_scale)
+    late = [i for i in order[1:] if rows[i] and rng.random() < 0.4]
+    staged = kv.clone() if late else None
+    flags = torch.zeros((P,), dtype=torch.int32, device=DEV)
+    err = torch.zeros((1,), dtype=torch.int32, device=DEV)
+    what = f"attention_pieces Sq={Sq} rows={rows} order={order} late={late} H={H} unit={unit}"
+    outs = []
+    for rep in range(2):
+        if late:
+            for i in late:
+                kv[b[i]:b[i + 1]] = float("nan")
+            flags.zero_()
+            torch.cuda.synchronize()
+        pieces = [(kv[b[i]:b[i + 1], :d], kv[b[i]:b[i + 1], d:], (i if i in late else -1), 1) for i in order]
+        o = torch.zeros((Sq, d), dtype=torch.bfloat16, device=DEV)
+        ops.attention_pieces(q, pieces, o, H, call_scale, flags=flags, err=err, timeout_us=5_000_000)
+        if late:
+            with torch.cuda.stream(SIDE):
+                for i in late:
+                    kv[b[i]:b[i + 1]].copy_(staged[b[i]:b[i + 1]])
+                    ops.flag_write(flags, i, 1, delay_us=rng.choice([0, 0, 200]))
+            torch.cuda.synchronize()
+        outs.append(o)
+    if int(err.item()) != 0:
+        fails.append(what + f": a wait gave up ({int(err.item()) & 0xffffffff:#x})")
+        return
+    ok = close_bf16(outs[0], ref, what, abs_floor=2.0 ** -5, rms_bound=2.0 ** -7)
+    if ok and not torch.equal(outs[0], outs[1]):
+        fails.append(what + ": two identical launches differ (race?)")
+    if ok and aligned:
+        ops.lib.icv_set_option(b"attn_kernel", 7); ops.lib.icv_set_option(b"attn7_variant", -1)
+        o2 = torch.zeros((Sq, d), dtype=torch.bfloat16, device=DEV)
+        ops.attention(q, kv[:, :d], kv[:, d:], o2, H, call_scale)
+        if not torch.equal(outs[0], o2):
+            fails.append(what + ": tile-aligned pieces in memory order differ from the plain launch")
+
+
+SIDE = torch.cuda.Stream(device=DEV)
+t0, n = time.time(), {"gemm": 0, "attention": 0, "gemm_fp8": 0, "attention_fp8": 0, "conv": 0, "fp8_pieces": 0, "pieces": 0}
+R6_TOO = os.environ.get("FUZZ_R6", "0") == "1"       # FUZZ_R6=1 adds round 6's entry point: the arrival-driven attention over pieces
 R5_TOO = os.environ.get("FUZZ_R5", "0") == "1"       # FUZZ_R5=1 adds round 5's entry points: the convolution and the e4m3 pieces
 FP8_TOO = os.environ.get("FUZZ_FP8", "0") == "1"     # FUZZ_FP8=1 adds the e4m3 entry points (a different case sequence)
 try:
     while (sum(n.values()) < max_cases) if max_cases > 0 else (time.time() - t0 < budget):
-        if R5_TOO and rng.random() < 0.5:
+        if R6_TOO and rng.random() < 0.5:
+            fuzz_attention_pieces(); n["pieces"] += 1
+        elif R5_TOO and rng.random() < 0.5:
             if rng.random() < 0.6:
                 fuzz_conv(); n["conv"] += 1
             else:
@@ -336,5 +404,6 @@ for f in fails[:40]:
 print(f"fuzz seed {seed}: {n['gemm']} GEMM cases, {n['attention']} attention cases" +
       (f", {n['gemm_fp8']} e4m3 GEMM cases, {n['attention_fp8']} e4m3 attention cases" if FP8_TOO else "") +
       (f", {n['conv']} convolution cases, {n['fp8_pieces']} e4m3-pieces cases" if R5_TOO else "") +
+      (f", {n['pieces']} arrival-driven attention (pieces) cases" if os.environ.get("FUZZ_R6", "0") == "1" else "") +
       f" in {time.time() - t0:.0f} s, {len(fails)} failures")
 sys.exit(1 if fails else 0)

@@ -65,6 +65,17 @@ for world in (4, 8):
                     chunk_call(q, kh[b[c]:b[c + 1]], vh[b[c]:b[c + 1]], o, acc, ml, H, c == 0, c == C - 1, main.cuda_stream)
             rows.append((f"{C} ramped chunks, K|V halves of one [S, 2d] matrix", timeit(seq_kv)))
             del kv, kh, vh
+            # round 6: ONE arrival-gated launch over the pieces of the same exchange (csrc/attn7p.hip): own rows as one piece, then
+            # (chunk, peer) pieces cut on the 64-key tile grid - every flag already satisfied: the kernel-only view of the schedule
+            ba = chunk_bounds(n, C, 64)
+            kv2 = torch.cat([k, v], dim=1).contiguous()
+            own = kv2[:n]
+            peers_kv = kv2[n:].view(world - 1, n, 2 * d)
+            pieces = [(own[:, :d], own[:, d:], -1, 0)] + [(peers_kv[j, ba[c]:ba[c + 1], :d], peers_kv[j, ba[c]:ba[c + 1], d:], -1, 0)
+                                                          for c in range(C) for j in range(world - 1)]
+            rows.append((f"ONE arrival-gated launch, {len(pieces)} pieces (own + {C} chunks x {world - 1} peers)", timeit(lambda: ops.attention_pieces(q, pieces, o, H, SCALE))))
+            rows.append(("ONE arrival-gated launch, 1 piece (all keys)", timeit(lambda: ops.attention_pieces(q, [(kv2[:, :d], kv2[:, d:], -1, 0)], o, H, SCALE))))
+            del kv2, own, peers_kv, pieces
         lib.icv_set_option(b"attn7_short", 1 << 30)
         rows.append((f"{C} ramped chunks, 4-wave blocks two per CU", timeit(seq)))
         lib.icv_set_option(b"attn7_short", -1)
