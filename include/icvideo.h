@@ -457,7 +457,7 @@ int icv_ipc_arrival(icv_ipc* ipc, const uint32_t** flags);
 int icv_ipc_gather_consumed(icv_ipc* ipc, int64_t ticket);
 int icv_ipc_configure(icv_ipc* ipc, int copy_own_rows);
 /* Liveness (round 6).  Every device-side wait of the transport is a one-wave kernel with a deadline (ICV_IPC_WAIT_TIMEOUT_MS, default
- * 30000, 0 = none): a wait that expires records whom it was waiting for and lets its queue go on with stale rows.
+ * 60000, 0 = none): a wait that expires records whom it was waiting for and lets its queue go on with stale rows.
  * icv_ipc_check: 0 = no wait of this rank has expired; otherwise non-zero and icv_last_error names the peer - the run is invalid from
  * that exchange on (call it once per denoising step; it reads one host word).
  * icv_ipc_drain(ipc, timeout_ms): give this rank's queues that long to finish on their own, then satisfy every wait word of the segment

@@ -145,7 +145,7 @@ extern "C" int icv_ipc_create(const char* shm_name, int rank, int world, void* h
   {   // deadlines (milliseconds): ICV_IPC_WAIT_TIMEOUT_MS bounds every device-side wait (0 = wait for ever), ICV_IPC_DRAIN_TIMEOUT_MS the teardown
     const char* w = getenv("ICV_IPC_WAIT_TIMEOUT_MS");
     const char* d = getenv("ICV_IPC_DRAIN_TIMEOUT_MS");
-    const long long wait_ms = w ? atoll(w) : 30000;
+    const long long wait_ms = w ? atoll(w) : 60000;
     c->timeout_ticks = wait_ms > 0 ? (unsigned long long)wait_ms * 100000ull : 0ull;
     if (d) c->drain_ms = atoi(d) > 0 ? atoi(d) : 0;
   }

@@ -387,7 +387,7 @@ class WanDiT:
             if self._is_gpu():
                 self.sp_err = ops.alloc((1,), torch.int32)
                 self.sp_err.zero_()
-            self.sp_timeout_us = int(float(os.environ.get("ICV_ATTN_ARRIVAL_TIMEOUT_MS", "30000")) * 1000)
+            self.sp_timeout_us = int(float(os.environ.get("ICV_ATTN_ARRIVAL_TIMEOUT_MS", "60000")) * 1000)
 
     def check_exchange(self):
         """Raise if the K|V exchange lost a peer: a device-side wait of the copy-engine transport or of the arrival-driven attention

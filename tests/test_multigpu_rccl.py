@@ -184,6 +184,73 @@ def test_shared_gpu_arrival_driven_attention(tmp_path, gpu_single, world, kv_exc
     _close(got, ref, f"arrival-driven vs chunked launches, x{world} {kv_exchange}", rel_bound=1e-2, psnr_bound=50.0)
 
 
+DEAD_PEER_WORKER = r"""
+import os, sys, time, torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.cuda.set_device(0)
+from infinicube_amd.videogen.ops import HipOps
+from infinicube_amd.videogen.seqpar import KVGather, ShardPlan
+ops = HipOps("cuda:0")
+kg = KVGather(ShardPlan.make(world * 256, world, rank), None, "ipc")
+kg.reserve(1 << 20, "cuda:0")                       # set-up + self-test: everybody alive
+rows = kg.local_rows(256, 512, torch.bfloat16, ops.alloc)
+rows.fill_(float(rank + 1))
+out = torch.zeros((world * 256, 512), dtype=torch.bfloat16, device="cuda:0")
+torch.cuda.synchronize(); dist.barrier()
+if rank == world - 1:
+    os._exit(0)                                     # the peer DIES here: it never publishes its rows, never pulls anybody's
+t0 = time.time()
+kg.acquire()
+h = kg.start(rows, out)
+kg.wait(h)
+torch.cuda.synchronize()                            # must RETURN: the pull's wait gives up after ICV_IPC_WAIT_TIMEOUT_MS
+t_sync = time.time() - t0
+try:
+    kg.check()
+    print("NO ERROR"); rc = 1
+except RuntimeError as e:
+    print(f"rank {rank}: sync returned after {t_sync:.2f} s; check(): {e}", flush=True)
+    rc = 0 if (f"rank {world - 1}" in str(e) and "gave up waiting" in str(e) and t_sync < 10.0) else 2
+t1 = time.time()
+kg.acquire()                                        # the NEXT layer's acquire would wait for the dead peer's pull of our rows: bounded as well
+torch.cuda.synchronize()
+kg.close()                                          # teardown must not hang either
+print(f"rank {rank}: second bounded wait + close took {time.time() - t1:.2f} s", flush=True)
+if time.time() - t1 > 20.0:
+    rc = 3
+os._exit(rc)                                        # no collective teardown with a dead peer
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_copy_engine_transport_dead_peer_is_a_bounded_wait_and_a_named_error(world):
+    """a peer that crashes mid-run used to leave the survivors' pull streams spinning for ever (the runtime's
+    hipStreamWaitValue32 is an unbounded spin kernel) and their teardown blocked.  Now every device-side wait has a deadline: the
+    survivors' device synchronise returns, icv_ipc_check names the dead rank, the next acquire is bounded too and close() returns."""
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ICV_IPC_WAIT_TIMEOUT_MS="800",
+                   ICV_IPC_DRAIN_TIMEOUT_MS="1000", PYTHONPATH=os.pathsep.join([ROOT, HERE, os.environ.get("PYTHONPATH", "")]),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="16")
+        procs.append(subprocess.Popen([sys.executable, "-c", DEAD_PEER_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL))
+    outs = []
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=240)
+            outs.append(o.decode(errors="replace"))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} (rc {p.returncode}):\n{outs[r][-3000:]}"
+    print("\n".join(line for o in outs for line in o.splitlines() if line.startswith("rank ")))
+
+
 LATE_PEER_WORKER = r"""
 import math, os, sys, time, torch, torch.distributed as dist
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])

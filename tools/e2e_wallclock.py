@@ -33,7 +33,8 @@ class HashTokenizer:
 def synthetic_factory(torch_dtype, device, model_configs):
     """The random-init pipeline of this tool as a module-level factory: what every rank of a worker pool builds
     (ICV_WORLD=N ICV_WORKER_FACTORY=e2e_wallclock:synthetic_factory PYTHONPATH=tools; MODEL=14b|1.3b picks the DiT)."""
-    dev = WanVideoPipeline.resolve_device(device)
+    # ICV_TEST_SHARE_GPU=1: the 1-GPU rehearsal (every rank on cuda:0 over gloo) of tools/first_contact_multigpu.sh
+    dev = "cuda:0" if os.environ.get("ICV_TEST_SHARE_GPU") == "1" else WanVideoPipeline.resolve_device(device)
     cfg = preset(os.environ.get("MODEL", "14b"))
     sd = syn.make_dit_state_dict(cfg, seed=0, device=dev, dtype=torch.bfloat16)
     with torch.device(dev):
