@@ -31,7 +31,7 @@ extern "C" {
 /* 3: icv_ipc_* (the copy-engine K|V transport), icv_conv3d_ndhwc and the padded-volume VAE helpers were added; no existing
  *    signature changed.
  * 4: icv_attention_fwd_pieces (ONE arrival-gated attention launch per layer over K|V pieces), icv_ipc_arrival / _gather_consumed / _configure / _check /
- *    _drain / _probe_copy (arrival flags, bounded device-side waits, teardown that does not depend on live peers, copy-engine-or-blit
+ *    _drain / _probe_copy, icv_probe_copy_path (arrival flags, bounded device-side waits, teardown that does not depend on live peers, copy-engine-or-blit
  *    probe), icv_flag_write; no existing
  *    signature changed. */
 #define ICV_ABI_VERSION 4
