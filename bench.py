@@ -715,7 +715,8 @@ def run_rank(args, world, rank, phase, stdout_fd):
                 "frac_of_bf16_mfma_peak": f_step * args.steps / elapsed / 1e12 / (PEAK_BF16_TFLOPS * world),
             },
             "roofline": {
-                "kernel": "att7::attn7_kernel (self-attention, K6)" if args.attn_dtype == "bf16" else
+                "kernel": ("att7p::attn7p_kernel (self-attention, K6: ONE arrival-gated launch per layer over the K|V pieces; the time includes "
+                           "whatever the launch waited for rows inside)" if piece_events else "att7::attn7_kernel (self-attention, K6)") if args.attn_dtype == "bf16" else
                           "att8::attn8_kernel + its quantise pre-pass (e4m3 self-attention, K6)",
                 "bound": "mfma", "achieved": attn_tflops, "peak": attn_peak, "unit": "TFLOP/s",
                 "frac": attn_tflops / attn_peak, "traffic": traffic, "traffic_source": traffic_source,

@@ -39,7 +39,9 @@ def synthetic_factory(torch_dtype, device, model_configs):
     sd = syn.make_dit_state_dict(cfg, seed=0, device=dev, dtype=torch.bfloat16)
     with torch.device(dev):
         t5 = UMT5Encoder().to(torch.bfloat16).eval()
-    return WanVideoPipeline(dev, torch_dtype, DiTHolder(sd, cfg), UMT5TextEncoder(t5, HashTokenizer(), dev), WanVAE(WanVAENet(), dev, torch.bfloat16))
+    from infinicube_amd.videogen.ops import HipOps
+    return WanVideoPipeline(dev, torch_dtype, DiTHolder(sd, cfg), UMT5TextEncoder(t5, HashTokenizer(), dev), WanVAE(WanVAENet(), dev, torch.bfloat16),
+                            ops=HipOps(dev))      # explicit: the pipeline would map the literal "cuda:0" to cuda:LOCAL_RANK (wrong when ranks share a GPU)
 
 
 def run_e2e_pool(model="14b", steps=50, gemm="bf16", log=print):
