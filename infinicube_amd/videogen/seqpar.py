@@ -435,6 +435,7 @@ class _IpcHeap:
         self._shm_name = name
         err, blob = "", b""
         try:
+            self._require_hw_queues(world)
             # torch owns the memory (borrowed by the library); a dedicated allocation, so the exported range is this heap
             self.mem = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
             h = ctypes.c_void_p()
@@ -458,6 +459,25 @@ class _IpcHeap:
         self._unlink()                                      # everyone has it mapped: leave nothing behind in /dev/shm
         self._live.append(self)
         self._raise_if_any(self._agree((self._self_test(), b"")), "self-test")
+
+    @staticmethod
+    def _require_hw_queues(world: int) -> None:
+        """One pull stream per peer + the launch stream + torch's / RCCL's own, and a pull that waits for its peer's flag is a spinning
+        kernel that blocks its HARDWARE queue (profiles/r05/kv_contention.md): with the runtime's default of 4 queues the launch stream
+        can sit behind a pending pull.  GPU_MAX_HW_QUEUES is read when HIP initialises, so it cannot be fixed from here: a process that
+        was started without it does not get this transport - a local error like any other set-up failure, so the autotune /
+        the launch ladder drop the candidate on every rank.  multigpu.WorkerPool and bench.py start their ranks with 16;
+        ICV_IPC_ALLOW_FEW_QUEUES=1 overrides."""
+        if world <= 1 or os.environ.get("ICV_IPC_ALLOW_FEW_QUEUES") == "1":
+            return
+        need, v = min(16, world + 2), os.environ.get("GPU_MAX_HW_QUEUES")
+        try:
+            have = int(v) if v is not None else 4          # the runtime's default
+        except ValueError:
+            have = 0
+        if have < need:
+            raise RuntimeError(f"GPU_MAX_HW_QUEUES={v if v is not None else 'unset (runtime default: 4)'}: the copy-engine transport wants >= {need} hardware "
+                               f"queues for {world} ranks, and the variable is read when HIP initialises - export it before the process starts")
 
     def _agree(self, item):
         if self.world == 1:

@@ -50,6 +50,7 @@ def run_ranks(n, out, args, timeout=420, extra_env=None):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    PYTHONPATH=os.pathsep.join([ROOT, HERE, os.environ.get("PYTHONPATH", "")]), OMP_NUM_THREADS="2")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("GPU_MAX_HW_QUEUES", "16")      # what every real launcher of ranks sets (the copy-engine transport refuses a process without it)
         env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, WORKER, "--out", out] + [str(x) for x in args], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL))
@@ -371,6 +372,7 @@ def test_copy_engine_transport_one_rank_failing_is_an_error_on_every_rank_not_a_
                    PYTHONPATH=os.pathsep.join([ROOT, HERE, os.environ.get("PYTHONPATH", "")]), OMP_NUM_THREADS="2",
                    ICV_TEST_HOOKS="1", ICV_IPC_INJECT=f"selftest:{bad}")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("GPU_MAX_HW_QUEUES", "16")
         procs.append(subprocess.Popen([sys.executable, "-c", IPC_ABORT_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                       stdin=subprocess.DEVNULL))
     t0, outs = time.time(), []
