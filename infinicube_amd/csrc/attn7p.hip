@@ -16,7 +16,8 @@
 //     tiles instead of its own (dead) past-the-end tiles.  The verdict is taken by ONE lane and read by all waves after a barrier:
 //     every wave issues its share of a tile's DMA, so a per-wave opinion about "ready" would tear a tile;
 //   * a piece that has NOT arrived when its predecessor ends costs a bubble: wave 0 spins on the flag (s_sleep between polls, bounded
-//     by a time-out that sets an error word and lets the kernel finish with garbage rather than hang the queue), then the ring is refilled;
+//     by a time-out that sets an error word and lets the kernel finish with garbage rather than hang the queue; once the word is set no
+//     waiter of this or a later launch waits out the deadline again), then the ring is refilled;
 //   * no cache maintenance is needed for the late rows: the rows of a piece are first read after its flag was seen, the launch's own
 //     acquire invalidated whatever an earlier launch left in L2 / L1, and pieces are whole rows (no cache line straddles two pieces),
 //     so no stale line of a piece can exist; the flag itself is polled with system-scope (uncached) loads.
@@ -187,6 +188,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
         const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();                                          \
         while ((int)(__hip_atomic_load(pp.flags + fi_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - want_) < 0) { \
           __builtin_amdgcn_s_sleep(16);                                                                           \
+          /* fail fast: once ANY work-group of any launch has given up, nobody waits out the deadline again */    \
+          if (pp.err && __hip_atomic_load(pp.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;       \
           if (pp.timeout_ticks && __builtin_amdgcn_s_memrealtime() - t0_ > pp.timeout_ticks) {                    \
             if (pp.err) atomicCAS(pp.err, 0u, 0x80000000u | (unsigned)(J_));                                      \
             break;                                                                                                \

@@ -78,6 +78,9 @@ __global__ void wait_ready_kernel(const uint32_t* flag, uint32_t value, unsigned
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0) {
     __builtin_amdgcn_s_sleep(8);
+    // fail fast: after the FIRST wait of this rank that gave up, later waits do not sit out the deadline again (a dead peer would
+    // otherwise cost deadline x chunks x layers before the host's next icv_ipc_check)
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
     if (timeout_ticks && __builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
       atomicCAS_system(err, 0u, code);
       return;
@@ -94,6 +97,7 @@ __global__ void wait_done_kernel(const uint32_t* done_col, int world, int rank, 
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   while ((int32_t)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0) {
     __builtin_amdgcn_s_sleep(8);
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;       // fail fast (see wait_ready_kernel)
     if (timeout_ticks && __builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
       atomicCAS_system(err, 0u, kErrDone | ((uint32_t)p << 20) | (value & 0xfffffu));
       return;

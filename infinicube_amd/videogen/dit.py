@@ -389,6 +389,13 @@ class WanDiT:
                 self.sp_err.zero_()
             self.sp_timeout_us = int(float(os.environ.get("ICV_ATTN_ARRIVAL_TIMEOUT_MS", "60000")) * 1000)
 
+    def _check_transport(self):
+        """Per step, free (one host word): did a device-side wait of the K|V transport give up?  Then the rest of the loop would run on
+        stale rows - stop now (the in-kernel waits fail fast after the first one, so a dead peer costs one deadline, not one per layer)."""
+        kg = getattr(self, "kv_gather", None)
+        if kg is not None and hasattr(kg, "check"):
+            kg.check()
+
     def check_exchange(self):
         """Raise if the K|V exchange lost a peer: a device-side wait of the copy-engine transport or of the arrival-driven attention
         gave up (both are bounded; what they computed since is garbage).  One host word + one 4-byte read-back: call per step at most."""
@@ -990,6 +997,8 @@ class WanDiT:
                 branch_exchange(self.head_own, self.head_out)           # slot 0 = cond, slot 1 = uncond
                 ops.unpatchify_cfg_euler(latent, self.head_out[0], self.head_out[1], cfg_scale,
                                          scheduler.dsigma(i), plan.tok0, plan.n_tok, round_bf16=round_bf16)
+                if self.sp_on:
+                    self._check_transport()
                 if on_step is not None:
                     on_step(i, latent)
             if self.sp_on:
@@ -1018,6 +1027,8 @@ class WanDiT:
                     self.forward_tokens(latent, ctx_uncond, ts, buf_tokens, self.head_out[1], stem="load" if share else None)
             ops.unpatchify_cfg_euler(latent, self.head_out[0], self.head_out[1] if use_cfg else None,
                                      cfg_scale, scheduler.dsigma(i), plan.tok0, plan.n_tok, round_bf16=round_bf16)
+            if self.sp_on:
+                self._check_transport()
             if on_step is not None:
                 on_step(i, latent)
         if self.sp_on:
