@@ -396,18 +396,31 @@ class WanDiT:
         if kg is not None and hasattr(kg, "check"):
             kg.check()
 
-    def check_exchange(self):
-        """Raise if the K|V exchange lost a peer: a device-side wait of the copy-engine transport or of the arrival-driven attention
-        gave up (both are bounded; what they computed since is garbage).  One host word + one 4-byte read-back: call per step at most."""
+    def exchange_gave_up(self) -> Optional[str]:
+        """None, or why the K|V exchange of this engine is no longer valid: a device-side wait of the copy-engine transport or of the
+        arrival-driven attention ran into its deadline (both are bounded; what was computed since is garbage).  One host word + one
+        4-byte read-back; never raises (seqpar.autotune_kv_exchange asks it after a candidate's warm-up: a transport whose data
+        movement cannot make progress beside the WAITING attention work-groups - a starved RCCL channel kernel - shows up here, and
+        the candidate is dropped on every rank)."""
         kg = getattr(self, "kv_gather", None)
         if kg is not None and hasattr(kg, "check"):
-            kg.check()
+            try:
+                kg.check()
+            except RuntimeError as e:
+                return str(e)
         err = getattr(self, "sp_err", None)
         if err is not None:
             e = int(err.item()) & 0xffffffff
             if e:
-                raise RuntimeError(f"sequence-parallel attention gave up waiting for K|V piece {e & 0xffff} of a layer after "
-                                   f"{self.sp_timeout_us / 1e6:.0f} s (a peer is dead or stalled); the result is invalid")
+                return (f"sequence-parallel attention gave up waiting for K|V piece {e & 0xffff} of a layer after "
+                        f"{self.sp_timeout_us / 1e6:.0f} s (the transfer made no progress beside the waiting attention, or a peer is dead / stalled)")
+        return None
+
+    def check_exchange(self):
+        """Raise if the K|V exchange is no longer valid (exchange_gave_up); call per step at most."""
+        why = self.exchange_gave_up()
+        if why:
+            raise RuntimeError(why + "; the result is invalid")
 
     def _sp_acquire(self):
         """Before the K|V GEMM overwrites the local rows: wait for the peers' pulls of the previous layer (mode "ipc" only)."""

@@ -687,6 +687,9 @@ def gather_latent(latent: torch.Tensor, plan: ShardPlan, grid, group=None) -> to
     return full.reshape(T, Hp, Wp, C, 2, 2).permute(3, 0, 1, 4, 2, 5).reshape(C, T, H8, W8).contiguous()
 
 
+AUTOTUNE_WAIT_DEADLINE_US = 5_000_000      # in-kernel deadline of the arrival-driven attention while a candidate is being tried
+
+
 def autotune_kv_exchange(model, run_layers, sync, candidates=None, reps: int = 2, reduce_max=None, log=None, exchange_only=None, probe=None,
                          on_candidate=None):
     """Start-up choice of the K|V exchange (transport x chunk count) by MEASUREMENT on the ranks that will run it.
@@ -705,6 +708,8 @@ def autotune_kv_exchange(model, run_layers, sync, candidates=None, reps: int = 2
     candidate that every rank set up is different: a rank that raises in the middle of ``run_layers()`` leaves its peers
     blocked in that candidate's exchange, and no reduce can be reached from there - such an error is FATAL for this attempt and
     propagates (the launch ladder above, multigpu / launch_guard, abandons the process group and falls back to its next plan).
+    A candidate whose warm-up ends with a device-side wait that GAVE UP (``model.exchange_gave_up()``: the arrival-driven attention's
+    in-kernel deadline, shortened to AUTOTUNE_WAIT_DEADLINE_US here, or the copy-engine transport's) is dropped on every rank too.
     ``exchange_only()`` (optional): one layer's exchange with nothing to hide under; its time is recorded next to the layer time
     (``exchange_ms``: the raw transfer, for the bandwidth it implies), never used for the choice.
     ``probe(mode, chunks) -> dict`` (optional): further per-candidate measurements merged into the candidate's row (bench.py: the
@@ -732,8 +737,26 @@ def autotune_kv_exchange(model, run_layers, sync, candidates=None, reps: int = 2
             if log:
                 log(f"autotune {mode:9s} chunks {chunks}: unusable ({err or 'set-up failed on another rank'})")
             continue
+        # warm-up under a SHORT in-kernel deadline: a candidate whose data movement cannot make progress beside the waiting work-groups of
+        # the arrival-driven attention (an RCCL channel kernel that finds no room on CUs full of spinning attention work-groups: a hazard
+        # no one-GPU rehearsal can show - a 1-rank ncclAllGather is a plain device copy) must cost seconds, not the product's deadline
+        long_deadline = getattr(model, "sp_timeout_us", None)
+        if long_deadline is not None:
+            model.sp_timeout_us = min(long_deadline, AUTOTUNE_WAIT_DEADLINE_US)
         run_layers()
         sync()
+        if long_deadline is not None:
+            model.sp_timeout_us = long_deadline
+        gave_up = model.exchange_gave_up() if hasattr(model, "exchange_gave_up") else None
+        bad = 1.0 if gave_up else 0.0
+        if reduce_max is not None:
+            bad = reduce_max([bad])[0]
+        if bad:
+            why = gave_up or "a device-side wait gave up on another rank"
+            table.append(dict(kv_exchange=mode, sp_chunks=chunks, ms=None, error=("starved or stalled: " + why)[:300], exchange_ms=None))
+            if log:
+                log(f"autotune {mode:17s} chunks {chunks}: dropped ({why[:200]})")
+            continue
         t0 = time.perf_counter()
         for _ in range(reps):
             run_layers()

@@ -147,3 +147,46 @@ def test_a_piece_that_never_arrives_is_a_bounded_wait_and_an_error_word(hip_ops)
     torch.cuda.synchronize()
     assert time.time() - t0 < 5.0
     assert (int(err.item()) & 0xffffffff) == (0x80000000 | 1)
+
+
+def test_autotune_drops_a_candidate_whose_rows_never_come_under_the_waiting_attention(hip_ops, monkeypatch):
+    """The hazard no 1-GPU rehearsal of a transport can show: a kernel-based transport (an RCCL channel kernel) that finds no room on CUs
+    full of WAITING attention work-groups would starve the arrival-driven launch until its in-kernel deadline (a 1-rank ncclAllGather is
+    a plain device copy - tools/probe_rccl_under_arrival.py - so RCCL itself cannot be provoked here).  seqpar.autotune_kv_exchange
+    therefore warms every candidate up under a SHORT deadline and drops the one whose launch gave up.  Here a stand-in engine has one
+    candidate whose flag is never raised and one that is fine: the first must cost about the short deadline, be reported as starved,
+    and the second must win."""
+    import time
+    from infinicube_amd.videogen import seqpar
+    monkeypatch.setattr(seqpar, "AUTOTUNE_WAIT_DEADLINE_US", 50_000)
+    H, Sq = 2, 512
+    d = H * 128
+    q, kv = _qkv(Sq, 1024, H, 340)
+    q, kv = q.to(DEV), kv.to(DEV)
+    views = _views(kv, [0, 512, 1024], d)
+
+    class Engine:
+        sp_timeout_us = 60_000_000
+
+        def set_kv_exchange(self, mode, chunks):
+            self.mode = mode
+            self.err = torch.zeros((1,), dtype=torch.int32, device=DEV)
+            self.flags = torch.zeros((1,), dtype=torch.int32, device=DEV)
+            self.o = torch.zeros((Sq, d), dtype=torch.bfloat16, device=DEV)
+            return self
+
+        def run(self):
+            gate = 0 if self.mode == "starved+arrival" else -1
+            hip_ops.attention_pieces(q, [(views[0][0], views[0][1], -1, 0), (views[1][0], views[1][1], gate, 1)], self.o, H, SCALE,
+                                     flags=self.flags, err=self.err, timeout_us=self.sp_timeout_us)
+
+        def exchange_gave_up(self):
+            e = int(self.err.item()) & 0xffffffff
+            return f"attention gave up waiting for K|V piece {e & 0xffff}" if e else None
+
+    eng = Engine()
+    t0 = time.time()
+    best, table = seqpar.autotune_kv_exchange(eng, eng.run, torch.cuda.synchronize, [("starved+arrival", 4), ("fine+arrival", 4)], reps=1)
+    assert time.time() - t0 < 5.0, "the starved candidate must cost the SHORT deadline, not the product's"
+    assert best == ("fine+arrival", 4) and eng.mode == "fine+arrival" and eng.sp_timeout_us == 60_000_000
+    assert table[0]["ms"] is None and "starved or stalled" in table[0]["error"] and "piece 1" in table[0]["error"] and table[1]["ms"] > 0
