@@ -716,7 +716,8 @@ def run_rank(args, world, rank, phase, stdout_fd):
             },
             "roofline": {
                 "kernel": ("att7p::attn7p_kernel (self-attention, K6: ONE arrival-gated launch per layer over the K|V pieces; the time includes "
-                           "whatever the launch waited for rows inside)" if piece_events else "att7::attn7_kernel (self-attention, K6)") if args.attn_dtype == "bf16" else
+                           "whatever the launch waited for rows inside)" if piece_events else
+                           "att7p::attn7p_kernel, one piece (self-attention, K6: attn7's schedule in the pieces kernel, bit-identical, 1.5-2.7 % faster)") if args.attn_dtype == "bf16" else
                           "att8::attn8_kernel + its quantise pre-pass (e4m3 self-attention, K6)",
                 "bound": "mfma", "achieved": attn_tflops, "peak": attn_peak, "unit": "TFLOP/s",
                 "frac": attn_tflops / attn_peak, "traffic": traffic, "traffic_source": traffic_source,

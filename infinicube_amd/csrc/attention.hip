@@ -21,6 +21,8 @@ int icv_attn9_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, c
                        void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml, int state_in,
                        int state_out, int64_t Sq, int64_t Skv, int64_t heads, float scale, int var,
                        hipStream_t st);
+int icv_attn7p_single(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, float* acc,
+                      int64_t ldacc, float* ml, int state_in, int state_out, int64_t Sq, int64_t Skv, int64_t heads, float scale, hipStream_t st);
 int icv_attn7_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                        void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml, int state_in,
                        int state_out, int64_t Sq, int64_t Skv, int64_t heads, float scale, int var,
@@ -52,6 +54,13 @@ static int attn_route(const void* q, int64_t ldq, const void* k, int64_t ldk, co
       // clusters: +1.4 % on the 37 440-key self-attention of both model sizes, neutral on the sequence-parallel shard
       // shapes (same-process A/B, profiles/r03/attention_variants.md); a negative option value = this default
       const int var7 = icv_get_option_int("attn7_variant", -1);
+      // round 6: the default long-key launch (self-attention, plain or carried-state chunk) runs as ONE piece of the pieces kernel
+      // (csrc/attn7p.hip: attn7's variant-132 schedule, bit-identical, 1.5-2.7 % faster at the 14B shapes); an explicit attn7_variant,
+      // attn7_plain = 1 (A/B), the ablation switches and the short-key shape (cross-attention) keep attn7.hip
+      int short_max = icv_get_option_int("attn7_short", -1);
+      if (short_max < 0) short_max = 1024;
+      if (var7 < 0 && Skv > short_max && !icv_get_option_int("attn7_plain", 0) && !icv_get_option_int("attn7_ablate", 0) && state_out != 2)
+        return icv_attn7p_single(ATT_ARGS, st);
       return icv_attn7_dispatch(ATT_ARGS, var7 < 0 ? ATTN7_VARIANT_DEFAULT : var7, st);
     }
 #ifdef ICV_EXPERIMENTS

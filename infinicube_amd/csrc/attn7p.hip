@@ -104,6 +104,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
   int head, qb;
   attc::work_item(p, head, qb);
   const int64_t q0 = (int64_t)qb * QB + wave * 32;
+  const unsigned long long t_start = p.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
   const bf16_t* qh = p.q + (int64_t)head * D;
   int64_t qr_c = q0 + l31;
   qr_c = qr_c < p.Sq ? qr_c : p.Sq - 1;
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     unsigned long long* t = p.trace + (size_t)blockIdx.x * 4;
-    t[0] = 0; t[1] = __builtin_amdgcn_s_memrealtime(); t[2] = hwid; t[3] = xcc;
+    t[0] = t_start; t[1] = __builtin_amdgcn_s_memrealtime(); t[2] = hwid; t[3] = xcc;
   }
 #undef P_SET_DMA_PIECE
 #undef P_DMA_TILE
@@ -412,6 +413,22 @@ extern "C" int icv_attention_fwd_pieces(const void* q, int64_t ldq, const icv_kv
   pp.ptrace = (unsigned long long*)trace;
   pp.n_pieces = n;
   hipStream_t st = (hipStream_t)stream;
+  return (pp.a.sc == 1.0f && icv_get_option_int("attn_unit_scale", 1)) ? att7p::launch<true>(pp, st) : att7p::launch<false>(pp, st);
+}
+
+// The plain launch and the carried-state chunk launch as ONE piece of this kernel: the same tiles in the same order through the same
+// arithmetic as attn7.hip's default variant (bit-identical: tests/test_attn_pieces_gpu.py), measured 1.5-2.7 % faster at the 14B shapes
+// (23.36 vs 24.01 ms at S = 37 440, interleaved, profiles/r06/attn7p_vs_attn7.txt) - so attention.hip routes its default there.
+int icv_attn7p_single(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, float* acc,
+                      int64_t ldacc, float* ml, int state_in, int state_out, int64_t Sq, int64_t Skv, int64_t heads, float scale, hipStream_t st) {
+  ICV_REQUIRE(Skv > 0 && Skv < (1LL << 31) / 64 && 64 * ldk * 2 < (1LL << 32) && 64 * ldv * 2 < (1LL << 32), "icv_attention: key axis / row stride too large");
+  att7p::Params pp;
+  attc::fill_params(pp.a, q, ldq, nullptr, ldk, nullptr, ldv, o, ldo, acc, ldacc, ml, state_in, state_out, Sq, Skv, heads, scale, 256);
+  pp.a.trace = icv_attention_trace_buffer(&pp.a.trace_cap);
+  pp.flags = nullptr; pp.err = nullptr; pp.timeout_ticks = 0; pp.ptrace = nullptr;
+  pp.n_pieces = 1;
+  att7p::Piece& d = pp.piece[0];
+  d.k = (const bf16_t*)k; d.v = (const bf16_t*)v; d.rows = (int)Skv; d.flag = -1; d.value = 0; d.pad = 0;
   return (pp.a.sc == 1.0f && icv_get_option_int("attn_unit_scale", 1)) ? att7p::launch<true>(pp, st) : att7p::launch<false>(pp, st);
 }
 

@@ -40,7 +40,14 @@ def test_tile_aligned_pieces_in_memory_order_are_bit_identical_to_the_plain_laun
     scale = math.log(2.0) if unit else SCALE
     q, kv = q.to(DEV), kv.to(DEV)
     o_ref = torch.zeros((Sq, d), dtype=torch.bfloat16, device=DEV)
-    hip_ops.attention(q, kv[:, :d], kv[:, d:], o_ref, H, scale)
+    hip_ops.lib.icv_set_option(b"attn7_plain", 1)        # the reference = attn7.hip's own kernel (the default launch IS one piece of attn7p since round 6)
+    try:
+        hip_ops.attention(q, kv[:, :d], kv[:, d:], o_ref, H, scale)
+    finally:
+        hip_ops.lib.icv_set_option(b"attn7_plain", 0)
+    o_def = torch.zeros_like(o_ref)
+    hip_ops.attention(q, kv[:, :d], kv[:, d:], o_def, H, scale)
+    assert torch.equal(o_def, o_ref), "the default launch (one piece of attn7p) differs from attn7.hip's kernel"
     for bounds in ([0, Skv], [0, 64, Skv], [0, 64 * 5, 64 * 6, 64 * 20, Skv], [0, 64 * 36, Skv]):
         o = torch.zeros_like(o_ref)
         hip_ops.attention_pieces(q, [(k, v, -1, 0) for k, v in _views(kv, bounds, d)], o, H, scale)
