@@ -1,7 +1,9 @@
 """BASELINE.json config #1 in FULL on the CPU path: Wan2.1-1.3B t2v, 17 frames 256x448 (S = 2 240), 10 deterministic steps with CFG 5, dummy
 guidance buffers - the reference's own CPU-runnable case, here through oracle/wan_ref.py (the CPU restatement; the reference's DiT lives in an
 absent fork).  BASELINE.md §3 promised this figure; bench.py's `cpu_baseline` is a bounded-sample extrapolation for the 14B / 480p metric.
-Prints one line: seconds, threads, CPU model.  Usage: python tools/cpu_config1_full.py [threads]"""
+Prints one line: seconds, threads, CPU model.  Usage: python tools/cpu_config1_full.py [threads] [--save-golden]
+--save-golden also writes the final latent to tests/golden/config1_cpu_oracle_latent.npz: the fixture tests/test_dit_gpu.py::test_config1_...
+compares the HIP loop (and the GPU-executed oracle) with AT THE FULL GRID - the CPU path itself as the checker of config #1."""
 import os
 import sys
 import time
@@ -13,7 +15,8 @@ from infinicube_amd.videogen import synthetic as syn
 from infinicube_amd.videogen.config import TokenGrid, preset
 from oracle import wan_ref as R
 
-threads = int(sys.argv[1]) if len(sys.argv) > 1 else (os.cpu_count() or 1)
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+threads = int(args[0]) if args else (os.cpu_count() or 1)
 torch.set_num_threads(threads)
 cfg, grid, steps = preset("1.3b"), TokenGrid(17, 256, 448), 10
 sd = {k: v.float() for k, v in syn.make_dit_state_dict(cfg, seed=0, dtype=torch.bfloat16).items()}
@@ -33,3 +36,10 @@ flops = 2 * steps * 6.88e12          # F_fwd of config #1
 print(f"config #1 in full on the CPU oracle (fp32, torch {torch.__version__}): Wan2.1-1.3B 17f 256x448, S = {grid.S}, {steps} steps x 2 forwards: "
       f"{dt:.1f} s = {dt / steps:.2f} s per denoise step = {steps / dt:.4f} steps/s on {threads} threads of {os.cpu_count()} logical CPUs ({model}); "
       f"{flops / dt / 1e12:.3f} TFLOP/s algorithmic; latent finite: {bool(torch.isfinite(lat).all())}, rms {float(lat.pow(2).mean().sqrt()):.4f}")
+
+if "--save-golden" in sys.argv:
+    import numpy as np
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "config1_cpu_oracle_latent.npz")
+    np.savez_compressed(out, latent=lat.numpy().astype(np.float32), noise_head=noise.flatten()[:16].numpy(), steps=steps, cfg_scale=5.0,
+                        note="oracle/wan_ref.denoise_loop on CPU, Wan2.1-1.3B random-init (synthetic.make_dit_state_dict seed 0, bf16-rounded), 17f 256x448, 10 steps")
+    print("golden latent written to", out, os.path.getsize(out), "bytes")
