@@ -497,7 +497,7 @@ def test_config1_wan_1p3b_17f_256p_10_steps(hip_ops):
     rel_cpu = float((ref - cpu_ref).norm() / cpu_ref.norm())
     p_cpu = R.psnr(lat.cpu(), cpu_ref)
     print(f"config #1, full grid: oracle on the GPU vs the committed CPU-oracle latent rel-L2 {rel_cpu:.3g}; HIP loop vs the CPU-oracle latent {p_cpu:.1f} dB")
-    assert rel_cpu < 2e-3, f"the GPU-executed oracle drifted from the CPU path over 10 steps: rel-L2 {rel_cpu}"
+    assert rel_cpu < 1e-4, f"the GPU-executed oracle drifted from the CPU path over 10 steps: rel-L2 {rel_cpu}"
     assert p_cpu >= 40.0, f"config #1 vs the CPU path: {p_cpu:.1f} dB"
     p = R.psnr(lat.cpu(), ref)
     cos = float(torch.nn.functional.cosine_similarity((lat.cpu() - noise).flatten(), (ref - noise).flatten(), dim=0))
