@@ -61,6 +61,11 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
   w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
   return (unsigned)w;
 }
+// the same when the destination's previous content may be anything (both halves are overwritten): no zero-initialising v_mov per dword
+__device__ __forceinline__ int pack_fp8x4_over(float a, float b, float c, float d, int old) {
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, old, false);
+  return __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+}
 
 // pass 2a: Q / K rows -> e4m3 [rows, H*128] with the head's power-of-two scale
 __global__ __launch_bounds__(256) void quant_rows_kernel(const bf16_t* __restrict__ x, int64_t ld, int64_t rows,
@@ -142,16 +147,35 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
       : "memory");
 }
 
+// the same with the address split into a wave-uniform base (SGPR pair) and a per-lane 32-bit byte offset that does not change from
+// tile to tile: no vector arithmetic per request (round 6: attn8 is bounded by VALU issue, profiles/r06/rocprofv3_summary_i2v720_fp8.md)
+__device__ __forceinline__ void dma16s(const void* base, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  // the "s" constraint alone does not move a value the compiler chose to keep in vector registers: make it scalar (folds away when it is)
+  const uint64_t b = (uint64_t)(uintptr_t)base;
+  const uint64_t sbase = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)b);
+  (void)keep;
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1"
+      :
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory", "m0");
+}
+
 __device__ __forceinline__ i32x8 read32(const char* p0, const char* p1) {
   const i32x4 lo = *reinterpret_cast<const i32x4*>(p0);
   const i32x4 hi = *reinterpret_cast<const i32x4*>(p1);
   return (i32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-// VAR bit flags: 1 = wave groups one tile apart, 4 = s_setprio(1) around MFMA clusters
+// VAR bit flags: 32 = software-pipelined key loop (S(t+1) and O += V(t-1)P(t-1) issued around tile t's softmax; implies 8), 64 = its row sums on
+// packed adds, 1 = wave groups one tile apart, 4 = s_setprio(1) around MFMA clusters, 8 = lean vector work (LDS-DMA addresses as
+// scalar base + constant lane offset, row sums on packed fp32 adds)
 template <int VAR>
 __global__ __launch_bounds__(512) void attn8_kernel(Params p) {
-  constexpr bool STAGGER = VAR & 1, SETPRIO = VAR & 4;
+  constexpr bool STAGGER = VAR & 1, SETPRIO = VAR & 4, PIPE = VAR & 32, LEAN = (VAR & 8) || PIPE, PKADD = VAR & 64, PFD2 = VAR & 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -191,6 +215,9 @@ __global__ __launch_bounds__(512) void attn8_kernel(Params p) {
   f32x16 ot[4];
   float m_run, l_run;
   attc::load_state(p.c, qr_c, head, hi, ot, m_run, l_run);      // empty, or the state carried from the previous key chunk
+  // the carried state's loads retire HERE: left pending, the compiler's wait for them lands on the accumulators' first use inside
+  // the key loop - a vmcnt(0) per tile that also waits for the LDS-DMA requests just issued (found in the ISA, round 6)
+  if (!(VAR & 16)) __builtin_amdgcn_s_waitcnt(0x0F70);     // VAR bit 16: round 5's behaviour, kept for the A/B (tools/attn_fp8_bench.py)
   float m_base = m_run < -1.0e29f ? 0.f : m_run;               // reference baked into cinit (0 while there is none yet)
   f32x16 cinit;
 #pragma unroll
@@ -208,8 +235,43 @@ __global__ __launch_bounds__(512) void attn8_kernel(Params p) {
   const unsigned char* kh = p.k + (int64_t)head * D;
   // tile -> (piece, tile inside the piece), advanced incrementally: A8_DMA_TILE is called once per tile index, in order
   int d_pc = 0, d_tl = 0;
+  // LEAN: per-lane byte offsets inside a tile, fixed for the whole launch (the ragged last tile of a piece clamps its rows)
+  const int rag_rows = p.piece_rows - (p.tpp - 1) * KVB;
+  const unsigned koff_full = (unsigned)(krow * (int)p.ldk + kcol);
+  const unsigned koff_rag = (unsigned)((krow < rag_rows ? krow : rag_rows - 1) * (int)p.ldk + kcol);
+  const unsigned voff = (unsigned)(vrow * KVB + vcol);
+  // LEAN / PIPE: the next tile's two source addresses live in scalar registers and advance by a constant (a piece boundary
+  // recomputes them): ~10 scalar instructions per tile instead of ~50
+  const unsigned char* kp_ = kh;
+  const unsigned char* vp_ = p.vt + (int64_t)head * p.tpp * (D * KVB);
 #define A8_DMA_TILE(T_)                                                                              \
-  {                                                                                                  \
+  if (PIPE) {                                                                                        \
+    const unsigned l0_ = lds_base + (unsigned)(((T_) & (NSTAGE - 1)) * STAGE_BYTES + wave * 1024);   \
+    dma16s(kp_, d_tl == p.tpp - 1 ? koff_rag : koff_full, l0_);                                      \
+    dma16s(vp_, voff, l0_ + KT_BYTES);                                                               \
+    if ((T_) < nt - 1) {                                                                             \
+      if (d_tl + 1 == p.tpp) {                                                                       \
+        d_tl = 0;                                                                                    \
+        d_pc = d_pc + 1;                                                                             \
+        kp_ = kh + (int64_t)d_pc * p.piece_stride;                                                   \
+        vp_ = p.vt + (int64_t)d_pc * p.piece_stride + (int64_t)head * p.tpp * (D * KVB);             \
+      } else {                                                                                       \
+        d_tl = d_tl + 1;                                                                             \
+        kp_ += (int64_t)KVB * p.ldk;                                                                 \
+        vp_ += D * KVB;                                                                              \
+      }                                                                                              \
+    }                                                                                                \
+  } else if (LEAN) {                                                                                 \
+    const unsigned l0_ = lds_base + (unsigned)(((T_) & (NSTAGE - 1)) * STAGE_BYTES + wave * 1024);   \
+    const int64_t pb_ = (int64_t)d_pc * p.piece_stride;                                              \
+    dma16s(kh + pb_ + (int64_t)d_tl * KVB * p.ldk, d_tl == p.tpp - 1 ? koff_rag : koff_full, l0_);   \
+    dma16s(p.vt + pb_ + ((int64_t)head * p.tpp + d_tl) * (D * KVB), voff, l0_ + KT_BYTES);           \
+    /* the same advance as below in mask arithmetic: a boolean turned into an integer goes through a vector register */ \
+    const int go_ = ((T_) - (nt - 1)) >> 31;            /* -1 while there is a next tile */              \
+    const int in_ = (d_tl + 1 - p.tpp) >> 31;           /* -1 while the next tile is in the same piece */ \
+    d_pc += (1 + in_) & go_;                                                                         \
+    d_tl = (((d_tl + 1) & in_) & go_) | (d_tl & ~go_);                                               \
+  } else {                                                                                           \
     int kr_ = d_tl * KVB + krow;                                                                     \
     kr_ = kr_ < p.piece_rows ? kr_ : p.piece_rows - 1;                                               \
     const unsigned l0_ = lds_base + (unsigned)(((T_) & (NSTAGE - 1)) * STAGE_BYTES + wave * 1024);   \
@@ -230,14 +292,16 @@ __global__ __launch_bounds__(512) void attn8_kernel(Params p) {
   } while (0)
 
   const int grp = STAGGER ? (wave >> 2) : 0;
-  A8_DMA_TILE(0);
-  A8_DMA_TILE(1);
-  A8_VMCNT2();
-  A8_BARRIER();
-  if (grp == 1) {
-    A8_DMA_TILE(2);
+  if constexpr (!PIPE) {               // (the pipelined loop has its own prologue below)
+    A8_DMA_TILE(0);
+    A8_DMA_TILE(1);
     A8_VMCNT2();
     A8_BARRIER();
+    if (grp == 1) {
+      A8_DMA_TILE(2);
+      A8_VMCNT2();
+      A8_BARRIER();
+    }
   }
   const int ahead = 2 + grp;
 
@@ -247,8 +311,169 @@ __global__ __launch_bounds__(512) void attn8_kernel(Params p) {
   const int v_sw0 = (l31 >> 2) & 3;          // ((d0*32 + l31) >> 2) & 3 == (l31 >> 2) & 3
 
   int c_tl = 0;        // tile inside its piece of the tile being computed
-  for (int t = 0; t < nt; ++t) {
-    const char* ks = smem + (t & (NSTAGE - 1)) * STAGE_BYTES;
+  i32x8 pf = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  if constexpr (PIPE) {
+    // ---- software-pipelined key loop (round 6) ----
+    // One iteration = tile t's softmax (vector work) issued BETWEEN the matrix instructions of its neighbours: S(t+1) = K(t+1) Q^T and
+    // O += V(t-1) P(t-1).  A wave's MFMAs run asynchronously to its own VALU stream, so the exponentials no longer wait on the matrix
+    // pipe and the matrix pipe no longer waits for them (the un-pipelined loop relies on the OTHER wave of the SIMD being in the
+    // opposite phase - which a per-tile barrier prevents: both start every tile together).  Ring use: tile t+2 is requested at the top
+    // of iteration t into the stage K(t-2) left two iterations ago and V(t-2) left in the previous one; it has to have landed by the
+    // end of the iteration (vmcnt(0): one iteration of latency cover - measured sufficient, the rows come from L2).
+#define A8_QK(STG_, DST_)                                                                                                       \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                                \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                                           \
+      const int c0 = 4 * s + 2 * hi;                                                                                             \
+      const char* rowp = smem + (STG_) * STAGE_BYTES + kb * 4096 + k_row;                                                        \
+      const i32x8 kf = read32(rowp + ((c0 ^ k_sw) << 4), rowp + (((c0 + 1) ^ k_sw) << 4));                                       \
+      DST_[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf[s], s == 0 ? cinit : DST_[kb], 0, 0, 0, sK, 0, sQ);      \
+    }
+#define A8_PV(STG_, PF_)                                                                                                        \
+    _Pragma("unroll") for (int d0 = 0; d0 < 4; ++d0) {                                                                           \
+      const char* rowp = smem + (STG_) * STAGE_BYTES + KT_BYTES + (d0 * 32 + l31) * 64;                                          \
+      const i32x8 vf = read32(rowp + (((2 * hi) ^ v_sw0) << 4), rowp + (((2 * hi + 1) ^ v_sw0) << 4));                           \
+      ot[d0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, PF_, ot[d0], 0, 0, 0, sV, 0, 127);                            \
+    }
+    // V of "tile -1" (stage NSTAGE-1) = zeros: the first iteration's O += V(-1) P(-1) adds 0 x 0 instead of branching around it
+    *reinterpret_cast<i32x4*>(smem + (NSTAGE - 1) * STAGE_BYTES + KT_BYTES + tid * 16) = (i32x4){0, 0, 0, 0};
+    A8_DMA_TILE(0);
+    A8_DMA_TILE(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    A8_BARRIER();
+    f32x16 stx[2][2];
+    i32x8 pfx[2] = {pf, pf};
+    A8_QK(0, stx[0]);
+    for (int t4 = 0; t4 < nt; t4 += NSTAGE) {
+#pragma unroll
+      for (int ti = 0; ti < NSTAGE; ++ti) {
+        const int t = t4 + ti;
+        if (t >= nt) break;
+        f32x16(&st)[2] = stx[ti & 1];
+        f32x16(&sn)[2] = stx[(ti + 1) & 1];
+        const int key0 = c_tl * KVB;
+        {
+          const int in_ = (c_tl + 1 - p.tpp) >> 31;
+          c_tl = (c_tl + 1) & in_;
+        }
+        if (key0 + KVB > p.piece_rows) {               // the ragged last tile of a piece (S(t) was finished an iteration ago)
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+              if (key >= p.piece_rows) st[kb][r] = NEG_BIG;
+            }
+        }
+        A8_DMA_TILE(t + 2);
+        const bool no_ref = m_run < -1.0e29f;
+        // ---- the pipelined block: 8 segments = one MFMA each (S(t+1): two first halves, two of O += V(t-1) P(t-1), S(t+1): second
+        // halves - four MFMAs after the ones they accumulate on - , the other two of O), the NEXT segment's fragment read, and a tenth of
+        // tile t's softmax in the MFMA's shadow: 4 exponentials, their row-sum adds, their e4m3 packing ----
+        float pv[2][16];
+        float ps = 0.f;
+        f32x2 ps2 = {0.f, 0.f};
+        i32x8& pn = pfx[ti & 1];
+        const i32x8 pp = pfx[(ti + 1) & 1];
+        const char* const kst = smem + ((ti + 1) & (NSTAGE - 1)) * STAGE_BYTES + k_row;
+        const char* const vst = smem + ((ti + NSTAGE - 1) & (NSTAGE - 1)) * STAGE_BYTES + KT_BYTES + l31 * 64;
+        auto frag = [&](int g) -> i32x8 {
+          if (g == 0 || g == 1 || g == 4 || g == 5) {           // K fragment: key block kb = g & 1, k-step s = g >> 2
+            const int c0 = 4 * (g >> 2) + 2 * hi;
+            const char* rowp = kst + (g & 1) * 4096;
+            return read32(rowp + ((c0 ^ k_sw) << 4), rowp + (((c0 + 1) ^ k_sw) << 4));
+          }
+          const int d0 = (g & 1) + ((g >> 2) << 1);             // V^T fragment: d block 0, 1 (g = 2, 3) and 2, 3 (g = 6, 7)
+          const char* rowp = vst + d0 * 32 * 64;
+          return read32(rowp + (((2 * hi) ^ v_sw0) << 4), rowp + (((2 * hi + 1) ^ v_sw0) << 4));
+        };
+        i32x8 fr = frag(0), fr1 = fr;
+        if (PFD2) fr1 = frag(1);
+        if (SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          i32x8 nfr = fr;
+          if (g + (PFD2 ? 2 : 1) < 8) nfr = frag(g + (PFD2 ? 2 : 1));
+          if (g == 0 || g == 1) sn[g] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fr, qf[0], cinit, 0, 0, 0, sK, 0, sQ);
+          else if (g == 4 || g == 5) sn[g - 4] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fr, qf[1], sn[g - 4], 0, 0, 0, sK, 0, sQ);
+          else {
+            const int d0 = (g & 1) + ((g >> 2) << 1);
+            ot[d0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fr, pp, ot[d0], 0, 0, 0, sV, 0, 127);
+          }
+          const int kb = g >> 2, r0 = (g & 3) * 4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pv[kb][r0 + j] = __builtin_amdgcn_exp2f(st[kb][r0 + j]);
+          if (PKADD) {
+            ps2 += (f32x2){pv[kb][r0], pv[kb][r0 + 1]};
+            ps2 += (f32x2){pv[kb][r0 + 2], pv[kb][r0 + 3]};
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ps += pv[kb][r0 + j];
+          }
+          pn[g] = pack_fp8x4_over(pv[kb][r0], pv[kb][r0 + 1], pv[kb][r0 + 2], pv[kb][r0 + 3], pn[g]);
+          if (PFD2) { fr = fr1; fr1 = nfr; } else fr = nfr;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (SETPRIO) __builtin_amdgcn_s_setprio(0);
+        if (PKADD) ps = ps2[0] + ps2[1];
+        if (__any(!(ps <= p_lim) || no_ref)) {         // rare: re-base on the tile's true maximum (after O += V(t-1) P(t-1) was issued)
+          float mloc = st[0][0];
+#pragma unroll
+          for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[0][r]);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[1][r]);
+          mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) + m_base;
+          const float m_new = fmaxf(m_run, mloc);
+          const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+          m_run = m_new;
+          l_run *= alpha;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
+          const float dm = m_new - m_base;
+          m_base = m_new;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) cinit[r] = -m_new;
+          ps = 0.f;
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              pv[kb][r] = __builtin_amdgcn_exp2f(st[kb][r] - dm);
+              ps += pv[kb][r];
+              sn[kb][r] -= dm;                          // S(t+1) was started against the old reference
+            }
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) pn[kb * 4 + (r >> 2)] = pack_fp8x4_over(pv[kb][r], pv[kb][r + 1], pv[kb][r + 2], pv[kb][r + 3], pn[kb * 4 + (r >> 2)]);
+        }
+        l_run += ps;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        A8_BARRIER();
+      }
+    }
+    {                                                   // the last tile's O += V P
+      const int lt = (nt - 1) & (NSTAGE - 1);
+      i32x8 pl;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) pl[i] = ((nt - 1) & 1) ? pfx[1][i] : pfx[0][i];
+      A8_PV(lt, pl);
+    }
+    attc::store_result(p.c, q0 + l31, head, hi, ot, m_run, l_run);
+    return;
+#undef A8_QK
+#undef A8_PV
+  }
+  // LEAN: the ring position is a compile-time constant in each of NSTAGE unrolled bodies, so every ds_read address is a lane
+  // register (fixed for the launch) plus an immediate: no vector address arithmetic per tile
+  for (int t4 = 0; t4 < nt; t4 += (LEAN ? NSTAGE : 1))
+#pragma unroll
+  for (int ti = 0; ti < (LEAN ? NSTAGE : 1); ++ti) {
+    const int t = t4 + ti;
+    if (LEAN && t >= nt) break;
+    const char* ks = smem + (LEAN ? ti : (t & (NSTAGE - 1))) * STAGE_BYTES;
     const char* vs = ks + KT_BYTES;
     const int key0 = c_tl * KVB;                   // first key of this tile inside its piece
     if (++c_tl == p.tpp) c_tl = 0;
@@ -282,13 +507,26 @@ __global__ __launch_bounds__(512) void attn8_kernel(Params p) {
     // no reference yet) the tile's true max is taken, O / l rescaled, the scores re-based and P recomputed ----
     float pv[2][16];
     float ps = 0.f;
+    if (LEAN) {                       // two running partial sums per lane: v_pk_add_f32 adds a pair of P per instruction
+      f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        pv[kb][r] = __builtin_amdgcn_exp2f(st[kb][r]);
-        ps += pv[kb][r];
-      }
+        for (int r = 0; r < 16; r += 2) {
+          pv[kb][r] = __builtin_amdgcn_exp2f(st[kb][r]);
+          pv[kb][r + 1] = __builtin_amdgcn_exp2f(st[kb][r + 1]);
+          ps2 += (f32x2){pv[kb][r], pv[kb][r + 1]};
+        }
+      ps = ps2[0] + ps2[1];
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          pv[kb][r] = __builtin_amdgcn_exp2f(st[kb][r]);
+          ps += pv[kb][r];
+        }
+    }
     if (__any(!(ps <= p_lim) || no_ref)) {
       float mloc = st[0][0];
 #pragma unroll
@@ -318,11 +556,13 @@ __global__ __launch_bounds__(512) void attn8_kernel(Params p) {
         }
     }
     l_run += ps;
-    i32x8 pf;   // P^T operand: the lane's 32 keys in k-slot order j = kb*16 + r (tile_key), 4 e4m3 per dword
+    // P^T operand: the lane's 32 keys in k-slot order j = kb*16 + r (tile_key), 4 e4m3 per dword
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; r += 4) pf[kb * 4 + (r >> 2)] = (int)pack_fp8x4(pv[kb][r], pv[kb][r + 1], pv[kb][r + 2], pv[kb][r + 3]);
+      for (int r = 0; r < 16; r += 4)
+        pf[kb * 4 + (r >> 2)] = LEAN ? pack_fp8x4_over(pv[kb][r], pv[kb][r + 1], pv[kb][r + 2], pv[kb][r + 3], pf[kb * 4 + (r >> 2)])
+                                     : (int)pack_fp8x4(pv[kb][r], pv[kb][r + 1], pv[kb][r + 2], pv[kb][r + 3]);
     // ---- O^T += Vt P^T : one MFMA per 32-row d block ----
     if (SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -403,11 +643,24 @@ static int attn8_run(const void* qq, int64_t ldqq, const void* kq, int64_t ldkq,
   p.c.o = (bf16_t*)o; p.c.ldo = ldo; p.c.acc = acc; p.c.ldacc = ldacc; p.c.ml = ml; p.c.state_in = state_in; p.c.state_out = state_out;
   p.c.Sq = Sq; p.c.Skv = Skv; p.c.heads = (int)heads; p.c.nqb = p.nqb; p.c.sc = 1.0f; p.c.thr = p.thr;
   ICV_REQUIRE((int64_t)p.heads * p.nqb < (1LL << 31) && piece_rows < (1LL << 30), "icv_attention_fp8_fwd: grid too large");
-  switch (icv_get_option_int("attn8_variant", 0)) {
+  // default (-1) = 164: the software-pipelined loop, fragment reads two segments ahead, s_setprio(1) over the pipelined block
+  // (+10...12 % over round 5's loop = variant 0 at S = 37 440 / 86 400, +4 % at 512 text keys, bit-identical outputs:
+  // profiles/r06/attn8_pipelined_ab.txt)
+  int variant = icv_get_option_int("attn8_variant", -1);
+  if (variant < 0) variant = 164;
+  switch (variant) {
     case 0: return att8::launch<0>(p, st);
     case 1: return att8::launch<1>(p, st);
     case 4: return att8::launch<4>(p, st);
     case 5: return att8::launch<5>(p, st);
+    case 8: return att8::launch<8>(p, st);
+    case 9: return att8::launch<9>(p, st);
+    case 16: return att8::launch<16>(p, st);
+    case 32: return att8::launch<32>(p, st);
+    case 96: return att8::launch<96>(p, st);
+    case 36: return att8::launch<36>(p, st);
+    case 160: return att8::launch<160>(p, st);
+    case 164: return att8::launch<164>(p, st);
   }
   icv_set_error("icv_attention_fp8_fwd: unknown attn8_variant");
   return 1;

@@ -35,11 +35,21 @@ for name, Sq, Skv, H in (("1.3b self", 37440, 37440, 12), ("14b self", 37440, 37
                                                     o.data_ptr(), o.stride(0), Sq, Skv, H, ops._stream()))
     fl = 4.0 * Sq * Skv * d / 1e9
     alt = ""
+    ref_o = None
     for var in [int(x) for x in os.environ.get("ATTN8_VARIANTS", "").split(",") if x]:
         ops.lib.icv_set_option(b"attn8_variant", var)
         tv = timeit(lambda: ops.lib.icv_attention_fp8_fwd(qq.data_ptr(), qq.stride(0), kq.data_ptr(), kq.stride(0), vt.data_ptr(), amax.data_ptr(),
                                                         o.data_ptr(), o.stride(0), Sq, Skv, H, ops._stream()))
-        alt += f" | variant {var}: {fl / tv:7.1f} TF"
-    ops.lib.icv_set_option(b"attn8_variant", 0)
+        if ref_o is None:
+            ops.lib.icv_set_option(b"attn8_variant", 0)
+            ops.lib.icv_attention_fp8_fwd(qq.data_ptr(), qq.stride(0), kq.data_ptr(), kq.stride(0), vt.data_ptr(), amax.data_ptr(),
+                                          o.data_ptr(), o.stride(0), Sq, Skv, H, ops._stream())
+            ref_o = o.clone()
+            ops.lib.icv_set_option(b"attn8_variant", var)
+            ops.lib.icv_attention_fp8_fwd(qq.data_ptr(), qq.stride(0), kq.data_ptr(), kq.stride(0), vt.data_ptr(), amax.data_ptr(),
+                                          o.data_ptr(), o.stride(0), Sq, Skv, H, ops._stream())
+        dmax = float((o.float() - ref_o.float()).abs().max())
+        alt += f" | variant {var}: {fl / tv:7.1f} TF (max |diff| vs 0: {dmax:.3g})"
+    ops.lib.icv_set_option(b"attn8_variant", -1)
     print(f"{name:14s} Sq={Sq} Skv={Skv} H={H}: bf16 {fl / t16:7.1f} TF ({t16:.3f} ms) | fp8 fwd {fl / tf:7.1f} TF ({tf:.3f} ms) | "
           f"prepare {t8 - tf:.3f} ms | fp8 total speed-up {t16 / t8:.2f}x" + alt)
