@@ -23,6 +23,9 @@ int icv_attn9_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, c
                        hipStream_t st);
 int icv_attn7p_single(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, float* acc,
                       int64_t ldacc, float* ml, int state_in, int state_out, int64_t Sq, int64_t Skv, int64_t heads, float scale, hipStream_t st);
+int icv_attn7q_single(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, float* acc,
+                      int64_t ldacc, float* ml, int state_in, int state_out, int64_t Sq, int64_t Skv, int64_t heads, float scale, int variant,
+                      hipStream_t st);
 int icv_attn7_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                        void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml, int state_in,
                        int state_out, int64_t Sq, int64_t Skv, int64_t heads, float scale, int var,
@@ -44,6 +47,7 @@ int icv_attn4_dispatch(const void* q, int64_t ldq, const void* k, int64_t ldk, c
 // scale), 2 = attn2.hip, 3..6 = the experiments kept for A/B, 1 = experiments/attn1.hip (icv_attention_fwd only).
 constexpr int ATTN_KERNEL_DEFAULT = 7;
 constexpr int ATTN7_VARIANT_DEFAULT = 132;
+constexpr int ATTN7Q_DEFAULT = 0;
 static int attn_route(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
                       int64_t ldo, float* acc, int64_t ldacc, float* ml, int state_in, int state_out, int64_t Sq,
                       int64_t Skv, int64_t heads, float scale, hipStream_t st) {
@@ -59,8 +63,19 @@ static int attn_route(const void* q, int64_t ldq, const void* k, int64_t ldk, co
       // attn7_plain = 1 (A/B), the ablation switches and the short-key shape (cross-attention) keep attn7.hip
       int short_max = icv_get_option_int("attn7_short", -1);
       if (short_max < 0) short_max = 1024;
-      if (var7 < 0 && Skv > short_max && !icv_get_option_int("attn7_plain", 0) && !icv_get_option_int("attn7_ablate", 0) && state_out != 2)
+      if (var7 < 0 && Skv > short_max && !icv_get_option_int("attn7_plain", 0) && !icv_get_option_int("attn7_ablate", 0) && state_out != 2) {
+#ifdef ICV_EXPERIMENTS
+        // experiments/attn7q.hip: attn8's software-pipelined loop on the bf16 MFMA (1 / 2 = fragment prefetch distance).  Measured SLOWER than
+        // attn7p (1133 vs 1196 TF/s): same MFMA busy (0.58 vs 0.59), 43 % more vector instructions, lower sustained clock (1.89 vs 1.94 GHz) -
+        // the bf16 attention sits on the power limit, not on its schedule (profiles/r06/attn7q_pipelined_bf16_negative.txt)
+        const int q7 = icv_get_option_int("attn7q", ATTN7Q_DEFAULT);
+        if (q7 > 0) {
+          const int rc = icv_attn7q_single(ATT_ARGS, q7, st);
+          if (rc >= 0) return rc;
+        }
+#endif
         return icv_attn7p_single(ATT_ARGS, st);
+      }
       return icv_attn7_dispatch(ATT_ARGS, var7 < 0 ? ATTN7_VARIANT_DEFAULT : var7, st);
     }
 #ifdef ICV_EXPERIMENTS

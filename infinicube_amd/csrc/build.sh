@@ -2,7 +2,7 @@
 # Build libicvideo.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
 # Usage: infinicube_amd/csrc/build.sh [extra hipcc flags]
 #        ICV_EXPERIMENTS=1 infinicube_amd/csrc/build.sh   also compiles the measured-slower A/B kernels under experiments/
-#        (attention families 1, 3, 4, 5, 6 and the 4-wave GEMM) into the library; the shipped build leaves them out.
+#        (attention families 1, 3, 4, 5, 6, 9, the software-pipelined bf16 attention attn7q and the 4-wave GEMM) into the library; the shipped build leaves them out.
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 root="$(cd "$here/../.." && pwd)"
@@ -15,7 +15,7 @@ mkdir -p "$here/build"
 srcs=(api elementwise gemm gemm256 gemm256p gemm_fp8 fp8 attention attn2 attn7 attn7p attn8 buffers voxels vae_ops dit_forward comm ipc conv)
 tag=""
 if [[ "${ICV_EXPERIMENTS:-0}" == "1" ]]; then
-  srcs+=(experiments/attn1 experiments/attn3 experiments/attn4 experiments/attn5 experiments/attn6 experiments/attn9 experiments/gemm256w experiments/gemm256x)
+  srcs+=(experiments/attn1 experiments/attn3 experiments/attn4 experiments/attn5 experiments/attn6 experiments/attn9 experiments/attn7q experiments/gemm256w experiments/gemm256x)
   FLAGS+=(-DICV_EXPERIMENTS)
   tag="x"          # separate object files: the two configurations differ in -DICV_EXPERIMENTS
 fi
