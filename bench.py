@@ -629,8 +629,9 @@ def run_rank(args, world, rank, phase, stdout_fd):
         comm = {"rccl_ranks": world, "backend": dist.get_backend(), "kv_exchange": args.kv_exchange, "sp_chunks": args.sp_chunks,
                 "kv_group_ranks": layout.sp_world, "rccl_max_channels": os.environ.get("NCCL_MAX_NCHANNELS") or "rccl default",
                 "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES") or "runtime default (4)",
-                "attention": "ONE arrival-gated launch per layer over the K|V pieces (csrc/attn7p.hip)" if getattr(model, "attn_arrival", False)
-                else "one carried-state launch per row chunk",
+                "attention": ("one carried-state launch per row chunk, each gating on its e4m3 blobs' arrival flags inside the kernel (csrc/attn8.hip)"
+                              if getattr(model, "fp8_wire", False) else "ONE arrival-gated launch per layer over the K|V pieces (csrc/attn7p.hip)")
+                if getattr(model, "attn_arrival", False) else "one carried-state launch per row chunk",
                 "kv_exchanges_per_step_per_rank": tt[2].item() / args.steps,
                 # what one rank SENDS per layer exchange: its k | v rows in bf16, or (e4m3 on the wire) its e4m3 blobs
                 "kv_bytes_sent_per_exchange_layer": 0 if layout.sp_world <= 1 else

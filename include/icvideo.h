@@ -34,7 +34,7 @@ extern "C" {
  *    _drain / _probe_copy, icv_probe_copy_path (arrival flags, bounded device-side waits, teardown that does not depend on live peers, copy-engine-or-blit
  *    probe), icv_flag_write; no existing
  *    signature changed. */
-#define ICV_ABI_VERSION 4
+#define ICV_ABI_VERSION 5
 
 /* ---- library / device ------------------------------------------------------------------ */
 int icv_abi_version(void);
@@ -182,6 +182,19 @@ int icv_attention_fp8_quantize_kv(const void* k, int64_t ldk, const void* v, int
 int icv_attention_fp8_fwd_pieces(const void* qq, int64_t ldqq, const void* blobs, int64_t piece_rows, int64_t n_pieces,
                                  const float* amax, void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml, int64_t Sq,
                                  int64_t heads, int first, int last, void* stream);
+/* icv_attention_fp8_fwd_pieces over blobs that may still be ARRIVING (round 6; SURVEY.md §8e for the e4m3 wire format; the counterpart
+ * of icv_attention_fwd_pieces below): the blobs are walked in the order seq_piece[0 .. n_pieces) - a permutation of the pieces, this
+ * rank's own first - and position i is read once (int)(flags[seq_flag[i]] - seq_value[i]) >= 0 (seq_flag[i] < 0: there when the launch
+ * starts); the wait is inside the kernel, bounded by timeout_us (0 = for ever): a flag that does not come sets
+ * *err = 0x80000000 | position (first one wins; err may be NULL) and the launch finishes on whatever the slot holds.  own_blob (may be
+ * NULL): piece own_index is read THERE instead of from its slot in `blobs` (the rank's own blob is not copied).  seq_* are host
+ * arrays of n_pieces (<= ICV_ATTN_MAX_PIECES) entries; flags / err are device words.
+ * Replaces: the host-side wait for a chunk's whole exchange in front of icv_attention_fp8_fwd_pieces [EXT: the fork's gather-then-attend]. */
+int icv_attention_fp8_fwd_pieces_gated(const void* qq, int64_t ldqq, const void* blobs, int64_t piece_rows, int64_t n_pieces,
+                                       const void* own_blob, int64_t own_index, const int32_t* seq_piece, const int32_t* seq_flag,
+                                       const uint32_t* seq_value, const uint32_t* flags, uint32_t* err, int64_t timeout_us,
+                                       const float* amax, void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml, int64_t Sq,
+                                       int64_t heads, int first, int last, void* stream);
 
 /* Diagnostics: buf = device u64 [capacity][4] (NULL = off).  While set, every work-group b < capacity of the following
  * icv_attention_fwd / _fwd_chunk launches (attn7 kernel) writes {start, end in 100 MHz s_memrealtime ticks, HW_ID, XCC_ID}

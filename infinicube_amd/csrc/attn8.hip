@@ -132,6 +132,19 @@ struct Params {
   int piece_rows, tpp;
   float thr;
   attc::Params c;   // o / ldo, carried state (acc, ldacc, ml, state_in, state_out), Sq, heads: what load_state / store_result read
+  // ---- arrival-gated pieces (VAR bit 256, icv_attention_fp8_fwd_pieces_gated): the pieces are walked in the order seq_piece[0..n) (this
+  // rank's own blob first, then the peers in the order the exchange delivers them); position i may be read once
+  // (int)(flags[seq_flag[i]] - seq_value[i]) >= 0 (seq_flag < 0: there when the launch starts); piece `own_index` lives at own_delta bytes
+  // from its slot in the gathered chunk (the rank's own blob is read where it was quantised, not copied).  A flag that does not come
+  // within timeout_ticks sets *err = 0x80000000 | position and the launch finishes on whatever the slot holds (csrc/attn7p.hip's rule).
+  const unsigned* flags;
+  unsigned* err;
+  unsigned long long timeout_ticks;
+  int64_t own_delta;
+  int own_index, n_seq;
+  int seq_piece[ICV_ATTN_MAX_PIECES];
+  int seq_flag[ICV_ATTN_MAX_PIECES];
+  unsigned seq_value[ICV_ATTN_MAX_PIECES];
 };
 
 __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
@@ -170,12 +183,12 @@ __device__ __forceinline__ i32x8 read32(const char* p0, const char* p1) {
   return (i32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-// VAR bit flags: 32 = software-pipelined key loop (S(t+1) and O += V(t-1)P(t-1) issued around tile t's softmax; implies 8), 64 = its row sums on
+// VAR bit flags: 256 = arrival-gated pieces (with 32), 32 = software-pipelined key loop (S(t+1) and O += V(t-1)P(t-1) issued around tile t's softmax; implies 8), 64 = its row sums on
 // packed adds, 1 = wave groups one tile apart, 4 = s_setprio(1) around MFMA clusters, 8 = lean vector work (LDS-DMA addresses as
 // scalar base + constant lane offset, row sums on packed fp32 adds)
 template <int VAR>
 __global__ __launch_bounds__(512) void attn8_kernel(Params p) {
-  constexpr bool STAGGER = VAR & 1, SETPRIO = VAR & 4, PIPE = VAR & 32, LEAN = (VAR & 8) || PIPE, PKADD = VAR & 64, PFD2 = VAR & 128;
+  constexpr bool STAGGER = VAR & 1, SETPRIO = VAR & 4, PIPE = VAR & 32, LEAN = (VAR & 8) || PIPE, PKADD = VAR & 64, PFD2 = VAR & 128, GATE = VAR & 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -244,6 +257,32 @@ __global__ __launch_bounds__(512) void attn8_kernel(Params p) {
   // recomputes them): ~10 scalar instructions per tile instead of ~50
   const unsigned char* kp_ = kh;
   const unsigned char* vp_ = p.vt + (int64_t)head * p.tpp * (D * KVB);
+  // GATE: byte offset of the piece at sequence position POS_ from piece 0, and the bounded wait for its arrival flag.  Every wave waits
+  // for itself (it issues its own share of a tile's requests); a wave that waits holds up nothing but the barrier two tiles on.
+#define A8_PIECE_OFF(POS_) \
+  (GATE ? (int64_t)p.seq_piece[(POS_)] * p.piece_stride + (p.seq_piece[(POS_)] == p.own_index ? p.own_delta : (int64_t)0) : (int64_t)(POS_) * p.piece_stride)
+#define A8_GATE(POS_)                                                                                                     \
+  if (GATE) {                                                                                                             \
+    const int fi_ = p.seq_flag[(POS_)];                                                                                   \
+    if (fi_ >= 0) {                                                                                                       \
+      const unsigned want_ = p.seq_value[(POS_)];                                                                         \
+      const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();                                                    \
+      while ((int)(__hip_atomic_load(p.flags + fi_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - want_) < 0) {          \
+        __builtin_amdgcn_s_sleep(16);                                                                                     \
+        if (p.err && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;                   \
+        if (p.timeout_ticks && __builtin_amdgcn_s_memrealtime() - t0_ > p.timeout_ticks) {                                \
+          if (p.err) atomicCAS(p.err, 0u, 0x80000000u | (unsigned)(POS_));                                                \
+          break;                                                                                                          \
+        }                                                                                                                 \
+      }                                                                                                                   \
+    }                                                                                                                     \
+  }
+  if (GATE) {
+    A8_GATE(0);
+    const int64_t off0 = A8_PIECE_OFF(0);
+    kp_ += off0;
+    vp_ += off0;
+  }
 #define A8_DMA_TILE(T_)                                                                              \
   if (PIPE) {                                                                                        \
     const unsigned l0_ = lds_base + (unsigned)(((T_) & (NSTAGE - 1)) * STAGE_BYTES + wave * 1024);   \
@@ -253,8 +292,10 @@ __global__ __launch_bounds__(512) void attn8_kernel(Params p) {
       if (d_tl + 1 == p.tpp) {                                                                       \
         d_tl = 0;                                                                                    \
         d_pc = d_pc + 1;                                                                             \
-        kp_ = kh + (int64_t)d_pc * p.piece_stride;                                                   \
-        vp_ = p.vt + (int64_t)d_pc * p.piece_stride + (int64_t)head * p.tpp * (D * KVB);             \
+        A8_GATE(d_pc);                                                                               \
+        const int64_t po_ = A8_PIECE_OFF(d_pc);                                                      \
+        kp_ = kh + po_;                                                                              \
+        vp_ = p.vt + po_ + (int64_t)head * p.tpp * (D * KVB);                                        \
       } else {                                                                                       \
         d_tl = d_tl + 1;                                                                             \
         kp_ += (int64_t)KVB * p.ldk;                                                                 \
@@ -628,8 +669,14 @@ extern "C" int icv_attention_fp8_prepare(const void* q, int64_t ldq, const void*
 
 static int attn8_run(const void* qq, int64_t ldqq, const void* kq, int64_t ldkq, const void* vt, const float* amax, void* o,
                      int64_t ldo, float* acc, int64_t ldacc, float* ml, int state_in, int state_out, int64_t Sq, int64_t piece_rows,
-                     int64_t n_pieces, int64_t piece_stride, int64_t heads, hipStream_t st) {
+                     int64_t n_pieces, int64_t piece_stride, int64_t heads, hipStream_t st, const att8::Params* gate = nullptr) {
   att8::Params p;
+  p.flags = nullptr; p.err = nullptr; p.timeout_ticks = 0; p.own_delta = 0; p.own_index = -1; p.n_seq = 0;
+  if (gate) {
+    p.flags = gate->flags; p.err = gate->err; p.timeout_ticks = gate->timeout_ticks; p.own_delta = gate->own_delta; p.own_index = gate->own_index;
+    p.n_seq = gate->n_seq;
+    for (int i = 0; i < gate->n_seq; ++i) { p.seq_piece[i] = gate->seq_piece[i]; p.seq_flag[i] = gate->seq_flag[i]; p.seq_value[i] = gate->seq_value[i]; }
+  }
   const int64_t Skv = piece_rows * n_pieces;
   p.q = (const unsigned char*)qq; p.ldq = ldqq; p.k = (const unsigned char*)kq; p.ldk = ldkq; p.vt = (const unsigned char*)vt;
   p.amax = amax; p.Sq = Sq; p.Skv = Skv; p.heads = (int)heads;
@@ -646,6 +693,7 @@ static int attn8_run(const void* qq, int64_t ldqq, const void* kq, int64_t ldkq,
   // default (-1) = 164: the software-pipelined loop, fragment reads two segments ahead, s_setprio(1) over the pipelined block
   // (+10...12 % over round 5's loop = variant 0 at S = 37 440 / 86 400, +4 % at 512 text keys, bit-identical outputs:
   // profiles/r06/attn8_pipelined_ab.txt)
+  if (gate) return att8::launch<164 | 256>(p, st);
   int variant = icv_get_option_int("attn8_variant", -1);
   if (variant < 0) variant = 164;
   switch (variant) {
@@ -741,4 +789,44 @@ extern "C" int icv_attention_fp8_fwd_pieces(const void* qq, int64_t ldqq, const 
   const unsigned char* kq = (const unsigned char*)blobs;
   return attn8_run(qq, ldqq, kq, ldkq, kq + rp * ldkq, amax, o, ldo, acc, ldacc, ml, first ? 0 : 1, last ? 0 : 1, Sq, piece_rows, n_pieces,
                    icv_attention_fp8_blob_bytes(piece_rows, heads), heads, (hipStream_t)stream);
+}
+
+// The same over pieces that may still be ARRIVING (the sequence-parallel schedule of SURVEY.md §8e for the e4m3 wire format: "process K/V
+// chunks in arrival order (own shard first)"): the launch does not wait for the chunk's exchange on the host; it walks the blobs in the
+// order seq_piece[0..n_pieces) and every position gates, inside the kernel, on its arrival flag (seq_flag[i] < 0: present at launch) -
+// the words the copy-engine transport raises per peer (icv_ipc_arrival) or the one a side stream writes behind a collective
+// (icv_flag_write).  `own_blob` (may be NULL): the blob of piece `own_index` is read THERE instead of from its slot in `blobs`.
+// seq_* are host arrays.  Time-out / error word: icv_attention_fwd_pieces' rule.
+extern "C" int icv_attention_fp8_fwd_pieces_gated(const void* qq, int64_t ldqq, const void* blobs, int64_t piece_rows, int64_t n_pieces,
+                                                  const void* own_blob, int64_t own_index, const int32_t* seq_piece, const int32_t* seq_flag,
+                                                  const uint32_t* seq_value, const uint32_t* flags, uint32_t* err, int64_t timeout_us,
+                                                  const float* amax, void* o, int64_t ldo, float* acc, int64_t ldacc, float* ml, int64_t Sq,
+                                                  int64_t heads, int first, int last, void* stream) {
+  ICV_REQUIRE(qq && blobs && amax && seq_piece && seq_flag && seq_value, "icv_attention_fp8_fwd_pieces_gated: null pointer");
+  ICV_REQUIRE(Sq > 0 && piece_rows > 0 && n_pieces > 0 && n_pieces <= ICV_ATTN_MAX_PIECES && heads > 0,
+              "icv_attention_fp8_fwd_pieces_gated: empty problem or more than %d pieces", ICV_ATTN_MAX_PIECES);
+  ICV_REQUIRE(ldqq % 16 == 0, "icv_attention_fp8_fwd_pieces_gated: leading dims must keep 16-byte row alignment");
+  ICV_REQUIRE((first && last) || (acc && ml && ldacc % 4 == 0), "icv_attention_fp8_fwd_pieces_gated: carried state buffers required unless first && last");
+  ICV_REQUIRE(!last || (o && ldo % 4 == 0), "icv_attention_fp8_fwd_pieces_gated: output required for the last chunk");
+  ICV_REQUIRE(!own_blob || (own_index >= 0 && own_index < n_pieces && (uintptr_t)own_blob % 16 == 0), "icv_attention_fp8_fwd_pieces_gated: bad own blob");
+  const int64_t rp = (piece_rows + att8::KVB - 1) / att8::KVB * att8::KVB;
+  const int64_t ldkq = heads * att8::D;
+  const int64_t stride = icv_attention_fp8_blob_bytes(piece_rows, heads);
+  const unsigned char* kq = (const unsigned char*)blobs;
+  att8::Params g;
+  g.flags = flags; g.err = err; g.timeout_ticks = timeout_us > 0 ? (unsigned long long)timeout_us * 100ull : 0ull;
+  g.own_index = own_blob ? (int)own_index : -1;
+  g.own_delta = own_blob ? (int64_t)((const unsigned char*)own_blob - (kq + own_index * stride)) : 0;
+  g.n_seq = (int)n_pieces;
+  unsigned long long seen = 0;
+  for (int64_t i = 0; i < n_pieces; ++i) {
+    ICV_REQUIRE(seq_piece[i] >= 0 && seq_piece[i] < n_pieces && !((seen >> seq_piece[i]) & 1ull),
+                "icv_attention_fp8_fwd_pieces_gated: seq_piece is not a permutation of the pieces");
+    ICV_REQUIRE(seq_flag[i] < 0 || flags, "icv_attention_fp8_fwd_pieces_gated: position %lld waits for flag %d but no flag array was given", (long long)i,
+                seq_flag[i]);
+    seen |= 1ull << seq_piece[i];
+    g.seq_piece[i] = seq_piece[i]; g.seq_flag[i] = seq_flag[i]; g.seq_value[i] = seq_value[i];
+  }
+  return attn8_run(qq, ldqq, kq, ldkq, kq + rp * ldkq, amax, o, ldo, acc, ldacc, ml, first ? 0 : 1, last ? 0 : 1, Sq, piece_rows, n_pieces, stride, heads,
+                   (hipStream_t)stream, &g);
 }

@@ -47,6 +47,7 @@ SIGNATURES = {
     "icv_attention_fp8_kv_amax": (c_int, [_P, _I, _P, _I, _I, _I, _P, _P]),
     "icv_attention_fp8_quantize_kv": (c_int, [_P, _I, _P, _I, _I, _I, _P, _P, _P]),
     "icv_attention_fp8_fwd_pieces": (c_int, [_P, _I, _P, _I, _I, _P, _P, _I, _P, _I, _P, _I, _I, c_int, c_int, _P]),
+    "icv_attention_fp8_fwd_pieces_gated": (c_int, [_P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, c_int, c_int, _P]),
     "icv_attention_trace": (c_int, [_P, _I]),
     "icv_attention_fwd_chunk": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _F, c_int, c_int, _P]),
     "icv_patchify": (c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
@@ -116,7 +117,7 @@ ATTN_MAX_PIECES = 64   # ICV_ATTN_MAX_PIECES
 COMM_ID_BYTES = 128   # ICV_COMM_ID_BYTES
 IPC_HANDLE_BYTES = 72  # ICV_IPC_HANDLE_BYTES
 IPC_SLOTS = 32         # ICV_IPC_SLOTS
-ABI_VERSION = 4       # ICV_ABI_VERSION of include/icvideo.h
+ABI_VERSION = 5       # ICV_ABI_VERSION of include/icvideo.h
 
 _lib: Optional[ctypes.CDLL] = None
 

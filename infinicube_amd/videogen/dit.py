@@ -331,8 +331,7 @@ class WanDiT:
             self.sp_bounds = chunk_bounds(n, sp_chunks, self.sp_align)
             # e4m3 attention under sequence parallelism: ship e4m3 K|V (each rank quantises its own rows once) instead of bf16
             # rows that every rank re-quantises (ICV_FP8_WIRE=bf16 restores that order of operations)
-            self.fp8_wire = (self.attn_fp8 and os.environ.get("ICV_FP8_WIRE", "e4m3") == "e4m3" and hasattr(ops, "attention_fp8_quantize_kv")
-                             and hasattr(self.kv_gather, "allreduce_max"))
+            self.fp8_wire = self._fp8_wire_wanted()
             self._sp_local_rows()                                  # kv_loc: local k | v rows (one exchange moves both)
             self.kv_full = a((self.plan.world * n, 2 * d), BF16)   # gathered rows (chunk-major, rank-major inside)
             self.sp_acc = a((n, d), F32)                           # carried O accumulator between key chunks
@@ -376,11 +375,18 @@ class WanDiT:
         d = self.cfg.dim
         return (rows(tot8, d, torch.uint8), self.ops.alloc((self.plan.world * tot8, d), torch.uint8), self.ops.alloc((3, self.cfg.num_heads), F32))
 
+    def _fp8_wire_wanted(self) -> bool:
+        return bool(self.attn_fp8 and os.environ.get("ICV_FP8_WIRE", "e4m3") == "e4m3" and hasattr(self.ops, "attention_fp8_quantize_kv")
+                    and hasattr(self.kv_gather, "allreduce_max"))
+
     def _sp_set_arrival(self, want: bool):
-        """Arrival-driven self-attention (csrc/attn7p.hip): bf16 attention on an operator set that has the kernel.  The
-        e4m3 mode keeps the chunked launches (its pieces kernel has no arrival gate)."""
+        """Arrival-driven self-attention.  bf16: ONE launch per layer over all pieces (csrc/attn7p.hip).  e4m3 mode with the
+        e4m3 wire format: the chunk launches stay (a chunk's blobs have one size, the chunks of the ramp do not), but each of them gates on
+        its pieces' arrival flags inside the kernel instead of the host waiting for the chunk's whole exchange
+        (icv_attention_fp8_fwd_pieces_gated); e4m3 attention over bf16 rows on the wire keeps the host waits."""
         ops = self.ops
-        self.attn_arrival = bool(want) and not self.attn_fp8 and hasattr(ops, "attention_pieces") and hasattr(self.kv_gather, "enable_arrival")
+        self.attn_arrival = (bool(want) and hasattr(ops, "attention_pieces") and hasattr(self.kv_gather, "enable_arrival")
+                             and (not self.attn_fp8 or self._fp8_wire_wanted()))
         self.sp_align = 64 if self.attn_arrival else 1
         self.sp_err = None
         if self.attn_arrival:
@@ -579,7 +585,7 @@ class WanDiT:
                 if start:
                     self.ops.attention_fp8_quantize_kv(kv_loc[r0:r1, :d], kv_loc[r0:r1, d:], H, amax, blob.view(-1))
                 full = full8[world * off8: world * (off8 + rows8)]
-                bufs.append((full, r1 - r0, amax))
+                bufs.append((full, r1 - r0, amax, blob))
                 handles.append(self.kv_gather.start(blob, full) if start else ())
             return handles, bufs
         kv_full = self.kv_full if kv_full is None else kv_full
@@ -599,7 +605,7 @@ class WanDiT:
         ops = self.ops
         att = self.att if att is None else att
         C = len(bufs)
-        if getattr(self, "attn_arrival", False):
+        if getattr(self, "attn_arrival", False) and not getattr(self, "fp8_wire", False):
             # ONE launch over the pieces: this rank's own rows (in place, no flag) first, then every (row chunk, peer) in the order the
             # exchange delivers them - chunk-major, peers starting with the right-hand neighbour (the order the pulls are issued in)
             d, kg, world, rank = self.cfg.dim, self.kv_gather, self.plan.world, self.plan.rank
@@ -622,13 +628,24 @@ class WanDiT:
             if wire:
                 ws = ops.attention_fp8_with_amax(ws, bufs[0][2])     # this branch's abs-max table (queries' row written here)
             ops.attention_fp8_prepare(ws, H, q=q)                       # queries once per layer, under the first transfer
+        gated = wire and getattr(self, "attn_arrival", False)
         for c in range(C):
-            if not from_memory:
+            if not from_memory and not gated:
                 self.kv_gather.wait(handles[c])
             if wire:
-                full, m, amax = bufs[c]
+                full, m, amax, own_blob = bufs[c]
+                gate = None
+                if gated:
+                    # the chunk's launch starts NOW: this rank's blob first (read where it was quantised), then the peers' in the order the
+                    # pulls were issued, each behind its arrival flag inside the kernel
+                    kg, world, rank = self.kv_gather, self.plan.world, self.plan.rank
+                    fl, entries = (None, [(j, -1, 0) for j in range(world) if j != rank]) if from_memory else kg.arrival(handles[c])
+                    seq = [(rank, -1, 0)] + [(j, idx if fl is not None else -1, val) for j, idx, val in sorted(entries, key=lambda e: (e[0] - rank) % world)]
+                    gate = dict(seq=seq, flags=fl, own=(own_blob.view(-1), rank), err=self.sp_err, timeout_us=self.sp_timeout_us)
                 ops.attention_fp8_pieces(ws, amax, full.view(-1), m, self.plan.world, q.shape[0], att, self.sp_acc, self.sp_ml, H,
-                                         first=(c == 0), last=(c == C - 1))
+                                         first=(c == 0), last=(c == C - 1), gate=gate)
+                if gated and not from_memory:
+                    self.kv_gather.consumed(handles[c])
             elif ws is not None:
                 ops.attention_fp8_prepare(ws, H, k=bufs[c][0], v=bufs[c][1])
                 ops.attention_fp8_chunk(ws, q.shape[0], bufs[c][0].shape[0], att, self.sp_acc, self.sp_ml, H,

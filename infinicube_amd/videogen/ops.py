@@ -281,11 +281,31 @@ class HipOps:
         native.check(self.lib.icv_attention_fp8_quantize_kv(k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), k.shape[0], heads, amax.data_ptr(),
                                                             blob.data_ptr(), self._stream()), "icv_attention_fp8_quantize_kv")
 
-    def attention_fp8_pieces(self, ws, amax, blobs, piece_rows: int, n_pieces: int, Sq: int, o, acc, ml, heads: int, first: bool, last: bool):
+    def attention_fp8_pieces(self, ws, amax, blobs, piece_rows: int, n_pieces: int, Sq: int, o, acc, ml, heads: int, first: bool, last: bool, gate=None):
         """fp8 attention of the prepared queries (ws) over ``n_pieces`` blobs back to back (the gathered chunk), carried state as
-        attention_chunk."""
+        attention_chunk.  ``gate`` (arrival-driven, icv_attention_fp8_fwd_pieces_gated): dict(seq=[(piece, flag, value), ...] - the order in
+        which the pieces are walked, this rank's own first; flag < 0 = there now, else readable once (int32)(flags[flag] - value) >= 0 -,
+        flags=device words, own=(uint8 tensor, index) or None: that piece is read from the tensor instead of its slot in ``blobs``,
+        err=int32 device word or None, timeout_us)."""
         qq = ws[0]
         assert blobs.dtype == torch.uint8 and blobs.is_contiguous() and blobs.numel() >= n_pieces * self.attention_fp8_blob_bytes(piece_rows, heads)
+        if gate is not None:
+            seq = gate["seq"]
+            assert len(seq) == n_pieces
+            sp = (ctypes.c_int32 * n_pieces)(*[int(e[0]) for e in seq])
+            sf = (ctypes.c_int32 * n_pieces)(*[int(e[1]) for e in seq])
+            sv = (ctypes.c_uint32 * n_pieces)(*[int(e[2]) & 0xffffffff for e in seq])
+            own = gate.get("own")
+            own_t, own_i = own if own is not None else (None, -1)
+            if own_t is not None:
+                assert own_t.dtype == torch.uint8 and own_t.is_contiguous() and own_t.numel() >= self.attention_fp8_blob_bytes(piece_rows, heads)
+            native.check(self.lib.icv_attention_fp8_fwd_pieces_gated(
+                qq.data_ptr(), qq.stride(0), blobs.data_ptr(), piece_rows, n_pieces, native.ptr(own_t), int(own_i), ctypes.cast(sp, ctypes.c_void_p),
+                ctypes.cast(sf, ctypes.c_void_p), ctypes.cast(sv, ctypes.c_void_p), native.ptr(gate.get("flags")), native.ptr(gate.get("err")),
+                int(gate.get("timeout_us", 0)), amax.data_ptr(), native.ptr(o), o.stride(0) if o is not None else 0, native.ptr(acc),
+                acc.stride(0) if acc is not None else 0, native.ptr(ml), Sq, heads, int(first), int(last), self._stream()),
+                "icv_attention_fp8_fwd_pieces_gated")
+            return
         native.check(self.lib.icv_attention_fp8_fwd_pieces(
             qq.data_ptr(), qq.stride(0), blobs.data_ptr(), piece_rows, n_pieces, amax.data_ptr(), native.ptr(o), o.stride(0) if o is not None else 0,
             native.ptr(acc), acc.stride(0) if acc is not None else 0, native.ptr(ml), Sq, heads, int(first), int(last), self._stream()),

@@ -174,12 +174,14 @@ class OracleOps:
             q8 = (x.float().reshape(m, heads, -1) * torch.exp2(-e)[None, :, None]).to(FP8).reshape(m, d)
             blob[part * mp * d: part * mp * d + m * d] = q8.view(torch.uint8).reshape(-1)
 
-    def attention_fp8_pieces(self, ws, amax, blobs, piece_rows, n_pieces, Sq, o, acc, ml, heads, first, last):
+    def attention_fp8_pieces(self, ws, amax, blobs, piece_rows, n_pieces, Sq, o, acc, ml, heads, first, last, gate=None):
         d = heads * 128
         mp = (piece_rows + 63) // 64 * 64
         ks, vs = [], []
-        for i in range(n_pieces):
-            b = blobs.reshape(-1)[i * 2 * mp * d: (i + 1) * 2 * mp * d]
+        order = [e[0] for e in gate["seq"]] if gate is not None else list(range(n_pieces))      # CPU twin: the rows are there (the host waited)
+        own_t, own_i = (gate.get("own") or (None, -1)) if gate is not None else (None, -1)
+        for i in order:
+            b = own_t.reshape(-1)[: 2 * mp * d] if (own_t is not None and i == own_i) else blobs.reshape(-1)[i * 2 * mp * d: (i + 1) * 2 * mp * d]
             for part, (row, dst) in enumerate(((1, ks), (2, vs))):
                 x8 = b[part * mp * d: part * mp * d + piece_rows * d].view(FP8).float().reshape(piece_rows, heads, -1)
                 dst.append((x8 * torch.exp2(self._exp(amax[row]))[None, :, None]).reshape(piece_rows, d))

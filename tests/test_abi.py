@@ -26,7 +26,7 @@ def test_header_symbols_exported_and_bound():
 
 def test_lib_loads_and_reports_version():
     lib = native.lib()
-    assert lib.icv_abi_version() == native.ABI_VERSION == 4
+    assert lib.icv_abi_version() == native.ABI_VERSION == 5
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "icvideo.h")).read()
     assert f"#define ICV_ABI_VERSION {native.ABI_VERSION}" in hdr, "binding and header disagree on the ABI version"
     assert isinstance(lib.icv_last_error(), bytes)

@@ -341,6 +341,35 @@ def test_arrival_driven_attention_one_rank_rehearsal(hip_ops, mode):
     assert torch.isfinite(b).all() and torch.equal(a, b), f"arrival-driven vs one chunked launch: max |d| {float((a - b).abs().max())}"
 
 
+@pytest.mark.parametrize("mode", ["ipc+arrival", "allgather+arrival"])
+def test_arrival_gated_e4m3_chunks_one_rank_rehearsal(hip_ops, mode):
+    """The e4m3 mode of the arrival-driven schedule on one rank: every chunk launch gates on its blobs inside the kernel
+    (icv_attention_fp8_fwd_pieces_gated) and reads this rank's own blob where it was quantised.  One rank = one piece per chunk in the
+    same order, so the loop must be BIT-IDENTICAL to the host-waited chunk launches when both arms cut the same chunk bounds (the gated
+    arm cuts on the 64-key grid); otherwise the two differ by the re-association of the fp32 sums only."""
+    grid = TokenGrid(9, 64, 96)
+    cfg, sd, bsd, _, _ = _setup("tiny", grid)
+    noise, c1, c2, bl = syn.make_latent_noise(grid), syn.make_text_context(cfg, 1), syn.make_text_context(cfg, 2), syn.make_buffer_latents(cfg, grid)
+    lats = {}
+    for kv in (mode.split("+")[0], mode):
+        m = WanDiT(cfg, sd, hip_ops, bsd, gemm_dtype="fp8", attn_dtype="fp8").prepare(grid, force_sp=True, kv_exchange=kv, sp_chunks=3)
+        assert m.sp_on and m.fp8_wire and m.attn_arrival == kv.endswith("+arrival")
+        lat = noise.clone().to("cuda:0")
+        m.denoise(lat, m.encode_context(c1), m.encode_context(c2), m.embed_buffers(bl), FlowMatchScheduler(12), 5.0)
+        torch.cuda.synchronize()
+        lats[kv] = (lat.clone(), list(m.sp_bounds))
+        if m.attn_arrival:
+            assert int(m.sp_err.item()) == 0
+            m.check_exchange()
+        m.kv_gather.close()
+    (a, ba), (b, bb) = lats[mode.split("+")[0]], lats[mode]
+    assert torch.isfinite(b).all()
+    if ba == bb:
+        assert torch.equal(a, b), f"gated vs host-waited chunk launches: max |d| {float((a - b).abs().max())}"
+    else:                                          # different chunk bounds re-associate the fp32 sums
+        assert R.psnr(b.cpu(), a.cpu()) >= 50.0, f"gated vs host-waited chunk launches (other chunk bounds {bb} vs {ba}): {R.psnr(b.cpu(), a.cpu()):.1f} dB"
+
+
 def test_copy_engine_transport_refuses_misuse(hip_ops):
     """icv_ipc_* error paths on one rank: rows outside the symmetric heap, a heap that is too small for what is carved from it,
     more than ICV_IPC_SLOTS exchanges without a wait, a wait for a ticket that is not in flight - each a clean error, not a hang."""

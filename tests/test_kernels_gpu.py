@@ -956,6 +956,93 @@ def test_attention_fp8_pieces_e4m3_on_the_wire(hip_ops, Sq, m, W, H):
         assert e3 <= 0.02, f"two chunks of pieces vs one: {e3:.4f}"
 
 
+@pytest.mark.parametrize("Sq,m,W,H,own", [(300, 128, 4, 2, 1), (130, 100, 3, 2, 0), (520, 585, 8, 1, 5)])
+def test_attention_fp8_pieces_gated_by_arrival_flags(hip_ops, Sq, m, W, H, own):
+    """icv_attention_fp8_fwd_pieces_gated (round 6: the arrival-driven schedule for the e4m3 wire format).  (a) identity order, no flag,
+    no separate own blob = the ungated launch bit for bit; (b) this rank's blob read from its own tensor (its slot in the gathered chunk
+    holds NaN bytes) and the peers walked in pull order: the fp8 bars against the oracle; (c) two peers' blobs are NaN bytes when the
+    launch starts and a side stream delivers them - copy, then flag - one at once, one 2 ms later: bit-identical to (b), nobody timed
+    out; (d) a flag that never comes: the launch returns after the time-out with the position in the error word."""
+    d, Skv = H * 128, m * W
+    fold = (1.0 / math.sqrt(128)) * math.log2(math.e)
+    q = rnd((Sq, d), 641).to(torch.bfloat16)
+    kf = rnd((Skv, d), 642)
+    kf[Skv - 1] = q[min(3, Sq - 1)].float() * 3.0
+    k = (kf * fold).to(torch.bfloat16)
+    v = (rnd((Skv, d), 643) * torch.linspace(0.5, 2.0, d)[None, :]).to(torch.bfloat16)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    ws = hip_ops.attention_fp8_buffers(Sq, Skv, d, H)
+    amax = torch.zeros((3, H), device=DEV)
+    hip_ops.attention_fp8_kv_amax(kd, vd, H, amax)
+    bb = hip_ops.attention_fp8_blob_bytes(m, H)
+    blobs = torch.empty((W * bb,), dtype=torch.uint8, device=DEV)
+    for i in range(W):
+        hip_ops.attention_fp8_quantize_kv(kd[i * m:(i + 1) * m], vd[i * m:(i + 1) * m], H, amax, blobs[i * bb:(i + 1) * bb])
+    ws2 = hip_ops.attention_fp8_with_amax(ws, amax)
+    hip_ops.attention_fp8_prepare(ws2, H, q=qd)
+
+    def launch(bl, gate):
+        o = torch.zeros((Sq, d), dtype=torch.bfloat16, device=DEV)
+        hip_ops.attention_fp8_pieces(ws2, amax, bl, m, W, Sq, o, None, None, H, first=True, last=True, gate=gate)
+        return o
+
+    o_plain = launch(blobs, None)
+    o_a = launch(blobs, dict(seq=[(i, -1, 0) for i in range(W)]))
+    assert torch.equal(o_a, o_plain), "(a) identity order without flags differs from the ungated launch"
+    # (b) own blob elsewhere, pull order
+    own_blob = blobs[own * bb:(own + 1) * bb].clone()
+    staged = blobs.clone()
+    poisoned = blobs.clone()
+    poisoned[own * bb:(own + 1) * bb] = 0x7F                      # e4m3 NaN: reading the slot would show
+    order = [own] + [(own + j) % W for j in range(1, W)]
+    o_b = launch(poisoned, dict(seq=[(i, -1, 0) for i in order], own=(own_blob, own)))
+    got = o_b.float().cpu()
+    assert torch.isfinite(got).all(), "(b) the own piece was read from its slot in the gathered chunk"
+    ref8 = R.attention_fp8(q.float(), k.float(), v.float(), H)
+    ref = R.attention(q.float(), k.float(), v.float(), H, scale=math.log(2.0))
+    rms = float(ref.pow(2).mean().sqrt())
+    e8 = float((got - ref8).pow(2).mean().sqrt()) / rms
+    e0 = float((got - ref).pow(2).mean().sqrt()) / rms
+    assert e8 <= 0.03 and e0 <= 0.08, f"(b) gated fp8 pieces Sq={Sq} m={m} W={W}: rms err vs fp8 oracle {e8:.4f}, vs unquantised {e0:.4f}"
+    if W >= 3:
+        # (c) late peers
+        early, late = order[1], order[2]
+        flags = torch.zeros((8,), dtype=torch.int32, device=DEV)
+        err = torch.zeros((1,), dtype=torch.int32, device=DEV)
+        mark = torch.zeros((2,), dtype=torch.int32, device=DEV)
+        side = torch.cuda.Stream(device=DEV)
+        for value in (3, 4):                                     # twice: the first pass pays the side stream's first-use costs
+            for i in (early, late):
+                poisoned[i * bb:(i + 1) * bb] = 0x7F
+            torch.cuda.synchronize()
+            seq = [(i, {early: 1, late: 2}.get(i, -1), value if i in (early, late) else 0) for i in order]
+            o_c = torch.zeros((Sq, d), dtype=torch.bfloat16, device=DEV)
+            hip_ops.attention_fp8_pieces(ws2, amax, poisoned, m, W, Sq, o_c, None, None, H, first=True, last=True,
+                                         gate=dict(seq=seq, flags=flags, own=(own_blob, own), err=err, timeout_us=5_000_000))
+            with torch.cuda.stream(side):
+                poisoned[early * bb:(early + 1) * bb].copy_(staged[early * bb:(early + 1) * bb])
+                hip_ops.flag_write(flags, 1, value)
+                hip_ops.flag_write(mark, 0, 1, delay_us=2000)      # hold the stream: the late peer
+                poisoned[late * bb:(late + 1) * bb].copy_(staged[late * bb:(late + 1) * bb])
+                hip_ops.flag_write(flags, 2, value)
+            torch.cuda.synchronize()
+        assert int(err.item()) == 0, f"(c) a wave gave up waiting: err word {int(err.item()) & 0xffffffff:#x}"
+        assert torch.isfinite(o_c.float()).all(), "(c) a blob was read before it landed"
+        assert torch.equal(o_c, o_b), "(c) late blobs: result differs from the all-present launch in the same order"
+        # (d) a flag that never comes
+        import time
+        err.zero_()
+        seq = [(i, 5 if i == late else -1, 9 if i == late else 0) for i in order]
+        torch.cuda.synchronize()
+        t0 = time.time()
+        hip_ops.attention_fp8_pieces(ws2, amax, poisoned, m, W, Sq, o_c, None, None, H, first=True, last=True,
+                                     gate=dict(seq=seq, flags=flags, own=(own_blob, own), err=err, timeout_us=50_000))
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        assert (int(err.item()) & 0xffffffff) == (0x80000000 | order.index(late)), f"(d) error word {int(err.item()) & 0xffffffff:#x}"
+        assert dt < 2.0, f"(d) the bounded wait took {dt:.2f} s"
+
+
 @pytest.mark.parametrize("Sq,Skv,H", [(300, 257, 2), (1, 1, 1), (513, 64, 3)])
 def test_attention_add_into_output(hip_ops, Sq, Skv, H):
     """icv_attention_fwd_add: o += softmax(q k^T) v (the i2v image cross-attention; 257 = CLIP tokens)."""

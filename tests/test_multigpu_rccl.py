@@ -402,13 +402,15 @@ def test_shared_gpu_fp8_mode_cfg_sp_subgroups(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kv_exchange", ["allgather", "ipc"])
+@pytest.mark.parametrize("kv_exchange", ["allgather", "ipc", "ipc+arrival", "allgather+arrival"])
 def test_shared_gpu_fp8_mode_e4m3_on_the_wire(tmp_path, kv_exchange):
     """Config #5's kernels on the sharded path between real processes (2 ranks sharing the GPU): every rank quantises its own K|V
     rows once with the group's per-head scales (one max-reduce per layer), the exchange moves e4m3 blobs - over the collective
     and over the copy-engine transport - and icv_attention_fp8_fwd_pieces consumes them in place.  The scales are those of the
     unsharded launch, so the 2-rank result differs from the 1-GPU fp8 result by the softmax merge order only (bar: the bf16
-    path's), not by a second quantisation as in rounds 2-4 (bar then: rel-L2 6e-2 / 30 dB)."""
+    path's), not by a second quantisation as in rounds 2-4 (bar then: rel-L2 6e-2 / 30 dB).
+    "+arrival" (round 6): every chunk's launch starts without a host-side wait and gates on its blobs' arrival flags inside the kernel
+    (icv_attention_fp8_fwd_pieces_gated), this rank's own blob read where it was quantised."""
     args = GPU_TINY[2:] + ["--scenario", "loop", "--gemm-dtype", "fp8", "--attn-dtype", "fp8"]
     ref = run_ranks(1, str(tmp_path / "single.pt"), ["--backend", "nccl"] + args)
     got = run_ranks(2, str(tmp_path / "multi.pt"), ["--backend", "gloo", "--share-gpu"] + args + ["--parallelism", "sp", "--kv-exchange", kv_exchange])
