@@ -239,7 +239,7 @@ def test_one_rank_rehearsal_of_the_sequence_parallel_schedule():
     assert float((lats[0] - lats[1]).norm() / lats[0].norm()) < 1e-5
 
 
-def _sp_worker(rank, world, port, q, kv_exchange="allgather"):
+def _sp_worker(rank, world, port, q, kv_exchange="allgather", fp8=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -247,9 +247,10 @@ def _sp_worker(rank, world, port, q, kv_exchange="allgather"):
         torch.set_num_threads(2)
         sd, bsd, noise, c1, c2, bl = _inputs()
         plan = ShardPlan.make(GRID.S, world, rank)
-        m = WanDiT(CFG, sd, OracleOps(), bsd).prepare(GRID, plan, kv_exchange=kv_exchange)
+        kw = dict(gemm_dtype="fp8", attn_dtype="fp8", fp8_weights=WanDiT.FP8_WEIGHTS) if fp8 else {}
+        m = WanDiT(CFG, sd, OracleOps(), bsd, **kw).prepare(GRID, plan, kv_exchange=kv_exchange)
         assert isinstance(m.kv_gather, KVGather) and m.kv_gather.mode == kv_exchange.split("+")[0]
-        assert m.attn_arrival == kv_exchange.endswith("+arrival")
+        assert m.attn_arrival == kv_exchange.endswith("+arrival") and bool(getattr(m, "fp8_wire", False)) == fp8
         lat = noise.clone()
         m.denoise(lat, m.encode_context(c1), m.encode_context(c2), m.embed_buffers(bl), FlowMatchScheduler(3), 5.0)
         lat = gather_latent(lat, plan, GRID)
@@ -281,6 +282,30 @@ def test_gloo_world2_sequence_parallel_equals_single(kv_exchange):
     # vs the single-process run: same math per token, but CPU GEMM blocking differs with the row count,
     # and a 1e-7 difference can flip a bf16 storage rounding -> compare to rounding, not bitwise
     assert float((got[0] - ref).norm() / ref.norm()) < 2e-3 and R.psnr(got[0], ref) > 55.0
+
+
+def test_gloo_world2_e4m3_wire_arrival_gated_chunks_host_logic():
+    """The e4m3 mode of the sequence-parallel loop over two real processes (CPU twins of the kernels): e4m3 blobs on the wire, the chunk
+    launches host-waited (`allgather`) vs handed their pieces in pull order with the rank's own blob separate (`allgather+arrival`: the
+    routing of icv_attention_fp8_fwd_pieces_gated; on the CPU the rows are simply there).  Same blobs, same scales: the two differ by the
+    order in which a chunk's pieces enter the softmax only."""
+    ctx = mp.get_context("spawn")
+    lats = {}
+    for kv_exchange in ("allgather", "allgather+arrival"):
+        q = ctx.Queue()
+        port = 29500 + (os.getpid() + 7 * len(kv_exchange) + 101) % 2000
+        procs = [ctx.Process(target=_sp_worker, args=(r, 2, port, q, kv_exchange, True)) for r in range(2)]
+        for p in procs:
+            p.start()
+        got = dict(q.get(timeout=300) for _ in range(2))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert torch.equal(got[0], got[1])
+        lats[kv_exchange] = got[0]
+    a, b = lats["allgather"], lats["allgather+arrival"]
+    assert torch.isfinite(b).all() and float((a - b).norm() / a.norm()) < 2e-2 and R.psnr(b, a) > 40.0, \
+        f"gated vs host-waited e4m3 chunk launches: rel-L2 {float((a - b).norm() / a.norm())}"
 
 
 def test_parallel_layout_arithmetic():
