@@ -236,7 +236,10 @@ class KVGather:
         elif self.plan.world > 1 and torch.device(ops.device).type == "cuda":
             self._flags = ops.alloc((self.ARRIVAL_SLOTS,), torch.int32)
             self._flags.zero_()
-            self._flag_stream = torch.cuda.Stream(device=ops.device)
+            # HIGH priority = its own class of hardware queues: a stream of the default class can share a hardware queue with the compute stream
+            # (GPU_MAX_HW_QUEUES, default 4; every 4th stream of torch's pool does), and then the attention launch that waits for this
+            # stream's flag keeps the flag's writer from starting - a deterministic time-out (profiles/r06/stream_queue_share_probe.txt)
+            self._flag_stream = torch.cuda.Stream(device=ops.device, priority=-1)
 
     def arrival(self, handle):
         """(flags, [(peer index j, flag index, value), ...]) for the peers' rows of this row-chunk (own rows excluded: in place);

@@ -106,7 +106,7 @@ def test_rows_that_land_after_the_launch_started(hip_ops, Sq, H, late_ms):
     nwg = H * ((Sq + 255) // 256)
     trace = torch.zeros((nwg, 4), dtype=torch.int64, device=DEV)
     mark = torch.zeros((2,), dtype=torch.int64, device=DEV)
-    side = torch.cuda.Stream(device=DEV)
+    side = torch.cuda.Stream(device=DEV, priority=-1)       # its own hardware-queue class: a default-class stream can share the launch's queue and never run (profiles/r06/stream_queue_share_probe.txt)
     o = torch.zeros_like(want)
     for value in (7, 8):          # twice: the first pass pays the side stream's first-use costs (its queue, the copy kernels' module load)
         kv[bounds[1]:bounds[3]] = float("nan")

@@ -1010,7 +1010,7 @@ def test_attention_fp8_pieces_gated_by_arrival_flags(hip_ops, Sq, m, W, H, own):
         flags = torch.zeros((8,), dtype=torch.int32, device=DEV)
         err = torch.zeros((1,), dtype=torch.int32, device=DEV)
         mark = torch.zeros((2,), dtype=torch.int32, device=DEV)
-        side = torch.cuda.Stream(device=DEV)
+        side = torch.cuda.Stream(device=DEV, priority=-1)       # its own hardware-queue class: a default-class stream can share the launch's queue and never run (profiles/r06/stream_queue_share_probe.txt)
         for value in (3, 4):                                     # twice: the first pass pays the side stream's first-use costs
             for i in (early, late):
                 poisoned[i * bb:(i + 1) * bb] = 0x7F

@@ -2,7 +2,7 @@
 # FIRST CONTACT WITH AN N-GPU NODE, in one go.  Every multi-GPU statement of this repo so far comes from gloo
 # multi-process runs on CPU, N processes sharing one GPU and one-GPU rehearsals: RCCL / SDMA have never carried a K|V row over xGMI.
 # This script produces, under profiles/<round>/ (default r06), everything a reader needs to judge the first real run:
-#   first_contact_bench_n<N>_{auto,sp}.json      python bench.py --gpus N: ONE JSON line each - the plan that ran (multi_gpu.plan,
+#   first_contact_bench_n<N>_{auto,sp,auto_fp8}.json      python bench.py --gpus N: ONE JSON line each - the plan that ran (multi_gpu.plan,
 #                                                .failed_attempts), the K|V autotune table PER CANDIDATE (transport x {arrival-driven,
 #                                                4, 2 chunks}): two-layer time, raw exchange time -> receive GB/s and its fraction of the
 #                                                7 x 153 GB/s links, self-attention UNDER the real exchange next to the same launches
@@ -29,8 +29,9 @@ MODEL=${MODEL:-14b}
 EXTRA=(${EXTRA_BENCH_ARGS:-})                 # e.g. "--frames 17 --height 128 --width 160" for a quick rehearsal of this script
 TRACE_MODEL=${TRACE_MODEL:-1.3b}
 echo "== first contact: N = $N ranks, model $MODEL, records under $OUT"
-for layout in auto sp; do
-  env "${SHARE[@]}" timeout 1500 python bench.py --gpus "$N" --model "$MODEL" "${EXTRA[@]}" --steps 5 --warmup 2 --parallelism $layout --no-cpu-baseline \
+for layout in auto sp auto_fp8; do          # auto_fp8: config #5's e4m3 mode (e4m3 blobs on the wire; its "+arrival" candidates gate the chunk launches in the kernel)
+  DT=(); [[ $layout == auto_fp8 ]] && DT=(--gemm-dtype fp8 --attn-dtype fp8)
+  env "${SHARE[@]}" timeout 1500 python bench.py --gpus "$N" --model "$MODEL" "${EXTRA[@]}" "${DT[@]}" --steps 5 --warmup 2 --parallelism ${layout%_fp8} --no-cpu-baseline \
     2> "$OUT/first_contact_bench_n${N}_${layout}.stderr.txt" | tail -1 > "$OUT/first_contact_bench_n${N}_${layout}.json"
   python - "$OUT/first_contact_bench_n${N}_${layout}.json" <<'PY'
 import json, sys

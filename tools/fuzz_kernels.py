@@ -371,7 +371,7 @@ def fuzz_attention_pieces():
             fails.append(what + ": tile-aligned pieces in memory order differ from the plain launch")
 
 
-SIDE = torch.cuda.Stream(device=DEV)
+SIDE = torch.cuda.Stream(device=DEV, priority=-1)      # see profiles/r06/stream_queue_share_probe.txt
 t0, n = time.time(), {"gemm": 0, "attention": 0, "gemm_fp8": 0, "attention_fp8": 0, "conv": 0, "fp8_pieces": 0, "pieces": 0}
 R6_TOO = os.environ.get("FUZZ_R6", "0") == "1"       # FUZZ_R6=1 adds round 6's entry point: the arrival-driven attention over pieces
 R5_TOO = os.environ.get("FUZZ_R5", "0") == "1"       # FUZZ_R5=1 adds round 5's entry points: the convolution and the e4m3 pieces
