@@ -497,8 +497,10 @@ def run_rank(args, world, rank, phase, stdout_fd):
                 return t.tolist()
 
             t_tune = time.perf_counter()
-            # per transport: the arrival-driven attention (one launch per layer; bf16 attention only) and the chunked launches
-            arrival = [("+arrival", args.sp_chunks)] if (args.attn_dtype == "bf16" and os.environ.get("ICV_ATTN_ARRIVAL") != "0") else []
+            # per transport: the arrival-driven attention (bf16: one launch per layer; e4m3 blobs on the wire: the chunk launches gate on their
+            # blobs inside the kernel) and the host-waited chunk launches
+            arrival = [("+arrival", args.sp_chunks)] if ((args.attn_dtype == "bf16" or getattr(model, "fp8_wire", False))
+                                                          and os.environ.get("ICV_ATTN_ARRIVAL") != "0") else []
             cands = [(m + sfx, c) for m in ("allgather", "p2p", "native", "ipc")
                      for sfx, c in arrival + [("", c) for c in sorted({args.sp_chunks, 2}, reverse=True)]]
             if share:      # several ranks on ONE GPU (development boxes): RCCL refuses duplicate devices in a communicator
@@ -513,7 +515,7 @@ def run_rank(args, world, rank, phase, stdout_fd):
                     are already there: the difference is what the transfer exposes PLUS what its data movement costs the kernel beside it;
                   ipc_peer_copy - does a pull from the right-hand neighbour need compute units (icv_ipc_probe_copy: blit kernel) or not
                     (copy engine)?  Nothing in a timing table would tell."""
-                if model.attn_fp8:
+                if model.attn_fp8 and not getattr(model, "fp8_wire", False):
                     return {}
                 H, q = cfg.num_heads, model.qkv[0]
                 out = {}

@@ -373,9 +373,9 @@ class WanVideoPipeline:
             engine.forward_tokens(latent, ctx, 500.0, buf_tokens, engine.head_own, num_layers=min(2, engine.cfg.num_layers))
 
         modes = ("allgather", "p2p", "native", "ipc") if on_dev else ("allgather", "p2p")
-        # per transport: ONE arrival-gated attention launch per layer (dit.ARRIVAL_SUFFIX; bf16 attention only) and the chunked
+        # per transport: ONE arrival-gated attention launch per layer (dit.ARRIVAL_SUFFIX; in the e4m3 mode with e4m3 blobs on the wire: the chunk launches gate on their blobs in the kernel) and the chunked
         # carried-state launches with sp_chunks and with 2 chunks
-        arrival = [] if (engine.attn_fp8 or os.environ.get("ICV_ATTN_ARRIVAL") == "0") else ["+arrival"]
+        arrival = [] if ((engine.attn_fp8 and not getattr(engine, "fp8_wire", False)) or os.environ.get("ICV_ATTN_ARRIVAL") == "0") else ["+arrival"]
         cands = [(m + sfx, c) for m in modes for sfx, c in [(a, self.sp_chunks) for a in arrival] + [("", c) for c in sorted({self.sp_chunks, 2}, reverse=True)]]
         t0 = time.perf_counter()
         best, table = autotune_kv_exchange(engine, two_layers, sync, cands, reps=2, reduce_max=reduce_max)
