@@ -307,6 +307,62 @@ def fuzz_attention_fp8_pieces():
         fails.append(f"{what}: rms err {err:.3g} vs rms {rms:.3g}")
 
 
+def fuzz_attention_fp8_pieces_gated():
+    """round 6, the arrival gate of the e4m3 chunk launch (icv_attention_fp8_fwd_pieces_gated): a random walk order with the 'own' blob read from
+    another tensor (its slot holds NaN bytes), a random subset of the other blobs delivered by a side stream AFTER the launch (copy, then
+    flag): must equal the all-present launch in the same order bit for bit, stay inside the e4m3 noise bar, and nobody may time out."""
+    H, W = rng.choice([1, 2, 3]), rng.choice([1, 2, 3, 4, 8])
+    m = 64 * rng.randint(1, 12) if rng.random() < 0.5 else rng.randint(1, 700)
+    Sq = rng.choice([1, 33, 256, 257, 300]) if rng.random() < 0.7 else rng.randint(1, 900)
+    d, Skv = H * 128, m * W
+    g = torch.Generator(device=DEV).manual_seed(rng.randint(0, 2 ** 31))
+    q = torch.randn((Sq, d), device=DEV, generator=g).to(torch.bfloat16)
+    k = (torch.randn((Skv, d), device=DEV, generator=g) * (128 ** -0.5 * math.log2(math.e))).to(torch.bfloat16)
+    v = torch.randn((Skv, d), device=DEV, generator=g).to(torch.bfloat16)
+    ws = ops.attention_fp8_buffers(Sq, Skv, d, H)
+    amax = torch.zeros((3, H), device=DEV)
+    ops.attention_fp8_kv_amax(k, v, H, amax)
+    bb = ops.attention_fp8_blob_bytes(m, H)
+    blobs = torch.empty((W * bb,), dtype=torch.uint8, device=DEV)
+    for i in range(W):
+        ops.attention_fp8_quantize_kv(k[i * m:(i + 1) * m], v[i * m:(i + 1) * m], H, amax, blobs[i * bb:(i + 1) * bb])
+    ws2 = ops.attention_fp8_with_amax(ws, amax)
+    ops.attention_fp8_prepare(ws2, H, q=q)
+    own = rng.randrange(W)
+    order = [own] + rng.sample([i for i in range(W) if i != own], W - 1)
+    own_blob = blobs[own * bb:(own + 1) * bb].clone()
+    staged = blobs.clone()
+    blobs[own * bb:(own + 1) * bb] = 0x7F
+    want = torch.zeros((Sq, d), dtype=torch.bfloat16, device=DEV)
+    ops.attention_fp8_pieces(ws2, amax, blobs, m, W, Sq, want, None, None, H, first=True, last=True,
+                             gate=dict(seq=[(i, -1, 0) for i in order], own=(own_blob, own)))
+    late = [i for i in order[1:] if rng.random() < 0.5]
+    flags = torch.zeros((W + 1,), dtype=torch.int32, device=DEV)
+    err = torch.zeros((1,), dtype=torch.int32, device=DEV)
+    for i in late:
+        blobs[i * bb:(i + 1) * bb] = 0x7F
+    torch.cuda.synchronize()
+    o = torch.zeros_like(want)
+    ops.attention_fp8_pieces(ws2, amax, blobs, m, W, Sq, o, None, None, H, first=True, last=True,
+                             gate=dict(seq=[(i, i if i in late else -1, 5 if i in late else 0) for i in order], flags=flags, own=(own_blob, own), err=err,
+                                       timeout_us=5_000_000))
+    with torch.cuda.stream(SIDE):
+        for i in rng.sample(late, len(late)):           # any delivery order
+            blobs[i * bb:(i + 1) * bb].copy_(staged[i * bb:(i + 1) * bb])
+            ops.flag_write(flags, i, 5, delay_us=rng.choice([0, 0, 200]))
+    torch.cuda.synchronize()
+    what = f"attention_fp8_pieces_gated Sq={Sq} m={m} W={W} H={H} order={order} late={late}"
+    if int(err.item()) != 0:
+        fails.append(what + f": a wave gave up waiting (err {int(err.item()) & 0xffffffff:#x})")
+    if not torch.equal(o, want):
+        fails.append(what + ": late blobs change the result")
+    ref = ref_attention(q, k, v, H, math.log(2.0))
+    rms = float(ref.pow(2).mean().sqrt())
+    e = float((o.float() - ref).pow(2).mean().sqrt())
+    if not torch.isfinite(o.float()).all() or e > fp8_noise_bar(Sq * H) * rms:
+        fails.append(f"{what}: rms err {e:.3g} vs rms {rms:.3g}")
+
+
 def fuzz_attention_pieces():
     """round 6's arrival-driven launch (icv_attention_fwd_pieces): random piece lists (ragged, one-row, empty, out of memory order) over K|V
     rows held as ONE [S, 2d] matrix; some pieces gated on flags that a side stream raises AFTER the launch (rows copied in late).  Tile-aligned
@@ -372,14 +428,17 @@ def fuzz_attention_pieces():
 
 
 SIDE = torch.cuda.Stream(device=DEV, priority=-1)      # see profiles/r06/stream_queue_share_probe.txt
-t0, n = time.time(), {"gemm": 0, "attention": 0, "gemm_fp8": 0, "attention_fp8": 0, "conv": 0, "fp8_pieces": 0, "pieces": 0}
+t0, n = time.time(), {"gemm": 0, "attention": 0, "gemm_fp8": 0, "attention_fp8": 0, "conv": 0, "fp8_pieces": 0, "pieces": 0, "fp8_gated": 0}
 R6_TOO = os.environ.get("FUZZ_R6", "0") == "1"       # FUZZ_R6=1 adds round 6's entry point: the arrival-driven attention over pieces
 R5_TOO = os.environ.get("FUZZ_R5", "0") == "1"       # FUZZ_R5=1 adds round 5's entry points: the convolution and the e4m3 pieces
 FP8_TOO = os.environ.get("FUZZ_FP8", "0") == "1"     # FUZZ_FP8=1 adds the e4m3 entry points (a different case sequence)
 try:
     while (sum(n.values()) < max_cases) if max_cases > 0 else (time.time() - t0 < budget):
         if R6_TOO and rng.random() < 0.5:
-            fuzz_attention_pieces(); n["pieces"] += 1
+            if FP8_TOO and rng.random() < 0.3:
+                fuzz_attention_fp8_pieces_gated(); n["fp8_gated"] += 1
+            else:
+                fuzz_attention_pieces(); n["pieces"] += 1
         elif R5_TOO and rng.random() < 0.5:
             if rng.random() < 0.6:
                 fuzz_conv(); n["conv"] += 1
@@ -405,5 +464,6 @@ print(f"fuzz seed {seed}: {n['gemm']} GEMM cases, {n['attention']} attention cas
       (f", {n['gemm_fp8']} e4m3 GEMM cases, {n['attention_fp8']} e4m3 attention cases" if FP8_TOO else "") +
       (f", {n['conv']} convolution cases, {n['fp8_pieces']} e4m3-pieces cases" if R5_TOO else "") +
       (f", {n['pieces']} arrival-driven attention (pieces) cases" if os.environ.get("FUZZ_R6", "0") == "1" else "") +
+      (f", {n['fp8_gated']} arrival-gated e4m3 pieces cases" if (R6_TOO and FP8_TOO) else "") +
       f" in {time.time() - t0:.0f} s, {len(fails)} failures")
 sys.exit(1 if fails else 0)
