@@ -183,12 +183,13 @@ __device__ __forceinline__ i32x8 read32(const char* p0, const char* p1) {
   return (i32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-// VAR bit flags: 256 = arrival-gated pieces (with 32), 32 = software-pipelined key loop (S(t+1) and O += V(t-1)P(t-1) issued around tile t's softmax; implies 8), 64 = its row sums on
+// VAR bit flags: 512 = one barrier per two key tiles on an 8-stage ring (with 32), 256 = arrival-gated pieces (with 32), 32 = software-pipelined key loop (S(t+1) and O += V(t-1)P(t-1) issued around tile t's softmax; implies 8), 64 = its row sums on
 // packed adds, 1 = wave groups one tile apart, 4 = s_setprio(1) around MFMA clusters, 8 = lean vector work (LDS-DMA addresses as
 // scalar base + constant lane offset, row sums on packed fp32 adds)
 template <int VAR>
 __global__ __launch_bounds__(512) void attn8_kernel(Params p) {
-  constexpr bool STAGGER = VAR & 1, SETPRIO = VAR & 4, PIPE = VAR & 32, LEAN = (VAR & 8) || PIPE, PKADD = VAR & 64, PFD2 = VAR & 128, GATE = VAR & 256;
+  constexpr bool STAGGER = VAR & 1, SETPRIO = VAR & 4, PIPE = VAR & 32, LEAN = (VAR & 8) || PIPE, PKADD = VAR & 64, PFD2 = VAR & 128, GATE = VAR & 256, TWO = VAR & 512;
+  constexpr int NSTG = TWO ? 8 : NSTAGE;       // TWO (with 32): 8-stage ring, ONE vmcnt(0) + barrier per TWO key tiles
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(512) void attn8_kernel(Params p) {
   }
 #define A8_DMA_TILE(T_)                                                                              \
   if (PIPE) {                                                                                        \
-    const unsigned l0_ = lds_base + (unsigned)(((T_) & (NSTAGE - 1)) * STAGE_BYTES + wave * 1024);   \
+    const unsigned l0_ = lds_base + (unsigned)(((T_) & (NSTG - 1)) * STAGE_BYTES + wave * 1024);     \
     dma16s(kp_, d_tl == p.tpp - 1 ? koff_rag : koff_full, l0_);                                      \
     dma16s(vp_, voff, l0_ + KT_BYTES);                                                               \
     if ((T_) < nt - 1) {                                                                             \
@@ -376,18 +377,19 @@ __global__ __launch_bounds__(512) void attn8_kernel(Params p) {
       const i32x8 vf = read32(rowp + (((2 * hi) ^ v_sw0) << 4), rowp + (((2 * hi + 1) ^ v_sw0) << 4));                           \
       ot[d0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, PF_, ot[d0], 0, 0, 0, sV, 0, 127);                            \
     }
-    // V of "tile -1" (stage NSTAGE-1) = zeros: the first iteration's O += V(-1) P(-1) adds 0 x 0 instead of branching around it
-    *reinterpret_cast<i32x4*>(smem + (NSTAGE - 1) * STAGE_BYTES + KT_BYTES + tid * 16) = (i32x4){0, 0, 0, 0};
+    // V of "tile -1" (the last stage) = zeros: the first iteration's O += V(-1) P(-1) adds 0 x 0 instead of branching around it
+    *reinterpret_cast<i32x4*>(smem + (NSTG - 1) * STAGE_BYTES + KT_BYTES + tid * 16) = (i32x4){0, 0, 0, 0};
     A8_DMA_TILE(0);
     A8_DMA_TILE(1);
+    if (TWO) A8_DMA_TILE(2);          // TWO: a pair (t, t+1) reads K(t+1), K(t+2), V(t-1), V(t) - tiles <= t + 2 are there when it starts
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     A8_BARRIER();
     f32x16 stx[2][2];
     i32x8 pfx[2] = {pf, pf};
     A8_QK(0, stx[0]);
-    for (int t4 = 0; t4 < nt; t4 += NSTAGE) {
+    for (int t4 = 0; t4 < nt; t4 += NSTG) {
 #pragma unroll
-      for (int ti = 0; ti < NSTAGE; ++ti) {
+      for (int ti = 0; ti < NSTG; ++ti) {
         const int t = t4 + ti;
         if (t >= nt) break;
         f32x16(&st)[2] = stx[ti & 1];
@@ -406,7 +408,12 @@ __global__ __launch_bounds__(512) void attn8_kernel(Params p) {
               if (key >= p.piece_rows) st[kb][r] = NEG_BIG;
             }
         }
-        A8_DMA_TILE(t + 2);
+        if (!TWO) {
+          A8_DMA_TILE(t + 2);
+        } else if ((ti & 1) == 0) {      // requested at the top of the pair into the stages V(t-5), V(t-4) left two pairs ago
+          A8_DMA_TILE(t + 3);
+          A8_DMA_TILE(t + 4);
+        }
         const bool no_ref = m_run < -1.0e29f;
         // ---- the pipelined block: 8 segments = one MFMA each (S(t+1): two first halves, two of O += V(t-1) P(t-1), S(t+1): second
         // halves - four MFMAs after the ones they accumulate on - , the other two of O), the NEXT segment's fragment read, and a tenth of
@@ -416,8 +423,8 @@ __global__ __launch_bounds__(512) void attn8_kernel(Params p) {
         f32x2 ps2 = {0.f, 0.f};
         i32x8& pn = pfx[ti & 1];
         const i32x8 pp = pfx[(ti + 1) & 1];
-        const char* const kst = smem + ((ti + 1) & (NSTAGE - 1)) * STAGE_BYTES + k_row;
-        const char* const vst = smem + ((ti + NSTAGE - 1) & (NSTAGE - 1)) * STAGE_BYTES + KT_BYTES + l31 * 64;
+        const char* const kst = smem + ((ti + 1) & (NSTG - 1)) * STAGE_BYTES + k_row;
+        const char* const vst = smem + ((ti + NSTG - 1) & (NSTG - 1)) * STAGE_BYTES + KT_BYTES + l31 * 64;
         auto frag = [&](int g) -> i32x8 {
           if (g == 0 || g == 1 || g == 4 || g == 5) {           // K fragment: key block kb = g & 1, k-step s = g >> 2
             const int c0 = 4 * (g >> 2) + 2 * hi;
@@ -491,12 +498,15 @@ __global__ __launch_bounds__(512) void attn8_kernel(Params p) {
             for (int r = 0; r < 16; r += 4) pn[kb * 4 + (r >> 2)] = pack_fp8x4_over(pv[kb][r], pv[kb][r + 1], pv[kb][r + 2], pv[kb][r + 3], pn[kb * 4 + (r >> 2)]);
         }
         l_run += ps;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        A8_BARRIER();
+        if (!TWO || (ti & 1)) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          A8_BARRIER();
+        }
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (TWO, odd tile count: the last pair's requests were not waited for)
     {                                                   // the last tile's O += V P
-      const int lt = (nt - 1) & (NSTAGE - 1);
+      const int lt = (nt - 1) & (NSTG - 1);
       i32x8 pl;
 #pragma unroll
       for (int i = 0; i < 8; ++i) pl[i] = ((nt - 1) & 1) ? pfx[1][i] : pfx[0][i];
@@ -626,9 +636,10 @@ __global__ __launch_bounds__(512) void attn8_kernel(Params p) {
 template <int VAR>
 int launch(const Params& p, hipStream_t st) {
   static icv_dev_flags attr_set = {};
-  if (int rc = icv_ensure_dynamic_lds((const void*)attn8_kernel<VAR>, LDS_BYTES, &attr_set, "attn8")) return rc;
+  constexpr int lds = ((VAR & 512) ? 8 : NSTAGE) * STAGE_BYTES;
+  if (int rc = icv_ensure_dynamic_lds((const void*)attn8_kernel<VAR>, lds, &attr_set, "attn8")) return rc;
   const int64_t nwg = (int64_t)p.heads * p.nqb;
-  hipLaunchKernelGGL(attn8_kernel<VAR>, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p);
+  hipLaunchKernelGGL(attn8_kernel<VAR>, dim3((unsigned)nwg), dim3(512), lds, st, p);
   return icv_check_launch("icv_attention_fp8_fwd");
 }
 
@@ -709,6 +720,7 @@ static int attn8_run(const void* qq, int64_t ldqq, const void* kq, int64_t ldkq,
     case 36: return att8::launch<36>(p, st);
     case 160: return att8::launch<160>(p, st);
     case 164: return att8::launch<164>(p, st);
+    case 676: return att8::launch<676>(p, st);
   }
   icv_set_error("icv_attention_fp8_fwd: unknown attn8_variant");
   return 1;
