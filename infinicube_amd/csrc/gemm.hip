@@ -194,8 +194,21 @@ extern "C" int icv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t 
   ICV_REQUIRE(N < (1LL << 31), "icv_gemm_bf16: N=%lld too large", (long long)N);
   ICV_REQUIRE(N % 4 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldo % 4 == 0, "icv_gemm_bf16: N%%4, lda%%8, ldw%%8, ldo%%4 alignment");
   // both kernels keep per-lane A / W source offsets as 32-bit byte offsets from the operand base
-  ICV_REQUIRE((double)M * (double)lda * 2.0 < 4294967296.0 && (double)N * (double)ldw * 2.0 < 4294967296.0,
-              "icv_gemm_bf16: operand spans >= 4 GiB (M*lda or N*ldw): split the rows");
+  ICV_REQUIRE((double)N * (double)ldw * 2.0 < 4294967296.0, "icv_gemm_bf16: the weight operand spans >= 4 GiB (N*ldw)");
+  if ((double)M * (double)lda * 2.0 >= 4294967296.0) {
+    // an A operand of >= 4 GiB (e.g. both CFG forwards of a 720p clip as one FFN2 launch: 172 800 rows x 13 824): the same launch over
+    // row ranges of < 4 GiB each, cut on the 256-row tile grid (round 6; it used to be an error asking the caller to split)
+    const int64_t max_rows = (int64_t)(4294967295.0 / ((double)lda * 2.0)) / 256 * 256;
+    ICV_REQUIRE(max_rows >= 256, "icv_gemm_bf16: lda=%lld too large", (long long)lda);
+    const int64_t out_elem = (epilogue == ICV_EPI_BF16 || epilogue == ICV_EPI_GELU_BF16) ? 2 : 4;
+    for (int64_t m0 = 0; m0 < M; m0 += max_rows) {
+      const int64_t rows = M - m0 < max_rows ? M - m0 : max_rows;
+      if (int rc = icv_gemm_bf16((const char*)A + m0 * lda * 2, lda, W, ldw, bias, rows, N, K, epilogue, (char*)out + m0 * ldo * out_elem, ldo, nsplit,
+                                 split_stride, resid ? resid + m0 * ldr : nullptr, ldr, gate, stream))
+        return rc;
+    }
+    return 0;
+  }
   if (nsplit <= 0) nsplit = N;
   ICV_REQUIRE(nsplit % 4 == 0 && N % nsplit == 0, "icv_gemm_bf16: nsplit must divide N and be a multiple of 4");
   ICV_REQUIRE(epilogue != ICV_EPI_RESID_F32 || (resid && ldr % 4 == 0 && nsplit == N), "icv_gemm_bf16: RESID epilogue needs resid, ldr%%4==0, no split");

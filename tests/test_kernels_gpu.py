@@ -1187,6 +1187,29 @@ def test_gemm_persistent_under_graph_capture_and_on_two_streams(hip_ops):
     assert torch.equal(o1, ref) and torch.equal(o2, ref), "concurrent persistent launches on two streams"
 
 
+def test_gemm_a_operand_of_more_than_4_gib(hip_ops):
+    """A lane's A-row position is a 32-bit byte offset from the operand base: icv_gemm_bf16 runs an A operand of >= 4 GiB (here 160 256 rows x
+    13 824 = 4.43 GB: FFN2 of both CFG forwards of a long 720p clip) as row ranges cut on the 256-row tile grid.  Rows on both sides of the cut
+    (155 136) and the ragged tail against fp32 torch, for the gated-residual and the bf16 epilogue."""
+    M, N, K = 160256, 256, 13824
+    g = torch.Generator(device=DEV).manual_seed(77)
+    a = torch.empty((M, K), dtype=torch.bfloat16, device=DEV)
+    for r0 in range(0, M, 20032):                                                  # filled in slabs: no fp32 copy of the whole operand
+        a[r0:r0 + 20032] = torch.randn((min(20032, M - r0), K), device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn((N, K), device=DEV, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    bias = torch.randn((N,), device=DEV, generator=g) * 0.1
+    gate = torch.randn((N,), device=DEV, generator=g)
+    resid = torch.randn((M, N), device=DEV, generator=g)
+    rows = torch.cat([torch.arange(0, 300), torch.arange(155136 - 300, 155136 + 300), torch.arange(M - 300, M)]).to(DEV)
+    want = a[rows].float() @ w.float().t() + bias
+    out = resid.clone()
+    hip_ops.gemm(a, w, bias, out, EPI_RESID_F32, resid=out, gate=gate)
+    assert_f32_close(out[rows], resid[rows] + gate * want, rtol=3e-4, what="gemm, A > 4 GiB, gated residual")
+    ob = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    hip_ops.gemm(a, w, bias, ob, EPI_BF16)
+    assert_bf16_close(ob[rows], want, "gemm, A > 4 GiB, bf16 epilogue")
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 4, 64), (3, 68, 64), (255, 252, 192), (257, 260, 128), (513, 256, 64)])
 def test_gemm_ragged_shapes(hip_ops, M, N, K):
     a = rnd((M, K), 311).to(torch.bfloat16)
